@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI (include/dsm_hotpath.h) -- the only way the Python host side reaches
+the device.  There is no CPU fallback: if the HIP library is missing or no GPU is present the
+failure is loud (ImportError / DsmError)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdsm_hotpath.so")
+MAX_LEVELS = 6
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_int64_p = C.POINTER(C.c_int64)
+NO_CANDIDATE = 0x7FFFFFFFFFFFFFFF
+
+
+class DsmError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("huber_th", C.c_float),
+        ("coarse_cutoff_th", C.c_float),
+        ("scale_xi_rot", C.c_float),
+        ("scale_xi_trans", C.c_float),
+        ("scale_a", C.c_float),
+        ("scale_b", C.c_float),
+        ("affine_opt_mode_a", C.c_float),
+        ("affine_opt_mode_b", C.c_float),
+        ("lambda_extrapolation_limit", C.c_float),
+        ("max_iterations", C.c_int * MAX_LEVELS),
+        ("poll_chunk", C.c_int),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("evals", C.c_int64 * MAX_LEVELS),
+        ("launches", C.c_int64 * MAX_LEVELS),
+        ("algorithmic_bytes", C.c_int64),
+        ("eval_kernel_ms", C.c_double * MAX_LEVELS),
+        ("total_ms", C.c_double),
+        ("polls", C.c_int64),
+    ]
+
+
+# every symbol include/dsm_hotpath.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_pp_f = C.POINTER(c_float_p)
+_pp_i = C.POINTER(c_int_p)
+_pp_d = C.POINTER(c_double_p)
+SYMBOLS = {
+    "dsm_last_error": (C.c_char_p, []),
+    "dsm_abi_version": (C.c_int, []),
+    "dsm_params_default": (None, [C.POINTER(Params)]),
+    "dsm_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "dsm_context_destroy": (C.c_int, [_vp]),
+    "dsm_context_sync": (C.c_int, [_vp]),
+    "dsm_context_set_timing": (C.c_int, [_vp, C.c_int]),
+    "dsm_context_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "dsm_context_stream": (_vp, [_vp]),
+    "dsm_tracker_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p, c_float_p, C.POINTER(Params), C.POINTER(_vp)]),
+    "dsm_tracker_destroy": (C.c_int, [_vp]),
+    "dsm_tracker_make_k": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "dsm_tracker_set_ref": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_float, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
+    "dsm_tracker_scale_depth": (C.c_int, [_vp, C.c_float]),
+    "dsm_tracker_get_template": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "dsm_tracker_upload_frame": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
+    "dsm_tracker_upload_image": (C.c_int, [_vp, C.c_int, c_float_p, C.c_float]),
+    "dsm_tracker_get_frame": (C.c_int, [_vp, C.c_int, C.c_int, c_float_p]),
+    "dsm_tracker_calc_res_pose": (C.c_int, [_vp, C.c_int, c_double_p, c_double_p, C.c_float, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "dsm_tracker_calc_res_scale": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, c_double_p, c_float_p, c_float_p, c_int_p]),
+    "dsm_tracker_track": (C.c_int, [_vp, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "dsm_tracker_optimize_scale": (C.c_int, [_vp, c_float_p, C.c_int, c_float_p]),
+    "dsm_track_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
+    "dsm_optimize_scale_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_float_p, C.c_int, c_float_p]),
+    "dsm_tracker_ref_frame_id": (C.c_int, [_vp]),
+    "dsm_reduction_geometry": (C.c_int, [_vp, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "dsm_ringdb_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dsm_ringdb_destroy": (C.c_int, [_vp]),
+    "dsm_ringdb_size": (C.c_int64, [_vp]),
+    "dsm_ringdb_query_then_enqueue": (C.c_int, [_vp, c_float_p, c_int_p, c_int_p]),
+    "dsm_ringdb_add_points": (C.c_int, [_vp, c_float_p, C.c_int64]),
+    "dsm_ringdb_enqueue": (C.c_int, [_vp, c_float_p]),
+    "dsm_ringdb_knn_packed": (C.c_int, [_vp, c_float_p, C.c_int, _vp]),
+    "dsm_ringdb_knn_packed_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "dsm_ringdb_knn_packed_host": (C.c_int, [_vp, c_float_p, C.c_int, c_int64_p]),
+    "dsm_sc_distance": (C.c_float, [c_int_p, c_double_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
+    "dsm_search_sc": (C.c_int, [c_int_p, c_double_p, C.c_int, C.c_int, c_int_p, _pp_i, _pp_d, c_int_p, C.c_int, c_int_p, c_float_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdsm_hotpath.so (built by __graft_entry__.build()).  Raises ImportError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().dsm_last_error()
+        raise DsmError(f"dsm error {rc}: {msg.decode() if msg else ''}")

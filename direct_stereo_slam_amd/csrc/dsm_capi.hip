@@ -1,0 +1,727 @@
+// dsm_capi.hip -- C ABI (include/dsm_hotpath.h) of the tracker / scale-optimiser hot path.
+// Host side only orchestrates: uploads, launch sequencing of the LM state machine, read-back.
+// All arithmetic of the path runs in the HIP kernels of tracker_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "dsm_internal.hpp"
+
+namespace dsm {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  g_err = buf;
+  return DSM_ERR_HIP;
+}
+
+static int invalid(const char *msg) {
+  set_error(msg);
+  return DSM_ERR_INVALID;
+}
+
+int ensure_stage(dsm_context *ctx, size_t floats) {
+  if (floats <= ctx->stage_floats) return DSM_OK;
+  if (ctx->d_stage) DSM_HIP(hipFree(ctx->d_stage));
+  ctx->d_stage = nullptr;
+  ctx->stage_floats = 0;
+  DSM_HIP(hipMalloc(&ctx->d_stage, floats * sizeof(float)));
+  ctx->stage_floats = floats;
+  return DSM_OK;
+}
+
+template <typename T>
+static int realloc_dev(T **p, size_t n) {
+  if (*p) DSM_HIP(hipFree(*p));
+  *p = nullptr;
+  DSM_HIP(hipMalloc(p, n * sizeof(T)));
+  return DSM_OK;
+}
+template <typename T>
+static int realloc_pinned(T **p, size_t n) {
+  if (*p) DSM_HIP(hipHostFree(*p));
+  *p = nullptr;
+  DSM_HIP(hipHostMalloc(p, n * sizeof(T), hipHostMallocDefault));
+  return DSM_OK;
+}
+
+int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride) {
+  if (nprob <= ctx->cap_prob && partial_stride <= ctx->partial_stride) return DSM_OK;
+  const int cap = nprob > ctx->cap_prob ? nprob : ctx->cap_prob;
+  const int ps = partial_stride > ctx->partial_stride ? partial_stride : ctx->partial_stride;
+  int rc;
+  if ((rc = realloc_dev(&ctx->d_tracker_ptrs, cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_tracker_ptrs, cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_states, cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_states, cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_partials, (size_t)cap * ps))) return rc;
+  if ((rc = realloc_dev(&ctx->d_start, cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_start, cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_single, cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_single, cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_status, 2 * (size_t)cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_status, 2 * (size_t)cap))) return rc;
+  DSM_HIP(hipMemsetAsync(ctx->d_states, 0, sizeof(LMState) * cap, ctx->stream));
+  ctx->cap_prob = cap;
+  ctx->partial_stride = ps;
+  return DSM_OK;
+}
+
+int sync_desc(dsm_tracker *t) {
+  if (!t->desc_dirty) return DSM_OK;
+  DSM_HIP(hipMemcpyAsync(t->d_desc, &t->desc, sizeof(TrackerDev), hipMemcpyHostToDevice, t->ctx->stream));
+  // the host copy may change again before the copy engine reads it
+  DSM_HIP(hipStreamSynchronize(t->ctx->stream));
+  t->desc_dirty = false;
+  return DSM_OK;
+}
+
+// ---- small host math (float, contraction off): makeK, TrackerAndScaler.cpp:117-141 ----
+static float cof3(const float *m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+static void mat3f_inverse(const float *m, float *r) { // Eigen Matrix3f::inverse(), cofactor form
+  const float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  const float det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+  const float invdet = 1.0f / det;
+  r[0] = c0 * invdet;
+  r[1] = c1 * invdet;
+  r[2] = c2 * invdet;
+  r[3] = cof3(m, 0, 1) * invdet;
+  r[4] = cof3(m, 1, 1) * invdet;
+  r[5] = cof3(m, 2, 1) * invdet;
+  r[6] = cof3(m, 0, 2) * invdet;
+  r[7] = cof3(m, 1, 2) * invdet;
+  r[8] = cof3(m, 2, 2) * invdet;
+}
+
+// SE3(Matrix4d) of Sophus/Eigen for tfm_f1_f0_ (TrackerAndScaler.cpp:82-86)
+static void se3_from_matrix(const double T[16], double pose[7]) {
+  const double M[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+  double q[4];
+  double t = M[0][0] + M[1][1] + M[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (M[2][1] - M[1][2]) * t;
+    q[1] = (M[0][2] - M[2][0]) * t;
+    q[2] = (M[1][0] - M[0][1]) * t;
+  } else {
+    int i = 0;
+    if (M[1][1] > M[0][0]) i = 1;
+    if (M[2][2] > M[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(M[i][i] - M[j][j] - M[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (M[k][j] - M[j][k]) * t;
+    q[j] = (M[j][i] + M[i][j]) * t;
+    q[k] = (M[k][i] + M[i][k]) * t;
+  }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) pose[i] = q[i] / n;
+  pose[4] = T[3];
+  pose[5] = T[7];
+  pose[6] = T[11];
+}
+
+static int default_layout() {
+  const char *e = getenv("DSM_IMG_LAYOUT");
+  if (e && !strcmp(e, "aos4")) return IMG_AOS4;
+  if (e && !strcmp(e, "aos3")) return IMG_AOS3;
+  return IMG_AOS3;
+}
+
+static int texel_floats(int layout) { return layout == IMG_AOS3 ? 3 : 4; }
+
+static int round8(int x) { return (x + 7) & ~7; }
+
+// record an event pair around a launch when timing is on
+struct EvSlot {
+  hipEvent_t a, b;
+  int lvl;
+};
+
+} // namespace dsm
+
+using namespace dsm;
+
+extern "C" {
+
+const char *dsm_last_error(void) { return g_err.c_str(); }
+int dsm_abi_version(void) { return DSM_ABI_VERSION; }
+
+void dsm_params_default(dsm_params *p) {
+  p->huber_th = 9.0f;
+  p->coarse_cutoff_th = 20.0f;
+  p->scale_xi_rot = 1.0f;
+  p->scale_xi_trans = 0.5f;
+  p->scale_a = 10.0f;
+  p->scale_b = 1000.0f;
+  p->affine_opt_mode_a = 0.0f;
+  p->affine_opt_mode_b = 0.0f;
+  p->lambda_extrapolation_limit = 0.001f;
+  const int it[DSM_MAX_LEVELS] = {10, 20, 50, 50, 50, 50};
+  memcpy(p->max_iterations, it, sizeof it);
+  p->poll_chunk = 4;
+}
+
+int dsm_context_create(int device_ordinal, dsm_context **out) {
+  if (!out) return invalid("dsm_context_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: this library has no CPU fallback");
+    return DSM_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= ndev) return invalid("dsm_context_create: bad device ordinal");
+  DSM_HIP(hipSetDevice(device_ordinal));
+  dsm_context *ctx = new dsm_context();
+  ctx->device = device_ordinal;
+  DSM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  DSM_HIP(hipEventCreate(&ctx->ev_total[0]));
+  DSM_HIP(hipEventCreate(&ctx->ev_total[1]));
+  *out = ctx;
+  return DSM_OK;
+}
+
+int dsm_context_destroy(dsm_context *ctx) {
+  if (!ctx) return DSM_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->d_tracker_ptrs);
+  hipHostFree(ctx->h_tracker_ptrs);
+  hipFree(ctx->d_states);
+  hipHostFree(ctx->h_states);
+  hipFree(ctx->d_partials);
+  hipFree(ctx->d_start);
+  hipHostFree(ctx->h_start);
+  hipFree(ctx->d_single);
+  hipHostFree(ctx->h_single);
+  hipFree(ctx->d_status);
+  hipHostFree(ctx->h_status);
+  hipFree(ctx->d_stage);
+  for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
+  hipEventDestroy(ctx->ev_total[0]);
+  hipEventDestroy(ctx->ev_total[1]);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DSM_OK;
+}
+
+int dsm_context_sync(dsm_context *ctx) {
+  if (!ctx) return invalid("null context");
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+int dsm_context_set_timing(dsm_context *ctx, int enable) {
+  if (!ctx) return invalid("null context");
+  ctx->timing = enable != 0;
+  return DSM_OK;
+}
+int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out) {
+  if (!ctx || !out) return invalid("null argument");
+  *out = ctx->stats;
+  return DSM_OK;
+}
+void *dsm_context_stream(dsm_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- tracker ------------------------------------------------------------------------------
+int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
+                       const float K1[4], const dsm_params *params, dsm_tracker **out) {
+  if (!ctx || !out || !T_f1_f0 || !K1) return invalid("dsm_tracker_create: null argument");
+  if (nlevels < 1 || nlevels > DSM_MAX_LEVELS) return invalid("dsm_tracker_create: nlevels out of range");
+  if ((w >> (nlevels - 1)) < 8 || (h >> (nlevels - 1)) < 8) return invalid("dsm_tracker_create: image too small for nlevels");
+  DSM_HIP(hipSetDevice(ctx->device));
+  dsm_tracker *t = new dsm_tracker();
+  t->ctx = ctx;
+  t->w = w;
+  t->h = h;
+  t->nlevels = nlevels;
+  if (params)
+    t->params = *params;
+  else
+    dsm_params_default(&t->params);
+  TrackerDev &D = t->desc;
+  memset(&D, 0, sizeof D);
+  D.nlevels = nlevels;
+  D.layout = default_layout();
+  D.p.huber_th = t->params.huber_th;
+  D.p.coarse_cutoff_th = t->params.coarse_cutoff_th;
+  D.p.scale_xi_rot = t->params.scale_xi_rot;
+  D.p.scale_xi_trans = t->params.scale_xi_trans;
+  D.p.scale_a = t->params.scale_a;
+  D.p.scale_b = t->params.scale_b;
+  D.p.affine_opt_mode_a = t->params.affine_opt_mode_a;
+  D.p.affine_opt_mode_b = t->params.affine_opt_mode_b;
+  D.p.lambda_extrapolation_limit = t->params.lambda_extrapolation_limit;
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) D.p.max_iterations[l] = t->params.max_iterations[l];
+  se3_from_matrix(T_f1_f0, D.T10);
+  const int ts = texel_floats(D.layout);
+  for (int l = 0; l < nlevels; l++) { // TrackerAndScaler.cpp:52-64
+    const int wl = w >> l, hl = h >> l;
+    D.lv[l].w = wl;
+    D.lv[l].h = hl;
+    DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)wl * hl));
+    for (int s = 0; s < 2; s++) {
+      DSM_HIP(hipMalloc(&t->d_img[s][l], sizeof(float) * ts * (size_t)wl * hl));
+      DSM_HIP(hipMemsetAsync(t->d_img[s][l], 0, sizeof(float) * ts * (size_t)wl * hl, ctx->stream));
+      D.lv[l].img[s] = t->d_img[s][l];
+    }
+    D.lv[l].pts = t->d_pts[l];
+    D.lv[l].n = 0;
+  }
+  // camera 1 pyramid, :89-98
+  D.lv[0].fx1 = K1[0];
+  D.lv[0].fy1 = K1[1];
+  D.lv[0].cx1 = K1[2];
+  D.lv[0].cy1 = K1[3];
+  for (int l = 1; l < nlevels; l++) {
+    D.lv[l].fx1 = D.lv[l - 1].fx1 * 0.5;
+    D.lv[l].fy1 = D.lv[l - 1].fy1 * 0.5;
+    D.lv[l].cx1 = (D.lv[0].cx1 + 0.5) / ((int)1 << l) - 0.5;
+    D.lv[l].cy1 = (D.lv[0].cy1 + 0.5) / ((int)1 << l) - 0.5;
+  }
+  DSM_HIP(hipMalloc(&t->d_desc, sizeof(TrackerDev)));
+  t->desc_dirty = true;
+  *out = t;
+  return DSM_OK;
+}
+
+int dsm_tracker_destroy(dsm_tracker *t) {
+  if (!t) return DSM_OK;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  for (int l = 0; l < t->nlevels; l++) {
+    hipFree(t->d_pts[l]);
+    hipFree(t->d_img[0][l]);
+    hipFree(t->d_img[1][l]);
+  }
+  hipFree(t->d_desc);
+  delete t;
+  return DSM_OK;
+}
+
+int dsm_tracker_make_k(dsm_tracker *t, float fx, float fy, float cx, float cy) {
+  if (!t) return invalid("null tracker");
+  TrackerDev &D = t->desc;
+  D.lv[0].fx = fx;
+  D.lv[0].fy = fy;
+  D.lv[0].cx = cx;
+  D.lv[0].cy = cy;
+  for (int l = 1; l < t->nlevels; l++) { // :126-133
+    D.lv[l].fx = D.lv[l - 1].fx * 0.5;
+    D.lv[l].fy = D.lv[l - 1].fy * 0.5;
+    D.lv[l].cx = (D.lv[0].cx + 0.5) / ((int)1 << l) - 0.5;
+    D.lv[l].cy = (D.lv[0].cy + 0.5) / ((int)1 << l) - 0.5;
+  }
+  for (int l = 0; l < t->nlevels; l++) { // :135-140
+    const float K[9] = {D.lv[l].fx, 0.0f, D.lv[l].cx, 0.0f, D.lv[l].fy, D.lv[l].cy, 0.0f, 0.0f, 1.0f};
+    mat3f_inverse(K, D.lv[l].Ki);
+  }
+  t->have_k = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, double ref_aff_b,
+                        float ref_exposure, const int *n, const float *const *pc_u,
+                        const float *const *pc_v, const float *const *pc_idepth,
+                        const float *const *pc_color) {
+  if (!t || !n || !pc_u || !pc_v || !pc_idepth || !pc_color) return invalid("dsm_tracker_set_ref: null argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  for (int l = 0; l < t->nlevels; l++)
+    if (n[l] < 0 || n[l] > (t->w >> l) * (t->h >> l)) return invalid("dsm_tracker_set_ref: n[lvl] out of range");
+  int rc = ensure_stage(ctx, 4 * (size_t)t->w * t->h);
+  if (rc) return rc;
+  for (int l = 0; l < t->nlevels; l++) {
+    const size_t nl = n[l];
+    float *su = ctx->d_stage, *sv = su + nl, *si = sv + nl, *sc = si + nl;
+    if (nl) {
+      DSM_HIP(hipMemcpyAsync(su, pc_u[l], nl * 4, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(sv, pc_v[l], nl * 4, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(si, pc_idepth[l], nl * 4, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(sc, pc_color[l], nl * 4, hipMemcpyHostToDevice, ctx->stream));
+      launch_interleave_template(ctx->stream, (int)nl, su, sv, si, sc, t->d_pts[l]);
+    }
+    DSM_HIP(hipStreamSynchronize(ctx->stream)); // staging buffer is reused by the next level
+    t->desc.lv[l].n = (int)nl;
+  }
+  t->desc.ref_a = ref_aff_a; // :323-324
+  t->desc.ref_b = ref_aff_b;
+  t->desc.ref_exposure = ref_exposure;
+  t->ref_frame_id = ref_frame_id;
+  t->have_ref = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {
+  if (!t) return invalid("null tracker");
+  if (!t->have_ref) {
+    set_error("dsm_tracker_scale_depth before set_ref");
+    return DSM_ERR_STATE;
+  }
+  DSM_HIP(hipSetDevice(t->ctx->device));
+  for (int l = 0; l < t->nlevels; l++) launch_scale_depth(t->ctx->stream, t->desc.lv[l].n, t->d_pts[l], scale);
+  DSM_HIP(hipStreamSynchronize(t->ctx->stream));
+  return DSM_OK;
+}
+
+int dsm_tracker_get_template(dsm_tracker *t, int lvl, int *n, float *pc_u, float *pc_v, float *pc_idepth,
+                             float *pc_color) {
+  if (!t || !n || lvl < 0 || lvl >= t->nlevels) return invalid("dsm_tracker_get_template: bad argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const size_t nl = t->desc.lv[lvl].n;
+  *n = (int)nl;
+  if (!pc_u && !pc_v && !pc_idepth && !pc_color) return DSM_OK;
+  if (!pc_u || !pc_v || !pc_idepth || !pc_color) return invalid("dsm_tracker_get_template: all four outputs or none");
+  if (!nl) return DSM_OK;
+  int rc = ensure_stage(ctx, 4 * nl);
+  if (rc) return rc;
+  float *su = ctx->d_stage, *sv = su + nl, *si = sv + nl, *sc = si + nl;
+  launch_deinterleave_template(ctx->stream, (int)nl, t->d_pts[lvl], su, sv, si, sc);
+  DSM_HIP(hipMemcpyAsync(pc_u, su, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(pc_v, sv, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(pc_idepth, si, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(pc_color, sc, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+
+int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, float ab_exposure) {
+  if (!t || !dIp || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_frame: bad argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const int layout = t->desc.layout;
+  if (layout != IMG_AOS3) {
+    int rc = ensure_stage(ctx, 3 * (size_t)t->w * t->h);
+    if (rc) return rc;
+  }
+  for (int l = 0; l < t->nlevels; l++) {
+    const size_t npx = (size_t)(t->w >> l) * (t->h >> l);
+    if (layout == IMG_AOS3) {
+      DSM_HIP(hipMemcpyAsync(t->d_img[slot][l], dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      DSM_HIP(hipMemcpyAsync(ctx->d_stage, dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
+      launch_aos3_to_aos4(ctx->stream, (int)npx, ctx->d_stage, (float4 *)t->d_img[slot][l]);
+      DSM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  t->desc.exposure[slot] = ab_exposure;
+  t->have_frame[slot] = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure) {
+  if (!t || !image || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_image: bad argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const int layout = t->desc.layout;
+  const size_t npx0 = (size_t)t->w * t->h;
+  int rc = ensure_stage(ctx, npx0);
+  if (rc) return rc;
+  DSM_HIP(hipMemcpyAsync(ctx->d_stage, image, npx0 * 4, hipMemcpyHostToDevice, ctx->stream));
+  launch_pyr_level0(ctx->stream, t->w, t->h, ctx->d_stage, t->d_img[slot][0], layout);
+  for (int l = 0; l < t->nlevels; l++) {
+    const int wl = t->w >> l, hl = t->h >> l;
+    if (l > 0) launch_pyr_down(ctx->stream, t->w >> (l - 1), wl, hl, t->d_img[slot][l - 1], t->d_img[slot][l], layout);
+    launch_pyr_grad(ctx->stream, wl, hl, t->d_img[slot][l], layout);
+  }
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  t->desc.exposure[slot] = ab_exposure;
+  t->have_frame[slot] = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out) {
+  if (!t || !dIp_out || slot < 0 || slot > 1 || lvl < 0 || lvl >= t->nlevels) return invalid("dsm_tracker_get_frame: bad argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const size_t npx = (size_t)(t->w >> lvl) * (t->h >> lvl);
+  if (t->desc.layout == IMG_AOS3) {
+    DSM_HIP(hipMemcpyAsync(dIp_out, t->d_img[slot][lvl], npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    int rc = ensure_stage(ctx, 3 * npx);
+    if (rc) return rc;
+    launch_aos4_to_aos3(ctx->stream, (int)npx, (const float4 *)t->d_img[slot][lvl], ctx->d_stage);
+    DSM_HIP(hipMemcpyAsync(dIp_out, ctx->d_stage, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  return DSM_OK;
+}
+
+int dsm_tracker_ref_frame_id(dsm_tracker *t) { return t ? t->ref_frame_id : -1; }
+
+int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pts_per_thread_out, int *chunks) {
+  (void)t;
+  (void)lvl;
+  if (threads) *threads = kThreads;
+  if (pts_per_thread_out) *pts_per_thread_out = pts_per_thread(n);
+  if (chunks) *chunks = num_chunks(n);
+  return DSM_OK;
+}
+
+// ---- common batch plumbing ------------------------------------------------------------------
+static int check_ready(dsm_tracker *t, int mode) {
+  if (!t->have_k || !t->have_ref || !t->have_frame[mode]) {
+    set_error(mode ? "optimize_scale needs make_k, set_ref and the right frame (slot 1)"
+                   : "track needs make_k, set_ref and the new left frame (slot 0)");
+    return DSM_ERR_STATE;
+  }
+  return DSM_OK;
+}
+
+static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode) {
+  if (!ctx || n <= 0 || !ts) return invalid("batch: bad argument");
+  DSM_HIP(hipSetDevice(ctx->device));
+  int ps = 0;
+  for (int i = 0; i < n; i++) {
+    dsm_tracker *t = ts[i];
+    if (!t || t->ctx != ctx) return invalid("batch: tracker does not belong to this context");
+    if (t->w != ts[0]->w || t->h != ts[0]->h || t->nlevels != ts[0]->nlevels || t->desc.layout != ts[0]->desc.layout)
+      return invalid("batch: all trackers must share image size, levels and layout");
+    int rc = check_ready(t, mode);
+    if (rc) return rc;
+    const int need = num_chunks(t->w * t->h) * kPartialStride;
+    if (need > ps) ps = need;
+  }
+  int rc = ensure_batch_capacity(ctx, n, ps);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    rc = sync_desc(ts[i]);
+    if (rc) return rc;
+    ctx->h_tracker_ptrs[i] = ts[i]->d_desc;
+  }
+  DSM_HIP(hipMemcpyAsync(ctx->d_tracker_ptrs, ctx->h_tracker_ptrs, sizeof(TrackerDev *) * n, hipMemcpyHostToDevice, ctx->stream));
+  return DSM_OK;
+}
+
+static hipEvent_t get_event(dsm_context *ctx, size_t idx) {
+  while (ctx->ev_pool.size() <= idx) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    ctx->ev_pool.push_back(ev);
+  }
+  return ctx->ev_pool[idx];
+}
+
+// runs the device LM state machine for a batch (mode 0 = trackNewestCoarse, 1 = optimizeScale)
+static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode, int coarsest) {
+  const int nlevels = ts[0]->nlevels;
+  if (coarsest < 0 || coarsest >= nlevels) return invalid("coarsest level out of range"); // :457 / :856
+  const dsm_params &P = ts[0]->params;
+  const int layout = ts[0]->desc.layout;
+  memset(&ctx->stats, 0, sizeof ctx->stats);
+  DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
+  DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo) * n, hipMemcpyHostToDevice, ctx->stream));
+  launch_lm(ctx->stream, mode, LM_OP_START, coarsest, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+            ctx->partial_stride, ctx->d_start, nullptr, ctx->d_status);
+  size_t ev_used = 0;
+  std::vector<int> ev_lvl;
+  for (int L = coarsest; L >= 0; L--) {
+    int max_chunks = 1, max_it = 0;
+    for (int i = 0; i < n; i++) {
+      const int c = num_chunks(ts[i]->desc.lv[L].n);
+      if (c > max_chunks) max_chunks = c;
+      if (ts[i]->params.max_iterations[L] > max_it) max_it = ts[i]->params.max_iterations[L];
+    }
+    const int grid_x = round8(max_chunks);
+    const int worst = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
+    int launched = 0;
+    while (launched < worst) {
+      const int chunk = P.poll_chunk > 0 ? (P.poll_chunk < worst - launched ? P.poll_chunk : worst - launched)
+                                         : worst - launched;
+      for (int k = 0; k < chunk; k++) {
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (ctx->timing) {
+          ea = get_event(ctx, ev_used++);
+          eb = get_event(ctx, ev_used++);
+          ev_lvl.push_back(L);
+          if (ea) DSM_HIP(hipEventRecord(ea, ctx->stream));
+        }
+        launch_eval(ctx->stream, mode, layout, L, grid_x, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+                    ctx->partial_stride);
+        if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, ctx->stream));
+        launch_lm(ctx->stream, mode, LM_OP_STEP, L, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+                  ctx->partial_stride, nullptr, nullptr, ctx->d_status);
+      }
+      launched += chunk;
+      ctx->stats.launches[L] += chunk;
+      if (P.poll_chunk > 0) {
+        DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+        DSM_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->stats.polls++;
+        bool any = false;
+        for (int i = 0; i < n; i++)
+          if (ctx->h_status[2 * i] == ST_RUNNING && ctx->h_status[2 * i + 1] == L) any = true;
+        if (!any) break;
+      }
+    }
+  }
+  DSM_HIP(hipMemcpyAsync(ctx->h_states, ctx->d_states, sizeof(LMState) * n, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
+  ctx->stats.total_ms = ms;
+  if (ctx->timing) {
+    for (size_t i = 0; i < ev_lvl.size(); i++) {
+      float m = 0;
+      if (hipEventElapsedTime(&m, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess)
+        ctx->stats.eval_kernel_ms[ev_lvl[i]] += m;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    const LMState &S = ctx->h_states[i];
+    if (S.status == ST_RUNNING) {
+      set_error("internal: LM state machine did not terminate within the launch bound");
+      return DSM_ERR_STATE;
+    }
+    for (int l = 0; l < nlevels; l++) {
+      ctx->stats.evals[l] += S.evals[l];
+      ctx->stats.algorithmic_bytes +=
+          S.evals[l] * (16ll * ts[i]->desc.lv[l].n + 12ll * (ts[i]->w >> l) * (ts[i]->h >> l));
+    }
+  }
+  return DSM_OK;
+}
+
+int dsm_track_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, double *pose_io, double *aff_io,
+                    int coarsest_lvl, const double *min_res_for_abort, double *last_residuals, double *flow_out,
+                    int *good) {
+  if (!pose_io || !aff_io) return invalid("dsm_track_batch: null pose/aff");
+  int rc = prepare_batch(ctx, n, ts, 0);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    StartInfo &I = ctx->h_start[i];
+    memset(&I, 0, sizeof I);
+    memcpy(I.pose, pose_io + 7 * i, sizeof I.pose);
+    memcpy(I.aff, aff_io + 2 * i, sizeof I.aff);
+    for (int l = 0; l < DSM_MAX_LEVELS; l++)
+      I.min_res[l] = min_res_for_abort ? min_res_for_abort[DSM_MAX_LEVELS * i + l] : std::numeric_limits<double>::quiet_NaN();
+    I.scale = 1.0f;
+    I.coarsest = coarsest_lvl;
+  }
+  rc = run_lm_batch(ctx, n, ts, 0, coarsest_lvl);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    const LMState &S = ctx->h_states[i];
+    const bool ok = S.status == ST_GOOD;
+    // the reference writes lastToNew_out / aff_g2l_out at :612-613, i.e. also when the later
+    // affine plausibility checks (:615-626) fail, but not when a level aborts (:598)
+    if (S.status == ST_GOOD || S.status == ST_BAD_AFFINE) {
+      memcpy(pose_io + 7 * i, S.cur, sizeof(double) * 7);
+      memcpy(aff_io + 2 * i, S.aff_cur, sizeof(double) * 2);
+    }
+    if (last_residuals) memcpy(last_residuals + DSM_MAX_LEVELS * i, S.last_residuals, sizeof(double) * DSM_MAX_LEVELS);
+    if (flow_out) memcpy(flow_out + 3 * i, S.flow, sizeof(double) * 3);
+    if (good) good[i] = ok ? 1 : 0;
+  }
+  return DSM_OK;
+}
+
+int dsm_tracker_track(dsm_tracker *t, double pose_io[7], double aff_io[2], int coarsest_lvl,
+                      const double *min_res_for_abort, double *last_residuals, double flow_out[3], int *good) {
+  if (!t) return invalid("null tracker");
+  dsm_tracker *ts[1] = {t};
+  return dsm_track_batch(t->ctx, 1, ts, pose_io, aff_io, coarsest_lvl, min_res_for_abort, last_residuals, flow_out, good);
+}
+
+int dsm_optimize_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, float *scale_io, int coarsest_lvl,
+                             float *err_out) {
+  if (!scale_io) return invalid("dsm_optimize_scale_batch: null scale");
+  int rc = prepare_batch(ctx, n, ts, 1);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    StartInfo &I = ctx->h_start[i];
+    memset(&I, 0, sizeof I);
+    I.pose[3] = 1.0;
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) I.min_res[l] = std::numeric_limits<double>::quiet_NaN();
+    I.scale = scale_io[i];
+    I.coarsest = coarsest_lvl;
+  }
+  rc = run_lm_batch(ctx, n, ts, 1, coarsest_lvl);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    const LMState &S = ctx->h_states[i];
+    scale_io[i] = S.scale_cur;                               // :954
+    if (err_out) err_out[i] = (float)S.last_residuals[0];    // :963
+  }
+  return DSM_OK;
+}
+
+int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl, float *err_out) {
+  if (!t) return invalid("null tracker");
+  dsm_tracker *ts[1] = {t};
+  return dsm_optimize_scale_batch(t->ctx, 1, ts, scale_io, coarsest_lvl, err_out);
+}
+
+// single fused evaluation
+static int single_eval(dsm_tracker *t, int mode, int lvl, const double *pose, const double *aff, float scale,
+                       float cutoff, SingleOut *out) {
+  if (!t) return invalid("null tracker");
+  if (lvl < 0 || lvl >= t->nlevels) return invalid("level out of range");
+  dsm_context *ctx = t->ctx;
+  dsm_tracker *ts[1] = {t};
+  int rc = prepare_batch(ctx, 1, ts, mode);
+  if (rc) return rc;
+  StartInfo &I = ctx->h_start[0];
+  memset(&I, 0, sizeof I);
+  if (pose) memcpy(I.pose, pose, sizeof I.pose);
+  if (aff) memcpy(I.aff, aff, sizeof I.aff);
+  I.scale = scale;
+  I.cutoff = cutoff;
+  I.lvl = lvl;
+  DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo), hipMemcpyHostToDevice, ctx->stream));
+  launch_lm(ctx->stream, mode, LM_OP_SINGLE_PREP, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+            ctx->partial_stride, ctx->d_start, nullptr, nullptr);
+  launch_eval(ctx->stream, mode, t->desc.layout, lvl, round8(num_chunks(t->desc.lv[lvl].n)), 1, ctx->d_tracker_ptrs,
+              ctx->d_states, ctx->d_partials, ctx->partial_stride);
+  launch_lm(ctx->stream, mode, LM_OP_SINGLE_FINISH, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+            ctx->partial_stride, nullptr, ctx->d_single, nullptr);
+  DSM_HIP(hipMemcpyAsync(ctx->h_single, ctx->d_single, sizeof(SingleOut), hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  *out = ctx->h_single[0];
+  return DSM_OK;
+}
+
+int dsm_tracker_calc_res_pose(dsm_tracker *t, int lvl, const double pose[7], const double aff[2], float cutoff_th,
+                              double rs[6], double H[64], double b[8], int *n_warped) {
+  if (!pose || !aff) return invalid("dsm_tracker_calc_res_pose: null pose/aff");
+  SingleOut o;
+  int rc = single_eval(t, 0, lvl, pose, aff, 1.0f, cutoff_th, &o);
+  if (rc) return rc;
+  if (rs) memcpy(rs, o.rs, sizeof o.rs);
+  if (H) memcpy(H, o.H, sizeof o.H);
+  if (b) memcpy(b, o.b, sizeof o.b);
+  if (n_warped) *n_warped = o.n_warped;
+  return DSM_OK;
+}
+
+int dsm_tracker_calc_res_scale(dsm_tracker *t, int lvl, float scale, float cutoff_th, double rs[6], float *H,
+                               float *b, int *n_warped) {
+  SingleOut o;
+  int rc = single_eval(t, 1, lvl, nullptr, nullptr, scale, cutoff_th, &o);
+  if (rc) return rc;
+  if (rs) memcpy(rs, o.rs, sizeof o.rs);
+  if (H) *H = o.Hs;
+  if (b) *b = o.bs;
+  if (n_warped) *n_warped = o.n_warped;
+  return DSM_OK;
+}
+
+} // extern "C"

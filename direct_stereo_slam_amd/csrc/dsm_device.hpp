@@ -1,0 +1,103 @@
+// dsm_device.hpp -- device-visible data structures of the MI355X hot path.
+//
+// Data layout in HBM:
+//   template  : per level one float4 {u, v, idepth, color} per point (16 B, one coalesced
+//               global_load_dwordx4 per lane)           <- pc_u/pc_v/pc_idepth/pc_color SoA of the
+//               reference (TrackerAndScaler.h:90-94), interleaved at upload time
+//   target    : per level the reference's AoS (I,dx,dy) float3 texels (FrameHessian::dIp,
+//               TrackerAndScaler.cpp:709,1016) -- either as is (12 B) or padded to float4
+//   partials  : per problem, per chunk 64 floats (45 upper-triangular 9x9 sums, E, flow sums,
+//               integer counts)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DSM_MAX_LEVELS 6
+
+namespace dsm {
+
+constexpr int kThreads = 256;      // workgroup size of the eval kernels (4 waves)
+constexpr int kPartialStride = 64; // floats per chunk partial
+constexpr int kNumAcc = 45;        // upper triangle of the 9x9 accumulator (Accumulator9)
+// partial slot indices
+constexpr int kSlotE = 45, kSlotFlowT = 46, kSlotFlowRT = 47, kSlotFlowNum = 48;
+constexpr int kSlotNTerms = 49, kSlotNSat = 50, kSlotNWarped = 51;
+constexpr int kNumSlots = 52;
+
+enum ImgLayout { IMG_AOS3 = 0, IMG_AOS4 = 1 };
+
+struct LevelDev {
+  const float4 *pts;   // n template points
+  const float *img[2]; // slot 0 = new left frame, slot 1 = right frame; layout per TrackerDev::layout
+  int n, w, h, pad;
+  float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
+  float Ki[9];              // inverse of K at this level (float, :135-140)
+  float fx1, fy1, cx1, cy1; // camera 1 (:89-98)
+};
+
+struct ParamsDev {
+  float huber_th, coarse_cutoff_th;
+  float scale_xi_rot, scale_xi_trans, scale_a, scale_b;
+  float affine_opt_mode_a, affine_opt_mode_b;
+  float lambda_extrapolation_limit;
+  int max_iterations[DSM_MAX_LEVELS];
+};
+
+// Read-only (during track / optimize_scale) description of one TrackerAndScaler.
+struct TrackerDev {
+  LevelDev lv[DSM_MAX_LEVELS];
+  ParamsDev p;
+  int nlevels;
+  int layout;
+  double ref_a, ref_b; // lastRef_aff_g2l
+  float ref_exposure;  // lastRef->ab_exposure
+  float exposure[2];   // new_frame_->ab_exposure, fh1_->ab_exposure
+  double T10[7];       // tfm_f1_f0_ as {qx,qy,qz,qw,tx,ty,tz}
+};
+
+// Inputs of one fused evaluation, produced on the device by the LM kernel.
+struct EvalIn {
+  float M[9];   // pose: R*Ki ("RKi", :715) ; scale: R10*Ki ("rot_f1_f0_K0_i", :1022)
+  float t[3];   // pose: translation (:716) ; scale: tsl_f1_f0 (:1024)
+  float aff0, aff1; // affLL (:717-720) (pose only)
+  float b0;     // (float) lastRef_aff_g2l.b (:646) (pose only)
+  float scale;  // scale only
+  float cutoff; // setting_coarseCutoffTH * levelCutoffRepeat
+  float max_energy; // :726-728
+};
+
+enum LMPhase { PH_INIT = 0, PH_ITER = 1 };
+enum LMStatus { ST_IDLE = 0, ST_RUNNING = 1, ST_GOOD = 2, ST_ABORTED = 3, ST_BAD_AFFINE = 4 };
+
+// Per-problem state of the Levenberg-Marquardt driver (trackNewestCoarse :451-638 /
+// optimizeScale :854-964), resident in device memory for the whole call.
+struct LMState {
+  int status, lvl, phase, iteration;
+  int have_repeated, coarsest, is_scale, pad0;
+  float lambda, level_cutoff_repeat;
+  float inc_f;      // scale: last increment (for the signed break test :937)
+  float scale_cur, scale_cand;
+  float Hs, bs;     // scale: H, b
+  float pad1;
+  double inc_norm;  // pose: |inc| of the proposal being evaluated (:588)
+  double cur[7], aff_cur[2];
+  double cand[7], aff_cand[2];
+  double H[64], b[8];
+  double res_old[6];
+  double last_residuals[DSM_MAX_LEVELS];
+  double min_res[DSM_MAX_LEVELS];
+  double flow[3];
+  long long evals[DSM_MAX_LEVELS];
+  EvalIn in;
+};
+
+// Output of a single fused evaluation (dsm_tracker_calc_res_pose / _scale)
+struct SingleOut {
+  double rs[6];
+  double H[64];
+  double b[8];
+  float Hs, bs;
+  int n_warped, pad;
+};
+
+} // namespace dsm

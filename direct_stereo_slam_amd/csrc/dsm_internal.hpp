@@ -1,0 +1,66 @@
+// dsm_internal.hpp -- host-side objects behind the opaque C handles of include/dsm_hotpath.h
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dsm_hotpath.h"
+#include "dsm_kernels.hpp"
+
+namespace dsm {
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+} // namespace dsm
+
+#define DSM_HIP(expr)                                                     \
+  do {                                                                    \
+    hipError_t e__ = (expr);                                              \
+    if (e__ != hipSuccess) return dsm::hip_fail(e__, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+struct dsm_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // batch workspaces (grown on demand)
+  int cap_prob = 0;
+  int partial_stride = 0; // floats per problem
+  dsm::TrackerDev **d_tracker_ptrs = nullptr;
+  dsm::TrackerDev **h_tracker_ptrs = nullptr; // pinned
+  dsm::LMState *d_states = nullptr;
+  dsm::LMState *h_states = nullptr; // pinned
+  float *d_partials = nullptr;
+  dsm::StartInfo *d_start = nullptr;
+  dsm::StartInfo *h_start = nullptr; // pinned
+  dsm::SingleOut *d_single = nullptr;
+  dsm::SingleOut *h_single = nullptr; // pinned
+  int *d_status = nullptr;
+  int *h_status = nullptr; // pinned
+  // staging for host->device template / frame uploads
+  float *d_stage = nullptr;
+  size_t stage_floats = 0;
+  // stats / timing
+  bool timing = false;
+  dsm_stats stats{};
+  std::vector<hipEvent_t> ev_pool;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+};
+
+struct dsm_tracker {
+  dsm_context *ctx = nullptr;
+  int w = 0, h = 0, nlevels = 0;
+  dsm_params params{};
+  dsm::TrackerDev desc{}; // host copy of the device descriptor
+  dsm::TrackerDev *d_desc = nullptr;
+  float4 *d_pts[DSM_MAX_LEVELS] = {};
+  float *d_img[2][DSM_MAX_LEVELS] = {};
+  bool have_k = false, have_ref = false, have_frame[2] = {false, false};
+  int ref_frame_id = -1;
+  bool desc_dirty = true;
+};
+
+namespace dsm {
+int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride);
+int ensure_stage(dsm_context *ctx, size_t floats);
+int sync_desc(dsm_tracker *t);
+} // namespace dsm

@@ -1,0 +1,66 @@
+// dsm_kernels.hpp -- host-side launch interface of the HIP kernels (tracker_kernels.hip,
+// ringkey_kernels.hip).  Internal to the shared library; the public boundary is
+// include/dsm_hotpath.h.
+#pragma once
+#include "dsm_device.hpp"
+
+namespace dsm {
+
+// Reduction geometry (part of the documented numerics): a workgroup of
+// 256 threads owns a chunk of 256*P consecutive template points, thread t handles points
+// chunk*256*P + k*256 + t for k = 0..P-1.
+__host__ __device__ inline int pts_per_thread(int n) {
+  return n >= 256 * 1024 ? 8 : n >= 64 * 1024 ? 4 : n >= 16 * 1024 ? 2 : 1;
+}
+__host__ __device__ inline int num_chunks(int n) {
+  const int per = kThreads * pts_per_thread(n);
+  return (n + per - 1) / per;
+}
+
+enum LMOp {
+  LM_OP_STEP = 0,          // consume the evaluation of level `lvl`, advance the LM state machine
+  LM_OP_START = 1,         // initialise the state machine at the coarsest level
+  LM_OP_SINGLE_PREP = 2,   // dsm_tracker_calc_res_*: build EvalIn from a host supplied pose/scale
+  LM_OP_SINGLE_FINISH = 3  // ... and reduce the partials into a SingleOut
+};
+
+struct StartInfo { // host -> device, one per problem
+  double pose[7];
+  double aff[2];
+  double min_res[DSM_MAX_LEVELS];
+  float scale;
+  float cutoff; // single evaluation only
+  int coarsest;
+  int lvl;      // single evaluation only
+};
+
+// mode: 0 = pose (calcResPose + calcGSSSEPose), 1 = scale (calcResScale + calcGSSSEScale)
+void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
+                 const TrackerDev *const *trackers, const LMState *states, float *partials,
+                 int partial_stride);
+void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
+               LMState *states, const float *partials, int partial_stride, const StartInfo *start,
+               SingleOut *single_out, int *status_out);
+
+void launch_interleave_template(hipStream_t s, int n, const float *u, const float *v, const float *id,
+                                const float *c, float4 *out);
+void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
+                                  float *c);
+void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
+void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out);
+void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out);
+// makeImages (upstream DSO): level 0 from the float image, level l from level l-1; layout aware
+void launch_pyr_level0(hipStream_t s, int w, int h, const float *image, float *out, int layout);
+void launch_pyr_down(hipStream_t s, int w_prev, int wl, int hl, const float *prev, float *out, int layout);
+void launch_pyr_grad(hipStream_t s, int wl, int hl, float *img, int layout);
+
+// ring-key kernels
+void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim,
+                        int k, float thres, int shard_rank, int shard_count, const float *d_queries,
+                        int nq, unsigned long long *d_scratch, int n_slices,
+                        unsigned long long *d_packed_out);
+int ringkey_num_slices(int64_t n_local, int nq);
+void launch_ringkey_insert(hipStream_t s, float *keysT, int64_t cap, int64_t pos, int dim,
+                           const float *d_key, int nkeys);
+
+} // namespace dsm

@@ -1,0 +1,191 @@
+// ringkey_kernels.hip -- exact brute-force k-NN over ScanContext ring keys (gfx950).
+//
+// Replaces the flann::Index<flann::L2<float>> KD-forest queried by search_ringkey
+// (src/loop_closure/loop_detection/search_place.h:25-39, built at LoopHandler.cpp:35-39) with an
+// exact scan.  Distances follow flann::L2<float>::operator() (squared L2, accumulated in groups
+// of four, UPSTREAM FLANN dist.h) with -ffp-contract=off, so they are bit-identical to the CPU
+// oracle; candidates are packed as  (float_bits(dist2) << 32) | global_index  so that an unsigned
+// 64-bit min is "smaller distance first, smaller index on ties" -- the merge order used inside
+// the kernel, across slices, and across GPUs (RCCL all-reduce(min)).
+//
+// HBM layout: dimension-major planes keysT[j * capacity + i] (i = local slot of this shard), so the
+// tile loads are fully coalesced; global index = i * shard_count + shard_rank.
+#include "dsm_kernels.hpp"
+
+namespace dsm {
+
+constexpr int kRkThreads = 256;
+constexpr int kRkTile = 128;
+// "no candidate": larger than every packed candidate both as uint64 and as int64 (dist2 >= 0 keeps bit 63 clear)
+constexpr unsigned long long kNoCand = 0x7FFFFFFFFFFFFFFFull;
+
+template <int K>
+__device__ __forceinline__ void topk_insert(unsigned long long (&t)[K], unsigned long long c) {
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    const bool lt = c < t[j];
+    const unsigned long long lo = lt ? c : t[j];
+    c = lt ? t[j] : c;
+    t[j] = lo;
+  }
+}
+
+// one thread = one query; key tiles are staged through LDS and broadcast to all lanes
+template <int DIM, int K>
+__global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__restrict__ keysT, long long cap,
+                                                                 long long n_local, int dim_rt, float thres,
+                                                                 int shard_rank, int shard_count,
+                                                                 const float *__restrict__ queries, int nq,
+                                                                 int n_slices,
+                                                                 unsigned long long *__restrict__ scratch) {
+  constexpr int DMAX = DIM > 0 ? DIM : 32;
+  const int dim = DIM > 0 ? DIM : dim_rt;
+  __shared__ __attribute__((aligned(16))) float tile[kRkTile * DMAX];
+  const int q = blockIdx.x * kRkThreads + threadIdx.x;
+  const int slice = blockIdx.y;
+  const long long per = (n_local + n_slices - 1) / n_slices;
+  const long long k0 = (long long)slice * per;
+  const long long k1 = k0 + per < n_local ? k0 + per : n_local;
+
+  float qv[DMAX];
+  if (DIM > 0) {
+#pragma unroll
+    for (int j = 0; j < DMAX; j++) qv[j] = q < nq ? queries[(size_t)q * DIM + j] : 0.f;
+  }
+  unsigned long long best[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) best[j] = kNoCand;
+
+  for (long long base = k0; base < k1; base += kRkTile) {
+    const int tn = (int)(k1 - base < kRkTile ? k1 - base : kRkTile);
+    __syncthreads();
+    for (int e = threadIdx.x; e < dim * kRkTile; e += kRkThreads) {
+      const int j = e / kRkTile, t = e % kRkTile;
+      if (t < tn) tile[t * dim + j] = keysT[(size_t)j * cap + base + t];
+    }
+    __syncthreads();
+    if (q < nq) {
+      for (int t = 0; t < tn; t++) {
+        const float *kp = tile + t * dim;
+        float result = 0.f;
+        if (DIM > 0) {
+#pragma unroll
+          for (int j = 0; j < DMAX; j += 4) { // flann::L2 main loop
+            const float d0 = qv[j] - kp[j], d1 = qv[j + 1] - kp[j + 1], d2 = qv[j + 2] - kp[j + 2],
+                        d3 = qv[j + 3] - kp[j + 3];
+            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          }
+        } else {
+          const float *qp = queries + (size_t)q * dim;
+          int j = 0;
+          for (; j + 3 < dim; j += 4) {
+            const float d0 = qp[j] - kp[j], d1 = qp[j + 1] - kp[j + 1], d2 = qp[j + 2] - kp[j + 2],
+                        d3 = qp[j + 3] - kp[j + 3];
+            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          }
+          for (; j < dim; j++) { // flann::L2 tail loop
+            const float d0 = qp[j] - kp[j];
+            result += d0 * d0;
+          }
+        }
+        if (result < thres) {
+          const unsigned long long g = (unsigned long long)(base + t) * shard_count + shard_rank;
+          topk_insert<K>(best, ((unsigned long long)__float_as_uint(result) << 32) | g);
+        }
+      }
+    }
+  }
+  if (q < nq) {
+#pragma unroll
+    for (int j = 0; j < K; j++) scratch[((size_t)slice * nq + q) * K + j] = best[j];
+  }
+}
+
+// one wave per query merges the per-slice candidates
+template <int K>
+__global__ __launch_bounds__(64) void ringkey_merge_kernel(const unsigned long long *__restrict__ scratch, int nq,
+                                                           int n_slices, unsigned long long *__restrict__ out) {
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x;
+  unsigned long long best[K];
+#pragma unroll
+  for (int j = 0; j < K; j++) best[j] = kNoCand;
+  for (int s = lane; s < n_slices; s += 64) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const unsigned long long c = scratch[((size_t)s * nq + q) * K + j];
+      if (c != kNoCand) topk_insert<K>(best, c);
+    }
+  }
+  // K rounds of wave-min extraction; the winner lane pops its head
+#pragma unroll
+  for (int r = 0; r < K; r++) {
+    unsigned long long m = best[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(m, off, 64);
+      m = o < m ? o : m;
+    }
+    if (lane == 0) out[(size_t)q * K + r] = m;
+    if (m != kNoCand && best[0] == m) {
+#pragma unroll
+      for (int j = 0; j + 1 < K; j++) best[j] = best[j + 1];
+      best[K - 1] = kNoCand;
+    }
+  }
+}
+
+__global__ void ringkey_insert_kernel(float *keysT, long long cap, long long pos, int dim, const float *key,
+                                      int nkeys) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < dim * nkeys) {
+    const int kk = e / dim, j = e % dim;
+    keysT[(size_t)j * cap + pos + kk] = key[(size_t)kk * dim + j];
+  }
+}
+
+int ringkey_num_slices(int64_t n_local, int nq) {
+  // enough workgroups to fill 256 CUs, at least one key tile per slice
+  const int qblocks = (nq + kRkThreads - 1) / kRkThreads;
+  int64_t want = 2048 / (qblocks > 0 ? qblocks : 1);
+  if (want < 1) want = 1;
+  const int64_t max_by_keys = (n_local + kRkTile - 1) / kRkTile;
+  int64_t s = want < max_by_keys ? want : max_by_keys;
+  if (s < 1) s = 1;
+  if (s > 4096) s = 4096;
+  return (int)s;
+}
+
+template <int K>
+static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim, float thres,
+                         int shard_rank, int shard_count, const float *d_queries, int nq,
+                         unsigned long long *d_scratch, int n_slices, unsigned long long *d_packed_out) {
+  dim3 grid((nq + kRkThreads - 1) / kRkThreads, n_slices), block(kRkThreads);
+  if (dim == 20)
+    hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
+                       thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
+  else
+    hipLaunchKernelGGL((ringkey_knn_kernel<0, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
+                       thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
+  hipLaunchKernelGGL((ringkey_merge_kernel<K>), dim3(nq), dim3(64), 0, s, d_scratch, nq, n_slices, d_packed_out);
+}
+
+void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim, int k, float thres,
+                        int shard_rank, int shard_count, const float *d_queries, int nq,
+                        unsigned long long *d_scratch, int n_slices, unsigned long long *d_packed_out) {
+  switch (k) {
+  case 1: launch_knn_k<1>(s, keysT, cap, n_local, dim, thres, shard_rank, shard_count, d_queries, nq, d_scratch, n_slices, d_packed_out); break;
+  case 2: launch_knn_k<2>(s, keysT, cap, n_local, dim, thres, shard_rank, shard_count, d_queries, nq, d_scratch, n_slices, d_packed_out); break;
+  case 3: launch_knn_k<3>(s, keysT, cap, n_local, dim, thres, shard_rank, shard_count, d_queries, nq, d_scratch, n_slices, d_packed_out); break;
+  default: launch_knn_k<4>(s, keysT, cap, n_local, dim, thres, shard_rank, shard_count, d_queries, nq, d_scratch, n_slices, d_packed_out); break;
+  }
+}
+
+void launch_ringkey_insert(hipStream_t s, float *keysT, int64_t cap, int64_t pos, int dim, const float *d_key,
+                           int nkeys) {
+  const int n = dim * nkeys;
+  hipLaunchKernelGGL(ringkey_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keysT, (long long)cap,
+                     (long long)pos, dim, d_key, nkeys);
+}
+
+} // namespace dsm

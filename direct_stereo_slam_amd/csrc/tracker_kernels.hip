@@ -1,0 +1,827 @@
+// tracker_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the direct photometric hot path.
+//
+//   eval_kernel<MODE, LAYOUT>  fused calcResPose+calcGSSSEPose (TrackerAndScaler.cpp:699-852,
+//                              640-697) or calcResScale+calcGSSSEScale (:1007-1172, :966-1005)
+//                              for a batch of independent problems: grid = (chunks, problems).
+//   lm_kernel                  per problem: fixed-order reduction of the chunk partials and one
+//                              step of the Levenberg-Marquardt state machine of
+//                              trackNewestCoarse (:451-638) / optimizeScale (:854-964).
+//   template / pyramid helpers interleave, scaleCoarseDepthL0 (:329-336), makeImages.
+//
+// Numerics contract: compiled with -ffp-contract=off; every per-point
+// value (warp, bounds test, bilinear taps, residual, Huber weight, cut-off test) is computed
+// with the same IEEE float32 operation sequence as the CPU oracle, so the integer outputs
+// (numTermsInE, numSaturated, warped count) are bit-exact.  Sums are reduced in a fixed tree
+// (thread-sequential -> 16-lane DPP rows -> 16 rows sequential -> chunks sequential in
+// double): deterministic run to run, equal to the reference's SSE lane order only up to
+// float rounding (quirk Q4 is a CPU artefact, not reproduced).  No float atomics.
+#include "dsm_kernels.hpp"
+#include "lm_math.hpp"
+
+namespace dsm {
+
+// ------------------------------------------------------------------------------------------
+// wave64 helpers: DPP butterflies inside 16-lane rows (v_add_f32 ... quad_perm / row_mirror)
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+// after this every lane holds the sum over its 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+  v = v + dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = v + dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
+  v = v + dpp_f<0x141>(v); // row_half_mirror
+  v = v + dpp_f<0x140>(v); // row_mirror
+  return v;
+}
+__device__ __forceinline__ int row16_sum(int v) {
+  v = v + dpp_i<0xB1>(v);
+  v = v + dpp_i<0x4E>(v);
+  v = v + dpp_i<0x141>(v);
+  v = v + dpp_i<0x140>(v);
+  return v;
+}
+
+// clang vector types: loads through address_space(1) pointers compile on the host pass too
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef float fvec3u __attribute__((ext_vector_type(3), aligned(4))); // 12-byte texel, dword aligned
+#define DSM_GLOBAL __attribute__((address_space(1)))
+
+// getInterpolatedElement33 (upstream DSO), call sites TrackerAndScaler.cpp:790,1106
+template <int LAYOUT>
+__device__ __forceinline__ void interp33(const DSM_GLOBAL float *img, float x, float y, int w, float &h0,
+                                         float &h1, float &h2) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const float dx = x - ix;
+  const float dy = y - iy;
+  const float dxdy = dx * dy;
+  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+  const int base = ix + iy * w;
+  float t00[3], t10[3], t01[3], t11[3];
+  if (LAYOUT == IMG_AOS3) {
+    const DSM_GLOBAL float *bp = img + 3 * base;
+    const fvec3u a = *(const DSM_GLOBAL fvec3u *)(bp);
+    const fvec3u b = *(const DSM_GLOBAL fvec3u *)(bp + 3);
+    const fvec3u c = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w);
+    const fvec3u d = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w + 3);
+    t00[0] = a.x, t00[1] = a.y, t00[2] = a.z;
+    t10[0] = b.x, t10[1] = b.y, t10[2] = b.z;
+    t01[0] = c.x, t01[1] = c.y, t01[2] = c.z;
+    t11[0] = d.x, t11[1] = d.y, t11[2] = d.z;
+  } else {
+    const DSM_GLOBAL fvec4 *bp = (const DSM_GLOBAL fvec4 *)img + base;
+    const fvec4 a = bp[0], b = bp[1], c = bp[w], d = bp[w + 1];
+    t00[0] = a.x, t00[1] = a.y, t00[2] = a.z;
+    t10[0] = b.x, t10[1] = b.y, t10[2] = b.z;
+    t01[0] = c.x, t01[1] = c.y, t01[2] = c.z;
+    t11[0] = d.x, t11[1] = d.y, t11[2] = d.z;
+  }
+  h0 = ((w11 * t11[0] + w01 * t01[0]) + w10 * t10[0]) + w00 * t00[0];
+  h1 = ((w11 * t11[1] + w01 * t01[1]) + w10 * t10[1]) + w00 * t00[1];
+  h2 = ((w11 * t11[2] + w01 * t01[2]) + w10 * t10[2]) + w00 * t00[2];
+}
+
+// ------------------------------------------------------------------------------------------
+// eval kernel
+// ------------------------------------------------------------------------------------------
+template <int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
+                                                        const LMState *__restrict__ states,
+                                                        float *__restrict__ partials,
+                                                        int partial_stride, int lvl) {
+  const int prob = blockIdx.y;
+  // uniform, read-only descriptors: global address space so they become scalar (s_load) reads
+  const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
+  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
+  const DSM_GLOBAL TrackerDev &T = *(const DSM_GLOBAL TrackerDev *)trackers[prob];
+  const DSM_GLOBAL LevelDev &L = T.lv[lvl];
+  const int n = L.n;
+  const int P = pts_per_thread(n);
+  const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
+  // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
+  // contiguous band of the template (and therefore of the target rows it gathers from).
+  const int per_xcd = gridDim.x >> 3;
+  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (chunk >= nchunks) return;
+
+  const DSM_GLOBAL EvalIn &in = S.in;
+  const float M0 = in.M[0], M1 = in.M[1], M2 = in.M[2], M3 = in.M[3], M4 = in.M[4], M5 = in.M[5],
+              M6 = in.M[6], M7 = in.M[7], M8 = in.M[8];
+  const float t0 = in.t[0], t1 = in.t[1], t2 = in.t[2];
+  const float cutoff = in.cutoff, max_energy = in.max_energy;
+  const float huber = T.p.huber_th;
+  const float fxl = MODE == 0 ? L.fx : L.fx1, fyl = MODE == 0 ? L.fy : L.fy1;
+  const float cxl = MODE == 0 ? L.cx : L.cx1, cyl = MODE == 0 ? L.cy : L.cy1;
+  const int wl = L.w, hl = L.h;
+  const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
+  // pointers read from the descriptor are generic; tell the compiler they are global (global_load, not flat_load)
+  const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)L.img[MODE];
+  const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)L.pts;
+  // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
+  const float sc = in.scale;
+  const float S0 = sc * M0, S1 = sc * M1, S2 = sc * M2, S3 = sc * M3, S4 = sc * M4, S5 = sc * M5,
+              S6 = sc * M6, S7 = sc * M7, S8 = sc * M8;
+  const float aff0 = in.aff0, aff1 = in.aff1, b0 = in.b0;
+
+  constexpr int NACC = MODE == 0 ? kNumAcc : 3;
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; i++) acc[i] = 0.f;
+  float E = 0.f;
+  int n_terms = 0, n_sat = 0, n_warped = 0;
+
+  const int tid = threadIdx.x;
+  const int chunk_start = chunk * kThreads * P;
+
+  // The loop body is branch-free: out-of-range lanes are clamped to a safe address and masked
+  // by selects, so the accumulators never cross a divergent join (no PHI copies of 45 VGPRs)
+  // and the gathers of one point can be in flight while the next template point is fetched.
+  int i = chunk_start + tid;
+  fvec4 p = pts[i < n ? i : n - 1];
+  __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads here so the loop-header wait can be relaxed
+  for (int k = 0; k < P; k++) {
+    const bool in_list = i < n;
+    const int i_next = i + kThreads;
+    const fvec4 p_next = pts[i_next < n ? i_next : n - 1]; // prefetch (clamped)
+    const float x = p.x, y = p.y, id = p.z, refColor = p.w;
+    float pt0, pt1, pt2;
+    if (MODE == 0) { // :747
+      pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
+      pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
+      pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
+    } else { // :1061
+      pt0 = ((S0 * x + S1 * y) + S2) + t0 * id;
+      pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
+      pt2 = ((S6 * x + S7 * y) + S8) + t2 * id;
+    }
+    const float u = pt0 / pt2;
+    const float v = pt1 / pt2;
+    const float Ku = fxl * u + cxl;
+    const float Kv = fyl * v + cyl;
+    const float new_idepth = id / pt2;
+    const bool inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && new_idepth > 0); // :786 / :1102
+    float h0, h1, h2;
+    interp33<LAYOUT>(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, wl, h0, h1, h2);
+    const bool fin = inb && __builtin_isfinite(h0); // :791
+    const float residual = MODE == 0 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
+    const float ar = __builtin_fabsf(residual);
+    const float hw = ar < huber ? 1.0f : huber / ar; // :794-795
+    const bool sat = ar > cutoff;                    // :797
+    const bool use = fin && !sat;
+    const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
+    E += fin ? e_term : 0.0f;
+    n_terms += fin ? 1 : 0;
+    n_sat += (fin && sat) ? 1 : 0;
+    n_warped += use ? 1 : 0;
+    if (MODE == 0) {
+      // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819)
+      const float dx = h1 * fxl, dy = h2 * fyl;
+      float J[9];
+      J[0] = new_idepth * dx;
+      J[1] = new_idepth * dy;
+      J[2] = 0.0f - new_idepth * (u * dx + v * dy);
+      J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+      J[4] = (u * v) * dy + dx * (1.0f + u * u);
+      J[5] = u * dy - v * dx;
+      J[6] = aff0 * (b0 - refColor);
+      J[7] = -1.0f;
+      J[8] = residual;
+      const float wgt = use ? hw : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 9; r++) J[r] = use ? J[r] : 0.0f; // masked lanes contribute exact zeros
+      int idx = 0;
+#pragma unroll
+      for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
+        const float Jw = J[r] * wgt;
+#pragma unroll
+        for (int c = r; c < 9; c++) {
+          acc[idx] = __builtin_fmaf(Jw, J[c], acc[idx]);
+          idx++;
+        }
+      }
+    } else {
+      // calcResScale :1068 and calcGSSSEScale :983-999
+      const float rx1 = ((M0 * x + M1 * y) + M2) / id;
+      const float rx2 = ((M3 * x + M4 * y) + M5) / id;
+      const float rx3 = ((M6 * x + M7 * y) + M8) / id;
+      const float dxfx = h1 * fxl, dyfy = h2 * fyl;
+      const float deno_sqrt = sc * rx3 + t2;
+      const float deno = 1.0f / (deno_sqrt * deno_sqrt);
+      const float xno = rx1 * t2 - rx3 * t0;
+      const float yno = rx2 * t2 - rx3 * t1;
+      const float J0 = use ? dxfx * (deno * xno) + dyfy * (deno * yno) : 0.0f;
+      const float J1 = use ? residual : 0.0f;
+      const float wgt = use ? hw : 0.0f;
+      const float J0w = J0 * wgt;
+      acc[0] = __builtin_fmaf(J0w, J0, acc[0]);
+      acc[1] = __builtin_fmaf(J0w, J1, acc[1]);
+      acc[2] = __builtin_fmaf(J1 * wgt, J1, acc[2]);
+    }
+    p = p_next;
+    i = i_next;
+  }
+
+  // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
+  // handles the 8*P such points of this chunk in a single pass.
+  float fT = 0.f, fRT = 0.f, fNum = 0.f;
+  if (lvl == 0 && tid < 8 * P) {
+    const int i = chunk_start + 32 * tid;
+    if (i < n) {
+      const fvec4 p = pts[i];
+      const float x = p.x, y = p.y, id = p.z;
+      const DSM_GLOBAL float *Ki = L.Ki;
+      float kx0, kx1, kx2, rx0, rx1, rx2;
+      if (MODE == 0) {
+        kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
+        kx1 = (Ki[3] * x + Ki[4] * y) + Ki[5];
+        kx2 = (Ki[6] * x + Ki[7] * y) + Ki[8];
+        rx0 = (M0 * x + M1 * y) + M2;
+        rx1 = (M3 * x + M4 * y) + M5;
+        rx2 = (M6 * x + M7 * y) + M8;
+      } else {
+        kx0 = ((sc * Ki[0]) * x + (sc * Ki[1]) * y) + (sc * Ki[2]);
+        kx1 = ((sc * Ki[3]) * x + (sc * Ki[4]) * y) + (sc * Ki[5]);
+        kx2 = ((sc * Ki[6]) * x + (sc * Ki[7]) * y) + (sc * Ki[8]);
+        rx0 = (S0 * x + S1 * y) + S2;
+        rx1 = (S3 * x + S4 * y) + S5;
+        rx2 = (S6 * x + S7 * y) + S8;
+      }
+      const float a0 = t0 * id, a1 = t1 * id, a2 = t2 * id;
+      const float ptz = rx2 + a2;
+      const float Ku = fxl * ((rx0 + a0) / ptz) + cxl, Kv = fyl * ((rx1 + a1) / ptz) + cyl;
+      const float pTz = kx2 + a2;
+      const float KuT = fxl * ((kx0 + a0) / pTz) + cxl, KvT = fyl * ((kx1 + a1) / pTz) + cyl;
+      const float pT2z = kx2 - a2;
+      const float KuT2 = fxl * ((kx0 - a0) / pT2z) + cxl, KvT2 = fyl * ((kx1 - a1) / pT2z) + cyl;
+      const float p3z = rx2 - a2;
+      const float Ku3 = fxl * ((rx0 - a0) / p3z) + cxl, Kv3 = fyl * ((rx1 - a1) / p3z) + cyl;
+      fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+      fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+      fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+      fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+      fNum += 2;
+    }
+  }
+
+  // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
+  __shared__ float red[16][kNumSlots];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row = wave * 4 + (lane >> 4);
+  const bool writer = (lane & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < NACC; i++) {
+    const float s = row16_sum(acc[i]);
+    if (writer) red[row][i] = s;
+  }
+  {
+    const float sE = row16_sum(E), sT = row16_sum(fT), sRT = row16_sum(fRT), sN = row16_sum(fNum);
+    const int iT = row16_sum(n_terms), iS = row16_sum(n_sat), iW = row16_sum(n_warped);
+    if (writer) {
+      red[row][kSlotE] = sE;
+      red[row][kSlotFlowT] = sT;
+      red[row][kSlotFlowRT] = sRT;
+      red[row][kSlotFlowNum] = sN;
+      red[row][kSlotNTerms] = __int_as_float(iT);
+      red[row][kSlotNSat] = __int_as_float(iS);
+      red[row][kSlotNWarped] = __int_as_float(iW);
+    }
+  }
+  __syncthreads();
+  float *out = partials + (size_t)prob * partial_stride + (size_t)chunk * kPartialStride;
+  const bool is_float_slot = tid < NACC || (tid >= kSlotE && tid < kSlotNTerms);
+  if (is_float_slot) {
+    float s = red[0][tid];
+#pragma unroll
+    for (int r = 1; r < 16; r++) s += red[r][tid];
+    out[tid] = s;
+  } else if (tid >= kSlotNTerms && tid < kNumSlots) {
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s += __float_as_int(red[r][tid]);
+    out[tid] = __int_as_float(s);
+  }
+}
+
+void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
+                 const TrackerDev *const *trackers, const LMState *states, float *partials,
+                 int partial_stride) {
+  dim3 grid(grid_x, nprob), block(kThreads);
+  if (mode == 0) {
+    if (layout == IMG_AOS3)
+      hipLaunchKernelGGL((eval_kernel<0, IMG_AOS3>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+    else
+      hipLaunchKernelGGL((eval_kernel<0, IMG_AOS4>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+  } else {
+    if (layout == IMG_AOS3)
+      hipLaunchKernelGGL((eval_kernel<1, IMG_AOS3>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+    else
+      hipLaunchKernelGGL((eval_kernel<1, IMG_AOS4>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LM state machine (one wave per problem; lane 0 runs the serial double precision math)
+// ------------------------------------------------------------------------------------------
+__device__ void make_eval_pose(const TrackerDev &T, LMState &S, int lvl, const double pose[7],
+                               const double aff[2], float cutoff) {
+  double Rd[9];
+  quat_to_rot(pose, Rd);
+  float Rf[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+  float Ki[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Ki[i] = T.lv[lvl].Ki[i];
+  float M[9];
+  mat3f_mul(Rf, Ki, M); // :715
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+  S.in.t[0] = (float)pose[4]; // :716
+  S.in.t[1] = (float)pose[5];
+  S.in.t[2] = (float)pose[6];
+  double affd[2];
+  aff_from_to(T.ref_exposure, T.exposure[0], T.ref_a, T.ref_b, aff[0], aff[1], affd); // :717-720
+  S.in.aff0 = (float)affd[0];
+  S.in.aff1 = (float)affd[1];
+  S.in.b0 = (float)T.ref_b; // :646
+  S.in.scale = 1.0f;
+  S.in.cutoff = cutoff;
+  const float h = T.p.huber_th;
+  S.in.max_energy = 2 * h * cutoff - h * h; // :726-728
+}
+
+__device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float scale, float cutoff) {
+  double Rd[9];
+  quat_to_rot(T.T10, Rd);
+  float Rf[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+  float Ki[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Ki[i] = T.lv[lvl].Ki[i];
+  float M[9];
+  mat3f_mul(Rf, Ki, M); // :1022-1023
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+  S.in.t[0] = (float)T.T10[4]; // :1024
+  S.in.t[1] = (float)T.T10[5];
+  S.in.t[2] = (float)T.T10[6];
+  S.in.aff0 = 1.0f;
+  S.in.aff1 = 0.0f;
+  S.in.b0 = 0.0f;
+  S.in.scale = scale;
+  S.in.cutoff = cutoff;
+  const float h = T.p.huber_th;
+  S.in.max_energy = 2 * h * cutoff - h * h; // :1030-1032
+}
+
+__device__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
+  S.lvl = lvl;
+  S.phase = PH_INIT;
+  S.iteration = 0;
+  S.level_cutoff_repeat = 1.0f;
+  const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
+  if (S.is_scale)
+    make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
+  else
+    make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
+}
+
+// Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
+__device__ void build_rs(const double *sums, const long long *isums, double rs[6]) {
+  const float E = (float)sums[kSlotE];
+  const float sT = (float)sums[kSlotFlowT], sRT = (float)sums[kSlotFlowRT], sN = (float)sums[kSlotFlowNum];
+  const int n_terms = (int)isums[0], n_sat = (int)isums[1];
+  rs[0] = E;
+  rs[1] = n_terms;
+  rs[2] = sT / (sN + 0.1);
+  rs[3] = 0;
+  rs[4] = sRT / (sN + 0.1);
+  rs[5] = n_sat / (float)n_terms;
+}
+
+// H_out / b_out of calcGSSSEPose (:681-696) from the reduced sums
+__device__ void build_Hb_pose(const TrackerDev &T, const double *sums, int n_warped4, double *H, double *b) {
+  float Hf[9][9];
+  int idx = 0;
+#pragma unroll
+  for (int r = 0; r < 9; r++)
+#pragma unroll
+    for (int c = r; c < 9; c++) {
+      const float d = (float)sums[idx++];
+      Hf[r][c] = d;
+      Hf[c][r] = d;
+    }
+  const float invn = 1.0f / n_warped4; // (1.0f / n), n padded to a multiple of 4 (quirk Q3)
+  const double s[8] = {T.p.scale_xi_rot,   T.p.scale_xi_rot,   T.p.scale_xi_rot, T.p.scale_xi_trans,
+                       T.p.scale_xi_trans, T.p.scale_xi_trans, T.p.scale_a,      T.p.scale_b};
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) H[r * 8 + c] = (((double)Hf[r][c] * (double)invn) * s[c]) * s[r];
+    b[r] = ((double)Hf[r][8] * (double)invn) * s[r];
+  }
+}
+
+__device__ void finish_track(const TrackerDev &T, LMState &S) {
+  // :612-637.  cur / aff_cur are the outputs.
+  const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
+  int status = ST_GOOD;
+  if ((modeA != 0 && (__builtin_fabsf((float)S.aff_cur[0]) > 1.2)) ||
+      (modeB != 0 && (__builtin_fabsf((float)S.aff_cur[1]) > 200)))
+    status = ST_BAD_AFFINE;
+  if (status == ST_GOOD) {
+    double rel[2];
+    aff_from_to(T.ref_exposure, T.exposure[0], T.ref_a, T.ref_b, S.aff_cur[0], S.aff_cur[1], rel);
+    const float rel0 = (float)rel[0], rel1 = (float)rel[1];
+    if ((modeA == 0 && (__builtin_fabsf(logf(rel0)) > 1.5)) || (modeB == 0 && (__builtin_fabsf(rel1) > 200)))
+      status = ST_BAD_AFFINE;
+  }
+  if (status == ST_GOOD) {
+    if (modeA < 0) S.aff_cur[0] = 0;
+    if (modeB < 0) S.aff_cur[1] = 0;
+  }
+  S.status = status;
+}
+
+// solve + propose for the pose problem (:505-554).  sA: LDS scratch 64 doubles.
+__device__ void propose_pose(const TrackerDev &T, LMState &S, double *sA) {
+  const float lambda = S.lambda;
+  const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
+  double nb[8], inc[8];
+  for (int i = 0; i < 64; i++) sA[i] = S.H[i];
+  for (int i = 0; i < 8; i++) sA[i * 8 + i] *= (1 + lambda); // :506-508
+  for (int i = 0; i < 8; i++) nb[i] = -S.b[i];
+  // the sub-solves below need the un-factorised Hl, so they are done first on copies
+  if (modeA < 0 && modeB < 0) { // :511-515
+    ldlt_solve(6, sA, nb, inc);
+    inc[6] = inc[7] = 0;
+  } else if (!(modeA < 0) && modeB < 0) { // :516-520
+    ldlt_solve(7, sA, nb, inc);
+    inc[7] = 0;
+  } else if (modeA < 0 && !(modeB < 0)) { // :521-534
+    for (int r = 0; r < 8; r++) sA[r * 8 + 6] = sA[r * 8 + 7];
+    for (int c = 0; c < 8; c++) sA[6 * 8 + c] = sA[7 * 8 + c];
+    nb[6] = nb[7];
+    double x7[8];
+    ldlt_solve(7, sA, nb, x7);
+    for (int i = 0; i < 6; i++) inc[i] = x7[i];
+    inc[6] = 0;
+    inc[7] = x7[6];
+  } else {
+    ldlt_solve(8, sA, nb, inc); // :509
+  }
+  float extrapFac = 1; // :536-539
+  const float lim = T.p.lambda_extrapolation_limit;
+  if (lambda < lim) extrapFac = sqrtf(sqrtf(lim / lambda));
+  for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+  const double sc[8] = {T.p.scale_xi_rot,   T.p.scale_xi_rot,   T.p.scale_xi_rot, T.p.scale_xi_trans,
+                        T.p.scale_xi_trans, T.p.scale_xi_trans, T.p.scale_a,      T.p.scale_b};
+  double incScaled[8], sum = 0; // :541-548
+  for (int i = 0; i < 8; i++) {
+    incScaled[i] = inc[i] * sc[i];
+    sum += incScaled[i];
+  }
+  if (!__builtin_isfinite(sum))
+    for (int i = 0; i < 8; i++) incScaled[i] = 0;
+  double ex[7];
+  se3_exp(incScaled, ex);
+  se3_mul(ex, S.cur, S.cand); // :550-551
+  S.aff_cand[0] = S.aff_cur[0] + incScaled[6];
+  S.aff_cand[1] = S.aff_cur[1] + incScaled[7];
+  double nrm = 0;
+  for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+  S.inc_norm = sqrt(nrm);
+  S.phase = PH_ITER;
+  make_eval_pose(T, S, S.lvl, S.cand, S.aff_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+}
+
+__device__ void propose_scale(const TrackerDev &T, LMState &S) { // :897-913
+  const float lambda = S.lambda;
+  float Hl = S.Hs;
+  Hl *= (1 + lambda);
+  float inc = -S.bs / Hl;
+  float extrapFac = 1;
+  const float lim = T.p.lambda_extrapolation_limit;
+  if (lambda < lim) extrapFac = sqrtf(sqrtf(lim / lambda));
+  inc *= extrapFac;
+  if (!__builtin_isfinite(inc) || __builtin_fabsf(inc) > S.scale_cur) inc = 0.0f;
+  S.inc_f = inc;
+  S.scale_cand = S.scale_cur + inc;
+  S.phase = PH_ITER;
+  make_eval_scale(T, S, S.lvl, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+}
+
+__device__ void end_level(const TrackerDev &T, LMState &S) {
+  const int lvl = S.lvl;
+  S.last_residuals[lvl] = sqrtf((float)(S.res_old[0] / S.res_old[1])); // :596 / :945
+  if (!S.is_scale) {
+    S.flow[0] = S.res_old[2]; // :597
+    S.flow[1] = S.res_old[3];
+    S.flow[2] = S.res_old[4];
+    if (S.last_residuals[lvl] > 1.5 * S.min_res[lvl]) { // :598
+      S.status = ST_ABORTED;
+      return;
+    }
+  }
+  int next = lvl - 1;
+  if (S.level_cutoff_repeat > 1 && !S.have_repeated) { // :601-604 / :947-950
+    next = lvl;
+    S.have_repeated = 1;
+  }
+  if (next < 0) {
+    if (S.is_scale)
+      S.status = ST_GOOD;
+    else
+      finish_track(T, S);
+    return;
+  }
+  begin_level(T, S, next);
+}
+
+__global__ __launch_bounds__(64) void lm_kernel(int mode, int op, int lvl,
+                                                const TrackerDev *const *__restrict__ trackers,
+                                                LMState *__restrict__ states,
+                                                const float *__restrict__ partials, int partial_stride,
+                                                const StartInfo *__restrict__ start,
+                                                SingleOut *__restrict__ single_out,
+                                                int *__restrict__ status_out) {
+  const int prob = blockIdx.x;
+  const int lane = threadIdx.x;
+  const TrackerDev &T = *trackers[prob];
+  LMState &S = states[prob];
+  __shared__ double sums[kNumSlots];
+  __shared__ long long isums[3];
+  __shared__ double sA[64];
+
+  if (op == LM_OP_START) {
+    if (lane == 0) {
+      const StartInfo &I = start[prob];
+      S.is_scale = mode;
+      S.coarsest = I.coarsest;
+      S.have_repeated = 0;
+      S.lambda = 0.01f;
+      S.inc_norm = 0;
+      S.inc_f = 0;
+      for (int i = 0; i < 7; i++) S.cur[i] = I.pose[i];
+      S.aff_cur[0] = I.aff[0];
+      S.aff_cur[1] = I.aff[1];
+      S.scale_cur = I.scale;
+      for (int i = 0; i < DSM_MAX_LEVELS; i++) {
+        S.last_residuals[i] = __builtin_nan(""); // :459 / :860
+        S.min_res[i] = I.min_res[i];
+        S.evals[i] = 0;
+      }
+      S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
+      S.status = ST_RUNNING;
+      begin_level(T, S, I.coarsest);
+      if (status_out) {
+        status_out[2 * prob] = S.status;
+        status_out[2 * prob + 1] = S.lvl;
+      }
+    }
+    return;
+  }
+  if (op == LM_OP_SINGLE_PREP) {
+    if (lane == 0) {
+      const StartInfo &I = start[prob];
+      S.is_scale = mode;
+      S.status = ST_RUNNING;
+      S.lvl = I.lvl;
+      if (mode)
+        make_eval_scale(T, S, I.lvl, I.scale, I.cutoff);
+      else
+        make_eval_pose(T, S, I.lvl, I.pose, I.aff, I.cutoff);
+    }
+    return;
+  }
+
+  const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
+  if (!active) {
+    if (lane == 0 && status_out) {
+      status_out[2 * prob] = S.status;
+      status_out[2 * prob + 1] = S.lvl;
+    }
+    return;
+  }
+  // fixed-order reduction over the chunk partials (double / int64)
+  const int nch = num_chunks(T.lv[lvl].n);
+  const float *P = partials + (size_t)prob * partial_stride;
+  if (lane < kSlotNTerms) {
+    double s = 0;
+    for (int c = 0; c < nch; c++) s += (double)P[(size_t)c * kPartialStride + lane];
+    sums[lane] = s;
+  } else if (lane < kNumSlots) {
+    long long s = 0;
+    for (int c = 0; c < nch; c++) s += __float_as_int(P[(size_t)c * kPartialStride + lane]);
+    isums[lane - kSlotNTerms] = s;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+
+  double rs[6];
+  build_rs(sums, isums, rs);
+  const int n_warped = (int)isums[2];
+  const int n4 = (n_warped + 3) & ~3; // :824-835 padding counts in n (quirk Q3)
+
+  if (op == LM_OP_SINGLE_FINISH) {
+    SingleOut &O = single_out[prob];
+    for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
+    O.n_warped = n4;
+    if (mode == 0) {
+      build_Hb_pose(T, sums, n4, O.H, O.b);
+      O.Hs = O.bs = 0;
+    } else {
+      O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
+      O.bs = (float)sums[1] * (1.0f / n4);
+    }
+    S.status = ST_IDLE;
+    return;
+  }
+
+  // ---- LM_OP_STEP ----
+  S.evals[lvl]++;
+  const int max_it = T.p.max_iterations[lvl];
+  const float lim = T.p.lambda_extrapolation_limit;
+  bool level_done = false;
+  if (S.phase == PH_INIT) {
+    if (rs[5] > 0.6 && S.level_cutoff_repeat < 50) { // :477-485 / :875-883
+      S.level_cutoff_repeat *= 2;
+      const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
+      if (mode)
+        make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
+      else
+        make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
+    } else {
+      for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
+      if (mode == 0)
+        build_Hb_pose(T, sums, n4, S.H, S.b); // :487
+      else {
+        S.Hs = (float)sums[0] * (1.0f / n4); // :885
+        S.bs = (float)sums[1] * (1.0f / n4);
+      }
+      S.lambda = 0.01f; // :489
+      S.iteration = 0;
+      if (max_it <= 0)
+        level_done = true;
+      else if (mode == 0)
+        propose_pose(T, S, sA);
+      else
+        propose_scale(T, S);
+    }
+  } else {
+    const bool accept = (rs[0] / rs[1]) < (S.res_old[0] / S.res_old[1]); // :559 / :915
+    if (accept) { // :576-581 / :926-930
+      for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
+      if (mode == 0) {
+        build_Hb_pose(T, sums, n4, S.H, S.b);
+        for (int i = 0; i < 7; i++) S.cur[i] = S.cand[i];
+        S.aff_cur[0] = S.aff_cand[0];
+        S.aff_cur[1] = S.aff_cand[1];
+      } else {
+        S.Hs = (float)sums[0] * (1.0f / n4);
+        S.bs = (float)sums[1] * (1.0f / n4);
+        S.scale_cur = S.scale_cand;
+      }
+      S.lambda *= 0.5f;
+    } else { // :583-585 / :932-934
+      S.lambda *= 4;
+      if (S.lambda < lim) S.lambda = lim;
+    }
+    const bool small = mode == 0 ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
+    S.iteration++;
+    if (small || S.iteration >= max_it)
+      level_done = true;
+    else if (mode == 0)
+      propose_pose(T, S, sA);
+    else
+      propose_scale(T, S);
+  }
+  if (level_done) end_level(T, S);
+  if (status_out) {
+    status_out[2 * prob] = S.status;
+    status_out[2 * prob + 1] = S.lvl;
+  }
+}
+
+void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
+               LMState *states, const float *partials, int partial_stride, const StartInfo *start,
+               SingleOut *single_out, int *status_out) {
+  hipLaunchKernelGGL(lm_kernel, dim3(nprob), dim3(64), 0, s, mode, op, lvl, trackers, states, partials,
+                     partial_stride, start, single_out, status_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// template helpers
+// ------------------------------------------------------------------------------------------
+__global__ void interleave_kernel(int n, const float *__restrict__ u, const float *__restrict__ v,
+                                  const float *__restrict__ id, const float *__restrict__ c,
+                                  float4 *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = make_float4(u[i], v[i], id[i], c[i]);
+}
+__global__ void deinterleave_kernel(int n, const float4 *__restrict__ in, float *u, float *v, float *id,
+                                    float *c) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = in[i];
+    u[i] = p.x;
+    v[i] = p.y;
+    id[i] = p.z;
+    c[i] = p.w;
+  }
+}
+// scaleCoarseDepthL0 (:329-336): lpc_idepth[p] /= scale
+__global__ void scale_depth_kernel(int n, float4 *pts, float scale) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pts[i].z = pts[i].z / scale;
+}
+__global__ void aos3_to_aos4_kernel(int npx, const float *__restrict__ in, float4 *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x)
+    out[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.f);
+}
+__global__ void aos4_to_aos3_kernel(int npx, const float4 *__restrict__ in, float *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const float4 p = in[i];
+    out[3 * i] = p.x;
+    out[3 * i + 1] = p.y;
+    out[3 * i + 2] = p.z;
+  }
+}
+
+static inline int grid_for(int n, int block = 256) {
+  int g = (n + block - 1) / block;
+  return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+void launch_interleave_template(hipStream_t s, int n, const float *u, const float *v, const float *id,
+                                const float *c, float4 *out) {
+  if (n > 0) hipLaunchKernelGGL(interleave_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, u, v, id, c, out);
+}
+void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
+                                  float *c) {
+  if (n > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, in, u, v, id, c);
+}
+void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale) {
+  if (n > 0) hipLaunchKernelGGL(scale_depth_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, pts, scale);
+}
+void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out) {
+  hipLaunchKernelGGL(aos3_to_aos4_kernel, dim3(grid_for(npx)), dim3(256), 0, s, npx, in, out);
+}
+void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out) {
+  hipLaunchKernelGGL(aos4_to_aos3_kernel, dim3(grid_for(npx)), dim3(256), 0, s, npx, in, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// makeImages (upstream DSO FrameHessian::makeImages; call sites FrontEnd.cpp:605,680)
+// texel stride TS = 3 (AOS3) or 4 (AOS4)
+// ------------------------------------------------------------------------------------------
+__global__ void pyr_level0_kernel(int npx, const float *__restrict__ image, float *__restrict__ out, int TS) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    out[TS * i] = image[i];
+    out[TS * i + 1] = 0.f;
+    out[TS * i + 2] = 0.f;
+    if (TS == 4) out[TS * i + 3] = 0.f;
+  }
+}
+__global__ void pyr_down_kernel(int wlm1, int wl, int hl, const float *__restrict__ prev,
+                                float *__restrict__ out, int TS) {
+  const int npx = wl * hl;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const int x = i % wl, y = i / wl;
+    const int b = 2 * x + 2 * y * wlm1;
+    out[TS * i] = 0.25f * (prev[TS * b] + prev[TS * (b + 1)] + prev[TS * (b + wlm1)] + prev[TS * (b + 1 + wlm1)]);
+    out[TS * i + 1] = 0.f;
+    out[TS * i + 2] = 0.f;
+    if (TS == 4) out[TS * i + 3] = 0.f;
+  }
+}
+__global__ void pyr_grad_kernel(int wl, int hl, float *img, int TS) {
+  const int lo = wl, hi = wl * (hl - 1);
+  for (int idx = lo + blockIdx.x * blockDim.x + threadIdx.x; idx < hi; idx += gridDim.x * blockDim.x) {
+    float dx = 0.5f * (img[TS * (idx + 1)] - img[TS * (idx - 1)]);
+    float dy = 0.5f * (img[TS * (idx + wl)] - img[TS * (idx - wl)]);
+    if (!__builtin_isfinite(dx)) dx = 0;
+    if (!__builtin_isfinite(dy)) dy = 0;
+    img[TS * idx + 1] = dx;
+    img[TS * idx + 2] = dy;
+  }
+}
+void launch_pyr_level0(hipStream_t s, int w, int h, const float *image, float *out, int layout) {
+  hipLaunchKernelGGL(pyr_level0_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w * h, image, out,
+                     layout == IMG_AOS3 ? 3 : 4);
+}
+void launch_pyr_down(hipStream_t s, int w_prev, int wl, int hl, const float *prev, float *out, int layout) {
+  hipLaunchKernelGGL(pyr_down_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, w_prev, wl, hl, prev, out,
+                     layout == IMG_AOS3 ? 3 : 4);
+}
+void launch_pyr_grad(hipStream_t s, int wl, int hl, float *img, int layout) {
+  hipLaunchKernelGGL(pyr_grad_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, img,
+                     layout == IMG_AOS3 ? 3 : 4);
+}
+
+} // namespace dsm

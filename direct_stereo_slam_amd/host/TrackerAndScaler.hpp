@@ -1,0 +1,129 @@
+// TrackerAndScaler.hpp -- C++ host adaptor that keeps the public surface of the reference's
+// dso::TrackerAndScaler (src/scale_optimization/TrackerAndScaler.h:38-64) on top of the C ABI
+// (include/dsm_hotpath.h), so FrontEnd.cpp's call sites (FrontEnd.cpp:204-206, :797-798,
+// :992-998, :1032) keep their shape.  Header-only, plain C++11, no Eigen/Sophus/DSO needed:
+// the DSO types are reduced to the fields this path actually reads.  INTEGRATION.md shows the
+// three-line conversions from the real dso::FrameHessian / Sophus::SE3 / dso::AffLight.
+#pragma once
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dsm_hotpath.h"
+
+namespace dsm_host {
+
+// Sophus::SE3d as the path uses it: unit quaternion (Eigen coefficient order x,y,z,w) + translation
+struct SE3 {
+  double q[4] = {0, 0, 0, 1};
+  double t[3] = {0, 0, 0};
+};
+// dso::AffLight
+struct AffLight {
+  double a = 0, b = 0;
+  AffLight() {}
+  AffLight(double a_, double b_) : a(a_), b(b_) {}
+};
+// The fields of dso::FrameHessian read by the tracker: dIp[lvl] (TrackerAndScaler.cpp:709,1016),
+// ab_exposure (:718), shell->id (:323), aff_g2l() (:324)
+struct FrameView {
+  const float *const *dIp = nullptr; // per level AoS (I,dx,dy), w_l*h_l texels
+  float ab_exposure = 1.0f;
+  int shell_id = -1;
+  AffLight aff_g2l;
+  long long unique_id = -1; // identity of the pixel data, to skip repeated uploads
+};
+// Output of makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315): pc_u/pc_v/pc_idepth/pc_color + pc_n
+struct TemplateLists {
+  int n[DSM_MAX_LEVELS] = {0};
+  const float *pc_u[DSM_MAX_LEVELS] = {nullptr};
+  const float *pc_v[DSM_MAX_LEVELS] = {nullptr};
+  const float *pc_idepth[DSM_MAX_LEVELS] = {nullptr};
+  const float *pc_color[DSM_MAX_LEVELS] = {nullptr};
+};
+
+inline void check(int rc, const char *what) {
+  if (rc != DSM_OK) throw std::runtime_error(std::string(what) + ": " + dsm_last_error());
+}
+
+class TrackerAndScaler {
+public:
+  // reference: TrackerAndScaler(int w, int h, const std::vector<double>& tfm_vec, const Mat33f& K1)
+  TrackerAndScaler(dsm_context *ctx, int w, int h, int pyrLevelsUsed, const std::vector<double> &tfm_vec,
+                   const float K1_fx_fy_cx_cy[4], const dsm_params *params = nullptr)
+      : refFrameID(-1), lastRef(nullptr), lastRef_aff_g2l(0, 0), firstCoarseRMSE(-1), levels_(pyrLevelsUsed) {
+    if (tfm_vec.size() != 16) throw std::invalid_argument("tfm_vec must hold 16 doubles");
+    check(dsm_tracker_create(ctx, w, h, pyrLevelsUsed, tfm_vec.data(), K1_fx_fy_cx_cy, params, &t_), "dsm_tracker_create");
+    lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
+  }
+  ~TrackerAndScaler() { dsm_tracker_destroy(t_); }
+  TrackerAndScaler(const TrackerAndScaler &) = delete;
+  TrackerAndScaler &operator=(const TrackerAndScaler &) = delete;
+
+  // reference: makeK(CalibHessian*) reads fxl(), fyl(), cxl(), cyl() (TrackerAndScaler.cpp:121-124)
+  void makeK(float fxl, float fyl, float cxl, float cyl) { check(dsm_tracker_make_k(t_, fxl, fyl, cxl, cyl), "makeK"); }
+
+  // reference: setCoarseTrackingRef(std::vector<FrameHessian*>) -- the host keeps makeCoarseDepthL0
+  // (it walks the PointHessian graph) and hands its result over
+  void setCoarseTrackingRef(const FrameView &ref, const TemplateLists &tpl) {
+    check(dsm_tracker_set_ref(t_, ref.shell_id, ref.aff_g2l.a, ref.aff_g2l.b, ref.ab_exposure, tpl.n, tpl.pc_u, tpl.pc_v,
+                              tpl.pc_idepth, tpl.pc_color),
+          "setCoarseTrackingRef");
+    lastRef = &ref;
+    refFrameID = ref.shell_id;     // :323
+    lastRef_aff_g2l = ref.aff_g2l; // :324
+    firstCoarseRMSE = -1;          // :326
+  }
+
+  void scaleCoarseDepthL0(float scale) { check(dsm_tracker_scale_depth(t_, scale), "scaleCoarseDepthL0"); }
+
+  // reference: bool trackNewestCoarse(FrameHessian*, SE3&, AffLight&, int, Vec5, Vec5&, Output3DWrapper*)
+  bool trackNewestCoarse(const FrameView &newFrameHessian, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
+                         const double minResForAbort[5], double lastResiduals[5]) {
+    upload(newFrameHessian, DSM_SLOT_NEW_LEFT);
+    double pose[7] = {lastToNew_out.q[0], lastToNew_out.q[1], lastToNew_out.q[2], lastToNew_out.q[3],
+                      lastToNew_out.t[0], lastToNew_out.t[1], lastToNew_out.t[2]};
+    double aff[2] = {aff_g2l_out.a, aff_g2l_out.b};
+    double mr[DSM_MAX_LEVELS], lr[DSM_MAX_LEVELS];
+    for (int i = 0; i < DSM_MAX_LEVELS; i++) mr[i] = (i < 5 && minResForAbort) ? minResForAbort[i] : NAN;
+    int good = 0;
+    check(dsm_tracker_track(t_, pose, aff, coarsestLvl, mr, lr, lastFlowIndicators, &good), "trackNewestCoarse");
+    for (int i = 0; i < 4; i++) lastToNew_out.q[i] = pose[i];
+    for (int i = 0; i < 3; i++) lastToNew_out.t[i] = pose[4 + i];
+    aff_g2l_out.a = aff[0];
+    aff_g2l_out.b = aff[1];
+    if (lastResiduals)
+      for (int i = 0; i < 5; i++) lastResiduals[i] = lr[i];
+    return good != 0;
+  }
+
+  // reference: float optimizeScale(FrameHessian* fh1, float& scale, int coarsestLvl)
+  float optimizeScale(const FrameView &fh1, float &scale, int coarsestLvl) {
+    upload(fh1, DSM_SLOT_NEW_RIGHT);
+    float err = NAN;
+    check(dsm_tracker_optimize_scale(t_, &scale, coarsestLvl, &err), "optimizeScale");
+    return err;
+  }
+
+  dsm_tracker *handle() { return t_; }
+
+  // act as pure output (TrackerAndScaler.h:59-64)
+  int refFrameID;
+  const FrameView *lastRef;
+  AffLight lastRef_aff_g2l;
+  double lastFlowIndicators[3];
+  double firstCoarseRMSE;
+
+private:
+  void upload(const FrameView &f, int slot) {
+    if (f.unique_id >= 0 && f.unique_id == uploaded_[slot]) return; // same pixels already resident
+    check(dsm_tracker_upload_frame(t_, slot, f.dIp, f.ab_exposure), "upload_frame");
+    uploaded_[slot] = f.unique_id;
+  }
+  dsm_tracker *t_ = nullptr;
+  int levels_;
+  long long uploaded_[2] = {-1, -1};
+};
+
+} // namespace dsm_host

@@ -1,0 +1,112 @@
+"""Ring-key database: host mirror of `search_ringkey` (src/loop_closure/loop_detection/search_place.h:25-57)
+on the C ABI, plus the cross-GPU merge for the sharded DB.
+
+The device scan lives in csrc/ringkey_kernels.hip.  `merge_topk_allreduce_min` is the only
+collective on the whole hot path: k rounds of an element-wise all-reduce(min) over packed
+(dist2 << 32 | global index) int64 candidates with winner pop -- RCCL on GPUs (backend "nccl"),
+gloo in the CPU tests.  A slot-wise min of sorted triples would NOT be a correct top-k.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NO_CANDIDATE, c_float_p, c_int64_p, c_int_p, check
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def unpack(packed):
+    """packed int64 -> (dist2 float32, global index int64); NO_CANDIDATE -> (inf, -1)"""
+    packed = np.asarray(packed, np.int64)
+    idx = (packed & 0xFFFFFFFF).astype(np.int64)
+    bits = (packed >> 32).astype(np.uint32)
+    dist = bits.view(np.float32).astype(np.float32)
+    none = packed == NO_CANDIDATE
+    return np.where(none, np.float32(np.inf), dist), np.where(none, -1, idx)
+
+
+def candidates_from_packed(packed_row):
+    """threshold already applied on the device; drop the dummy (idx > 0) and emit idx-1
+    (search_place.h:34-38)"""
+    out = []
+    for p in np.asarray(packed_row, np.int64):
+        if p == NO_CANDIDATE:
+            continue
+        idx = int(p & 0xFFFFFFFF)
+        if idx > 0:
+            out.append(idx - 1)
+    return out
+
+
+def merge_topk_allreduce_min(local_sorted, k, all_reduce_min):
+    """local_sorted: (nq, k) int64 torch tensor, ascending per row, NO_CANDIDATE padded.
+    all_reduce_min(tensor) performs the in-place element-wise MIN all-reduce over the shards.
+    Returns the global (nq, k) top-k, identical on every rank."""
+    import torch
+
+    nq = local_sorted.shape[0]
+    ptr = torch.zeros(nq, dtype=torch.int64, device=local_sorted.device)
+    padded = torch.cat([local_sorted, torch.full((nq, 1), NO_CANDIDATE, dtype=torch.int64, device=local_sorted.device)], 1)
+    out = torch.empty((nq, k), dtype=torch.int64, device=local_sorted.device)
+    for r in range(k):
+        head = padded.gather(1, ptr[:, None])[:, 0].contiguous()
+        gmin = head.clone()
+        all_reduce_min(gmin)
+        out[:, r] = gmin
+        ptr = ptr + ((head == gmin) & (gmin != NO_CANDIDATE)).to(torch.int64)  # indices are unique: one owner pops
+    return out
+
+
+class RingKeyDB:
+    """flann::Index replacement + delay queue.  shard_rank/shard_count: this handle stores only the
+    global ordinals with ordinal % shard_count == shard_rank."""
+
+    def __init__(self, ctx, dim=20, margin=100, k=3, thres=0.1, dummy=None, capacity=1024, shard_rank=0, shard_count=1):
+        self.ctx, self.L = ctx, ctx.L
+        self.dim, self.k = dim, k
+        self.shard_rank, self.shard_count = shard_rank, shard_count
+        d = None if dummy is None else _fp(np.ascontiguousarray(dummy, np.float32))
+        h = C.c_void_p()
+        check(self.L.dsm_ringdb_create(ctx.h, dim, margin, k, thres, d, capacity, shard_rank, shard_count, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.L.dsm_ringdb_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def size(self):
+        return self.L.dsm_ringdb_size(self.h)
+
+    def add_points(self, keys):
+        keys = np.ascontiguousarray(keys, np.float32).reshape(-1, self.dim)
+        check(self.L.dsm_ringdb_add_points(self.h, _fp(keys), keys.shape[0]))
+
+    def enqueue(self, key):
+        key = np.ascontiguousarray(key, np.float32)
+        check(self.L.dsm_ringdb_enqueue(self.h, _fp(key)))
+
+    def search_ringkey(self, key):
+        """search_place.h:25-57 for an unsharded DB: returns the candidate list"""
+        key = np.ascontiguousarray(key, np.float32)
+        cand = (C.c_int * self.k)()
+        nc = C.c_int()
+        check(self.L.dsm_ringdb_query_then_enqueue(self.h, _fp(key), cand, C.byref(nc)))
+        return [cand[i] for i in range(nc.value)]
+
+    def knn_packed_host(self, queries):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim)
+        out = np.zeros((q.shape[0], self.k), np.int64)
+        check(self.L.dsm_ringdb_knn_packed_host(self.h, _fp(q), q.shape[0], out.ctypes.data_as(c_int64_p)))
+        return out
+
+    def knn_packed_device(self, d_queries_ptr, nq, d_out_ptr):
+        """queries / output are raw device pointers (e.g. torch tensors' data_ptr()); asynchronous on
+        the context stream -- call ctx.sync() before another stream consumes the result."""
+        check(self.L.dsm_ringdb_knn_packed_dev(self.h, C.c_void_p(d_queries_ptr), nq, C.c_void_p(d_out_ptr)))

@@ -1,0 +1,187 @@
+"""Python host-side mirror of the reference's `dso::TrackerAndScaler` public surface
+(src/scale_optimization/TrackerAndScaler.h:38-64) on top of the C ABI.  Used by tests/ and
+bench.py; the C++ adaptor for the ROS node is direct_stereo_slam_amd/host/TrackerAndScaler.hpp.
+
+Method names follow the reference: makeK, setCoarseTrackingRef (takes the template lists that
+makeCoarseDepthL0 produced), scaleCoarseDepthL0, trackNewestCoarse, optimizeScale; the public
+output fields refFrameID / lastFlowIndicators keep their names.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MAX_LEVELS, Params, Stats, c_double_p, c_float_p, c_int_p, check
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ptr_array(arrs):
+    arr = (c_float_p * len(arrs))()
+    for i, a in enumerate(arrs):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        arr[i] = _fp(a)
+    return arr
+
+
+def default_params():
+    p = Params()
+    _lib.load().dsm_params_default(C.byref(p))
+    return p
+
+
+class Context:
+    """device + stream + batch workspaces (dsm_context)"""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        check(self.L.dsm_context_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dsm_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def sync(self):
+        check(self.L.dsm_context_sync(self.h))
+
+    def set_timing(self, on):
+        check(self.L.dsm_context_set_timing(self.h, int(on)))
+
+    def stats(self):
+        s = Stats()
+        check(self.L.dsm_context_get_stats(self.h, C.byref(s)))
+        return s
+
+    # ---- batched forms -----------------------------------------------------------------
+    def track_batch(self, trackers, poses, affs, coarsest, min_res=None):
+        n = len(trackers)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        poses = np.ascontiguousarray(poses, np.float64).reshape(n, 7).copy()
+        affs = np.ascontiguousarray(affs, np.float64).reshape(n, 2).copy()
+        mr = None
+        if min_res is not None:
+            mr = np.ascontiguousarray(min_res, np.float64).reshape(n, MAX_LEVELS)
+        last = np.zeros((n, MAX_LEVELS))
+        flow = np.zeros((n, 3))
+        good = np.zeros(n, np.int32)
+        check(self.L.dsm_track_batch(self.h, n, hs, _dp(poses), _dp(affs), coarsest, None if mr is None else _dp(mr),
+                                     _dp(last), _dp(flow), good.ctypes.data_as(c_int_p)))
+        return good.astype(bool), poses, affs, last, flow
+
+    def optimize_scale_batch(self, trackers, scales, coarsest):
+        n = len(trackers)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        sc = np.ascontiguousarray(scales, np.float32).reshape(n).copy()
+        err = np.zeros(n, np.float32)
+        check(self.L.dsm_optimize_scale_batch(self.h, n, hs, _fp(sc), coarsest, _fp(err)))
+        return err, sc
+
+
+class TrackerAndScaler:
+    def __init__(self, ctx, w, h, nlevels, tfm_vec, K1, params=None):
+        """tfm_vec: 16 doubles of T_stereo (cams/*/T_stereo.yaml); K1 = (fx,fy,cx,cy) of camera 1
+        (reference ctor, TrackerAndScaler.cpp:47-109)."""
+        self.ctx = ctx
+        self.L = ctx.L
+        self.w, self.hgt, self.nlevels = w, h, nlevels
+        self.params = params if params is not None else default_params()
+        T = np.ascontiguousarray(np.asarray(tfm_vec, np.float64).reshape(16))
+        K1 = np.ascontiguousarray(np.asarray(K1, np.float32))
+        hnd = C.c_void_p()
+        check(self.L.dsm_tracker_create(ctx.h, w, h, nlevels, _dp(T), _fp(K1), C.byref(self.params), C.byref(hnd)))
+        self.h = hnd
+        self.lastFlowIndicators = np.full(3, 1000.0)
+        self.firstCoarseRMSE = -1.0
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.L.dsm_tracker_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def refFrameID(self):
+        return self.L.dsm_tracker_ref_frame_id(self.h)
+
+    def makeK(self, fx, fy, cx, cy):
+        check(self.L.dsm_tracker_make_k(self.h, fx, fy, cx, cy))
+
+    def setCoarseTrackingRef(self, ref_frame_id, ref_aff, ref_exposure, pc_u, pc_v, pc_idepth, pc_color):
+        n = (C.c_int * self.nlevels)(*[len(a) for a in pc_u])
+        arrs = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (pc_u, pc_v, pc_idepth, pc_color)]
+        check(self.L.dsm_tracker_set_ref(self.h, ref_frame_id, float(ref_aff[0]), float(ref_aff[1]), ref_exposure, n,
+                                         *[_ptr_array(a) for a in arrs]))
+        self.firstCoarseRMSE = -1.0
+
+    def scaleCoarseDepthL0(self, scale):
+        check(self.L.dsm_tracker_scale_depth(self.h, scale))
+
+    def get_template(self, lvl):
+        n = C.c_int()
+        check(self.L.dsm_tracker_get_template(self.h, lvl, C.byref(n), None, None, None, None))
+        out = [np.zeros(n.value, np.float32) for _ in range(4)]
+        check(self.L.dsm_tracker_get_template(self.h, lvl, C.byref(n), *[_fp(a) for a in out]))
+        return out
+
+    def upload_frame(self, slot, dIp, ab_exposure=1.0):
+        dIp = [np.ascontiguousarray(a, np.float32) for a in dIp]
+        check(self.L.dsm_tracker_upload_frame(self.h, slot, _ptr_array(dIp), ab_exposure))
+
+    def upload_image(self, slot, image, ab_exposure=1.0):
+        image = np.ascontiguousarray(image, np.float32)
+        assert image.shape == (self.hgt, self.w)
+        check(self.L.dsm_tracker_upload_image(self.h, slot, _fp(image), ab_exposure))
+
+    def get_frame(self, slot, lvl):
+        out = np.zeros((self.hgt >> lvl, self.w >> lvl, 3), np.float32)
+        check(self.L.dsm_tracker_get_frame(self.h, slot, lvl, _fp(out)))
+        return out
+
+    def calcResPose(self, lvl, pose, aff, cutoff):
+        """fused calcResPose + calcGSSSEPose: returns (rs[6], H[8,8], b[8], n_warped)"""
+        pose = np.ascontiguousarray(pose, np.float64)
+        aff = np.ascontiguousarray(aff, np.float64)
+        rs, H, b, n = np.zeros(6), np.zeros(64), np.zeros(8), C.c_int()
+        check(self.L.dsm_tracker_calc_res_pose(self.h, lvl, _dp(pose), _dp(aff), cutoff, _dp(rs), _dp(H), _dp(b), C.byref(n)))
+        return rs, H.reshape(8, 8), b, n.value
+
+    def calcResScale(self, lvl, scale, cutoff):
+        rs, H, b, n = np.zeros(6), C.c_float(), C.c_float(), C.c_int()
+        check(self.L.dsm_tracker_calc_res_scale(self.h, lvl, scale, cutoff, _dp(rs), C.byref(H), C.byref(b), C.byref(n)))
+        return rs, H.value, b.value, n.value
+
+    def trackNewestCoarse(self, lastToNew, aff_g2l, coarsestLvl, minResForAbort=None):
+        """returns (good, lastToNew_out, aff_g2l_out, lastResiduals) and sets lastFlowIndicators"""
+        pose = np.array(lastToNew, np.float64)
+        aff = np.array(aff_g2l, np.float64)
+        mr = None if minResForAbort is None else np.ascontiguousarray(minResForAbort, np.float64)
+        last, flow, good = np.zeros(MAX_LEVELS), np.zeros(3), C.c_int()
+        check(self.L.dsm_tracker_track(self.h, _dp(pose), _dp(aff), coarsestLvl, None if mr is None else _dp(mr), _dp(last),
+                                       _dp(flow), C.byref(good)))
+        self.lastFlowIndicators = flow
+        return bool(good.value), pose, aff, last
+
+    def optimizeScale(self, scale, coarsestLvl):
+        """returns (error, scale_out) as the reference's `float optimizeScale(fh1, float &scale, lvl)`"""
+        s, err = C.c_float(scale), C.c_float()
+        check(self.L.dsm_tracker_optimize_scale(self.h, C.byref(s), coarsestLvl, C.byref(err)))
+        return err.value, s.value
+
+    def reduction_geometry(self, lvl, n):
+        t, p, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.L.dsm_reduction_geometry(self.h, lvl, n, C.byref(t), C.byref(p), C.byref(c)))
+        return t.value, p.value, c.value

@@ -1,0 +1,208 @@
+/*
+ * dsm_hotpath.h -- C ABI of the MI355X-native direct photometric hot path.
+ *
+ * Drop-in boundary for the hot path of IRVLab/direct_stereo_slam.
+ * The reference has no FFI layer: the seam is the C++ class `dso::TrackerAndScaler`
+ * (src/scale_optimization/TrackerAndScaler.h:34-137) and the free functions
+ * `search_ringkey` / `search_sc` (src/loop_closure/loop_detection/search_place.h:25-84).
+ * Every entry point below names the reference interface it replaces (file:line,
+ * relative to the reference tree).  The host adaptor that keeps the reference's C++
+ * surface on top of this ABI is direct_stereo_slam_amd/host/TrackerAndScaler.hpp; the
+ * reference-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, POD only, no exceptions; every function returns DSM_OK (0) or a negative
+ *    dsm_status.  dsm_last_error() gives a thread-local human readable message.
+ *  - all image / template data is IEEE float32; poses and affine brightness are float64
+ *    exactly as the reference keeps them (Sophus SE3d, AffLight{double a,b}).
+ *  - pose layout: double[7] = {qx, qy, qz, qw, tx, ty, tz} (Eigen quaternion coefficient
+ *    order, then translation) for the transform refToNew / lastToNew.
+ *  - host pointers are read during the call and never retained after it returns.
+ *  - one HIP stream per context; one call in flight per context (the reference calls
+ *    this path under track_mutex_ / coarse_tracker_swap_mutex_, FrontEnd.cpp:589,628).
+ *  - there is NO CPU fallback: every entry point fails with DSM_ERR_NO_DEVICE when no
+ *    gfx950 device is usable.
+ */
+#ifndef DSM_HOTPATH_H
+#define DSM_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_ABI_VERSION 1
+#define DSM_MAX_LEVELS 6 /* DSO PYR_LEVELS; the reference tracker uses <= 5 (TrackerAndScaler.cpp:457,463) */
+
+typedef enum dsm_status {
+  DSM_OK = 0,
+  DSM_ERR_INVALID = -1,   /* bad argument */
+  DSM_ERR_NO_DEVICE = -2, /* no usable HIP device */
+  DSM_ERR_HIP = -3,       /* HIP runtime error, see dsm_last_error() */
+  DSM_ERR_STATE = -4,     /* call order violated (e.g. track before set_ref) */
+  DSM_ERR_NOMEM = -5
+} dsm_status;
+
+typedef struct dsm_context dsm_context; /* device + stream + workspaces */
+typedef struct dsm_tracker dsm_tracker; /* one TrackerAndScaler instance */
+typedef struct dsm_ringdb dsm_ringdb;   /* ring-key database + delay queue */
+
+/* Runtime parameters.  These are DSO globals / literals in the reference; the values
+ * written by dsm_params_default() are the upstream DSO defaults as used by the
+ * reference's default `mode=1` (src/main.cpp:117-121). */
+typedef struct dsm_params {
+  float huber_th;                     /* setting_huberTH            (TrackerAndScaler.cpp:727,795)   9    */
+  float coarse_cutoff_th;             /* setting_coarseCutoffTH     (TrackerAndScaler.cpp:476)       20   */
+  float scale_xi_rot;                 /* SCALE_XI_ROT               (TrackerAndScaler.cpp:542,685)   1    */
+  float scale_xi_trans;               /* SCALE_XI_TRANS             (TrackerAndScaler.cpp:543,686)   0.5  */
+  float scale_a;                      /* SCALE_A                    (TrackerAndScaler.cpp:544,687)   10   */
+  float scale_b;                      /* SCALE_B                    (TrackerAndScaler.cpp:545,688)   1000 */
+  float affine_opt_mode_a;            /* setting_affineOptModeA     (TrackerAndScaler.cpp:511-534)   0    */
+  float affine_opt_mode_b;            /* setting_affineOptModeB                                      0    */
+  float lambda_extrapolation_limit;   /* literal                    (TrackerAndScaler.cpp:464,863)   0.001*/
+  int max_iterations[DSM_MAX_LEVELS]; /* literal {10,20,50,50,50}   (TrackerAndScaler.cpp:463,862); [5]=50 is an extension */
+  int poll_chunk;                     /* launches enqueued between host polls of the LM state; 0 = never poll
+                                         (enqueue the worst case, finished problems early-exit).  Not a
+                                         reference parameter; does not change results. */
+} dsm_params;
+
+/* Statistics of the last track / optimize_scale (batch) call on a context. */
+typedef struct dsm_stats {
+  int64_t evals[DSM_MAX_LEVELS];        /* fused residual+Jacobian evaluations executed, summed over the batch */
+  int64_t launches[DSM_MAX_LEVELS];     /* eval kernel launches per level */
+  int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + 12*w_l*h_l   */
+  double eval_kernel_ms[DSM_MAX_LEVELS];/* HIP-event time of the eval kernels per level (only when timing enabled) */
+  double total_ms;                      /* HIP-event time of the whole call */
+  int64_t polls;                        /* host polls of the device LM state */
+} dsm_stats;
+
+const char *dsm_last_error(void);
+int dsm_abi_version(void);
+void dsm_params_default(dsm_params *p);
+
+/* ---- context ------------------------------------------------------------------------- */
+int dsm_context_create(int device_ordinal, dsm_context **out);
+int dsm_context_destroy(dsm_context *ctx);
+int dsm_context_sync(dsm_context *ctx);
+/* enable per-level HIP-event timing of the eval kernels (off by default) */
+int dsm_context_set_timing(dsm_context *ctx, int enable);
+int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out);
+/* raw hipStream_t of the context (for callers that order their own device work) */
+void *dsm_context_stream(dsm_context *ctx);
+
+/* ---- TrackerAndScaler ---------------------------------------------------------------- */
+/* replaces TrackerAndScaler::TrackerAndScaler(w,h,tfm_vec,K1)  (TrackerAndScaler.cpp:47-109).
+ * T_f1_f0: row-major 4x4 stereo extrinsic (cams/<set>/T_stereo.yaml); K1 = {fx,fy,cx,cy} of camera 1. */
+int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
+                       const float K1[4], const dsm_params *params, dsm_tracker **out);
+/* replaces ~TrackerAndScaler (TrackerAndScaler.cpp:111-115) */
+int dsm_tracker_destroy(dsm_tracker *t);
+/* replaces TrackerAndScaler::makeK(CalibHessian*) (TrackerAndScaler.cpp:117-141) */
+int dsm_tracker_make_k(dsm_tracker *t, float fx, float fy, float cx, float cy);
+/* replaces the OUTPUT of TrackerAndScaler::setCoarseTrackingRef (TrackerAndScaler.cpp:317-327):
+ * the per-level template lists pc_u/pc_v/pc_idepth/pc_color with pc_n (built by
+ * makeCoarseDepthL0 :143-315, or by dsm_make_coarse_depth_l0 below), plus refFrameID,
+ * lastRef_aff_g2l and lastRef->ab_exposure. */
+int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, double ref_aff_b,
+                        float ref_exposure, const int *n, const float *const *pc_u,
+                        const float *const *pc_v, const float *const *pc_idepth,
+                        const float *const *pc_color);
+/* replaces TrackerAndScaler::scaleCoarseDepthL0(scale) (TrackerAndScaler.cpp:329-336) */
+int dsm_tracker_scale_depth(dsm_tracker *t, float scale);
+/* read back the device template of one level (tests; debugPlotIDepthMap replacement) */
+int dsm_tracker_get_template(dsm_tracker *t, int lvl, int *n, float *pc_u, float *pc_v,
+                             float *pc_idepth, float *pc_color);
+
+enum { DSM_SLOT_NEW_LEFT = 0, DSM_SLOT_NEW_RIGHT = 1 };
+/* replaces the consumption of FrameHessian::dIp[lvl] (TrackerAndScaler.cpp:709,1016):
+ * dIp[lvl] is the reference's AoS Eigen::Vector3f (I,dx,dy) array of w_l*h_l texels. */
+int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, float ab_exposure);
+/* "next" row N1: build the (I,dx,dy) pyramid on the device from the level-0 float image
+ * (upstream DSO FrameHessian::makeImages, call sites FrontEnd.cpp:605,680). */
+int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure);
+/* read back one pyramid level (AoS float3) */
+int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out);
+
+/* replaces calcResPose + calcGSSSEPose as ONE fused evaluation (TrackerAndScaler.cpp:699-852, 640-697).
+ * rs[6] as the reference's Vec6; H row-major 8x8 and b[8] in double, already SCALE_*-scaled.
+ * n_warped = pose_buf_warped_n_ (padded to a multiple of 4). */
+int dsm_tracker_calc_res_pose(dsm_tracker *t, int lvl, const double pose[7], const double aff[2],
+                              float cutoff_th, double rs[6], double H[64], double b[8],
+                              int *n_warped);
+/* replaces calcResScale + calcGSSSEScale (TrackerAndScaler.cpp:1007-1172, 966-1005) */
+int dsm_tracker_calc_res_scale(dsm_tracker *t, int lvl, float scale, float cutoff_th, double rs[6],
+                               float *H, float *b, int *n_warped);
+
+/* replaces TrackerAndScaler::trackNewestCoarse (TrackerAndScaler.cpp:451-638).
+ * min_res_for_abort / last_residuals: DSM_MAX_LEVELS doubles (reference: Vec5; NaN = no limit).
+ * flow_out = lastFlowIndicators.  *good = the reference's bool return value. */
+int dsm_tracker_track(dsm_tracker *t, double pose_io[7], double aff_io[2], int coarsest_lvl,
+                      const double *min_res_for_abort, double *last_residuals, double flow_out[3],
+                      int *good);
+/* replaces TrackerAndScaler::optimizeScale (TrackerAndScaler.cpp:854-964); err_out = return value */
+int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl, float *err_out);
+
+/* Batched forms: n independent trackers of one context advance in lock-step launches
+ * (SURVEY.md section 7 "throughput mode").  Arrays are n x 7 / n x 2 / n x DSM_MAX_LEVELS / n x 3. */
+int dsm_track_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, double *pose_io, double *aff_io,
+                    int coarsest_lvl, const double *min_res_for_abort, double *last_residuals,
+                    double *flow_out, int *good);
+int dsm_optimize_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, float *scale_io,
+                             int coarsest_lvl, float *err_out);
+
+/* outputs the reference exposes as public members (TrackerAndScaler.h:59-64) */
+int dsm_tracker_ref_frame_id(dsm_tracker *t);
+
+/* Geometry of the device reduction for level lvl with n template points (tests / DESIGN.md):
+ * threads per workgroup, points per thread, number of chunks. */
+int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pts_per_thread,
+                           int *chunks);
+
+/* ---- ring-key database (ScanContext place recognition) ------------------------------- */
+/* replaces the flann::Index built at LoopHandler.cpp:35-39 plus the function-static delay
+ * queue of search_ringkey (search_place.h:43-45).  dim=20, margin=LOOP_MARGIN=100,
+ * k=FLANN_NN=3, thres=RINGKEY_THRES=0.1 in the reference.  dummy_key (dim floats, may be
+ * NULL = zeros) is the content of the reference's uninitialised index slot 0 (quirk Q8).
+ * capacity = number of keys the device shard can hold (grows by doubling when exceeded).
+ * shard_rank / shard_count: this handle stores only ordinals with ordinal % count == rank. */
+int dsm_ringdb_create(dsm_context *ctx, int dim, int margin, int k, float thres,
+                      const float *dummy_key, int64_t capacity, int shard_rank, int shard_count,
+                      dsm_ringdb **out);
+int dsm_ringdb_destroy(dsm_ringdb *db);
+/* number of entries in the (global) index, dummy included (flann Index::size()) */
+int64_t dsm_ringdb_size(dsm_ringdb *db);
+/* replaces search_ringkey (search_place.h:25-57): query, threshold, then delay-queue insert.
+ * cand_out[k] receives 0..k candidate ordinals (index-1) in ascending-distance order. */
+int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_out, int *ncand_out);
+/* bulk insert (bench / sharded DB): n_keys keys appended directly to the index */
+int dsm_ringdb_add_points(dsm_ringdb *db, const float *keys, int64_t n_keys);
+/* the delay-queue half of search_ringkey alone (search_place.h:41-56): used by sharded callers
+ * that merge candidates across GPUs between the query and the insert */
+int dsm_ringdb_enqueue(dsm_ringdb *db, const float *key);
+/* batched exact k-NN over this shard: for each of nq queries (host pointer, nq x dim) writes k packed
+ * candidates  (int64 = float_bits(dist2) << 32 | global index), ascending, into the DEVICE buffer
+ * d_packed_out (nq*k int64).  Only entries with dist2 < thres are candidates; empty slots hold
+ * DSM_RINGDB_NO_CANDIDATE.  The cross-shard merge is k rounds of an element-wise min over ranks
+ * (RCCL all-reduce(min)) with winner pop, see direct_stereo_slam_amd/ringdb.py. */
+#define DSM_RINGDB_NO_CANDIDATE 0x7FFFFFFFFFFFFFFFll
+int dsm_ringdb_knn_packed(dsm_ringdb *db, const float *queries, int nq, void *d_packed_out);
+/* same, queries already on the device (nq x dim float32) */
+int dsm_ringdb_knn_packed_dev(dsm_ringdb *db, const void *d_queries, int nq, void *d_packed_out);
+/* same, result copied to host memory (nq*k int64) */
+int dsm_ringdb_knn_packed_host(dsm_ringdb *db, const float *queries, int nq, int64_t *packed_out);
+
+/* replaces the inner loop of search_sc (search_place.h:67-79): sparse merge-join distance of
+ * two ScanContext signatures.  Host side by design (<= 3 candidates per query). */
+float dsm_sc_distance(const int *sigA_idx, const double *sigA_val, int nA, const int *sigB_idx,
+                      const double *sigB_val, int nB, int sc_width);
+/* replaces search_sc (search_place.h:59-84) over caller supplied candidate signatures */
+int dsm_search_sc(const int *sig_idx, const double *sig_val, int n_sig, int n_cand,
+                  const int *cand_ids, const int *const *cand_idx, const double *const *cand_val,
+                  const int *cand_n, int sc_width, int *res_idx, float *res_diff);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSM_HOTPATH_H */

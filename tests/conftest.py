@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """product library + oracle are built once per session (hipcc cross-compiles without a GPU)"""
+    import __graft_entry__ as g
+
+    g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def ctx(built):
+    from direct_stereo_slam_amd.tracker import Context
+
+    c = Context(0)  # raises DsmError on a box without a GPU: gpu tests must not silently pass
+    yield c
+    c.close()
