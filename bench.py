@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/s of the direct photometric hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (config.workload): BASELINE.json configs[1] shape -- KITTI 00, raw 1241x376 cropped to the
+reference's working size 1232x368 (cams/kitti/0_2/camera0.txt:2-4), 5 pyramid levels (what DSO's
+level rule gives for this size), dense template (every interior pixel is a
+point), synthetic seeded scenes with ground-truth motion, LM iterations AS EXECUTED by the
+reference's rules (TrackerAndScaler.cpp:451-638, :854-964).  A "step" = B independent stereo
+frames per GPU: every frame is tracked against its keyframe template (trackNewestCoarse from the
+identity pose) and every 5th frame additionally runs the stereo scale optimiser from s=1
+(keyframe cadence, FrontEnd.cpp:806-811, "scale trapped" steady state).  Inputs (pyramids,
+templates) are resident in HBM when the timed region starts.
+
+Tracking does not shard inside a frame: N GPUs = N independent replicas,
+no data-path collective ("scaling": "weak").  With --ringkey the ring-key DB is sharded across the
+ranks and merged with RCCL all-reduce(min) instead (a secondary benchmark, not the default).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="independent stereo frames in flight per GPU")
+    ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes (cycled over the batch)")
+    ap.add_argument("--config", default="S1", choices=["S1", "S2"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension)")
+    ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
+    ap.add_argument("--kf-every", type=int, default=5)
+    ap.add_argument("--poll-chunk", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
+    ap.add_argument("--rk-n", type=int, default=1_000_000)
+    ap.add_argument("--rk-q", type=int, default=1024)
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, local, world
+
+
+def barrier_sync(world):
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world):
+    import torch
+
+    if world == 1:
+        return x
+    import torch.distributed as dist
+
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def build_workload(args, ctx, rank):
+    """B trackers on this GPU; pyramids are built on the device from the raw float image."""
+    from direct_stereo_slam_amd import synth as S
+    from direct_stereo_slam_amd.tracker import TrackerAndScaler, default_params
+
+    if args.config == "S1":
+        w, h, nl = 1232, 368, 5
+        K = S.kitti_K_work()
+    else:
+        w, h, nl = 1248, 384, 6
+        fx, fy, cx, cy = S.KITTI_K_RAW
+        K = (fx, fy, cx + (1248 - 1241) / 2.0, cy + (384 - 376) / 2.0)
+    T = S.KITTI_T_STEREO
+    params = default_params()
+    params.poll_chunk = args.poll_chunk
+    scenes = []
+    for i in range(args.scenes):
+        seed = 0x5EED0000 + 1000 * rank + i
+        scene = S.PlaneScene(seed=seed)
+        rng = np.random.default_rng(seed)
+        ref = scene.render(K, w, h, noise=2.0, rng=rng)
+        R, t = S.random_motion(rng)
+        new = scene.render(K, w, h, R, t, a=0.02, b=3.0, noise=2.0, rng=rng)
+        right = scene.render(K, w, h, T[:3, :3], T[:3, 3], noise=2.0, rng=rng)
+        scenes.append((scene, ref, new, right, S.pose_from_Rt(R, t)))
+    trackers, gts, host = [], [], []
+    for b in range(args.batch):
+        scene, ref, new, right, gt = scenes[b % args.scenes]
+        trk = TrackerAndScaler(ctx, w, h, nl, T, K, params)
+        trk.makeK(*K)
+        trk.upload_image(0, ref, 1.0)  # device makeImages of the keyframe, read back for the template colours
+        ref_p = [trk.get_frame(0, l) for l in range(nl)]
+        if args.template == "dense":
+            tpl = S.dense_template(scene, K, w, h, nl, ref_p)
+        else:
+            tpl = S.sparse_template(scene, K, w, h, nl, ref_p, n0=10000, seed=b)
+        trk.setCoarseTrackingRef(b, (0.0, 0.0), 1.0, *tpl)
+        trk.upload_image(0, new, 1.0)
+        trk.upload_image(1, right, 1.0)
+        trackers.append(trk)
+        gts.append(gt)
+        if b < args.cpu_frames:
+            host.append((tpl, new, right))
+    return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params)
+
+
+def one_step(ctx, wl, kf_idx):
+    from direct_stereo_slam_amd import synth as S
+
+    B = len(wl["trackers"])
+    poses0 = np.tile(S.IDENTITY_POSE, (B, 1))
+    good, poses, affs, last, flow = ctx.track_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1)
+    st_track = ctx.stats()
+    kf = [wl["trackers"][i] for i in kf_idx]
+    err, sc = ctx.optimize_scale_batch(kf, np.ones(len(kf)), wl["nl"] - 1)
+    st_scale = ctx.stats()
+    return good, poses, err, sc, st_track, st_scale
+
+
+def cpu_baseline(args, wl):
+    """the oracle (kind 'port') timed on this box's host cores: 1 thread, as the reference runs this
+    path on the image-callback thread.  Built with -O3 -march=native like CMakeLists.txt:4-6."""
+    from direct_stereo_slam_amd import synth as S
+    from oracle import oracle as O
+
+    nl, w, h = wl["nl"], wl["w"], wl["h"]
+    frames = wl["host"]
+    if not frames:
+        return None
+    trks = []
+    for tpl, new, right in frames:
+        orc = O.OracleTracker(w, h, nl, wl["T"], wl["K"], native=True)
+        orc.make_k(*wl["K"])
+        orc.set_ref(0, 0.0, 0.0, 1.0, *tpl)
+        orc.set_frame(0, O.make_images(new, nl, native=True), 1.0)
+        orc.set_frame(1, O.make_images(right, nl, native=True), 1.0)
+        trks.append(orc)
+    t0 = time.perf_counter()
+    for i, orc in enumerate(trks):
+        orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        if i % args.kf_every == 0:
+            orc.optimize_scale(1.0, nl - 1)
+    dt = time.perf_counter() - t0
+    return {"value": len(trks) / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+            "sample": f"{len(trks)} of the same {w}x{h}x{nl} dense frames (track + scale-opt every {args.kf_every}th), "
+                      f"oracle/dsm_oracle.c -O3 -march=native, {dt:.2f} s"}
+
+
+def bench_tracking(args):
+    import torch
+
+    from direct_stereo_slam_amd.tracker import Context
+
+    rank, local, world = dist_setup(args.gpus)
+    ctx = Context(local)
+    wl = build_workload(args, ctx, rank)
+    B = args.batch
+    kf_idx = list(range(0, B, args.kf_every))
+    for _ in range(args.warmup):
+        one_step(ctx, wl, kf_idx)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step(ctx, wl, kf_idx)
+    ctx.sync()
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    good, poses, err, sc, st_track, st_scale = out
+
+    # accuracy of the last step against the synthetic ground truth (sanity, not the metric)
+    terr = float(np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max())
+
+    # roofline of the dominant kernel (level-0 pose eval): one extra step with HIP-event timing
+    ctx.set_timing(True)
+    out_t = one_step(ctx, wl, kf_idx)
+    ctx.set_timing(False)
+    stt = out_t[4]
+    n0 = len(wl["trackers"][0].get_template(0)[0])
+    bytes_eval0 = 16 * n0 + 12 * wl["w"] * wl["h"]
+    l0_ms = stt.eval_kernel_ms[0]
+    l0_launches = stt.launches[0]
+    l0_evals = stt.evals[0]
+    achieved = (l0_evals * bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "eval_kernel<pose, LVL0>",
+                "bytes_per_launch": l0_evals * bytes_eval0 / max(1, l0_launches),
+                "avg_launch_us": 1e3 * l0_ms / max(1, l0_launches), "launches": int(l0_launches)}
+    all_bytes = stt.algorithmic_bytes + out_t[5].algorithmic_bytes
+    frames = world * B * args.steps
+    res = {
+        "metric": "stereo frames/sec @ 1241x376, 6-level pyramid, 1 MI355X; ATE vs CPU ref",
+        "value": frames / dt,
+        "unit": "stereo frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
+                               f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
+                               f"track every frame + scale-opt every {args.kf_every}th",
+                   "frames_in_flight_per_gpu": B, "replicas": world, "poll_chunk": args.poll_chunk,
+                   "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
+                   "algorithmic_MB_per_frame": all_bytes / B / 1e6,
+                   "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,
+                   "max_abs_translation_error_m": terr, "all_tracked": bool(good.all())},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(args, wl)
+    else:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+def bench_ringkey(args):
+    """secondary: sharded ring-key DB, RCCL all-reduce(min) merge; value = queries/s"""
+    import torch
+
+    from direct_stereo_slam_amd.ringdb import RingKeyDB, merge_topk_allreduce_min
+    from direct_stereo_slam_amd.tracker import Context
+
+    rank, local, world = dist_setup(args.gpus)
+    ctx = Context(local)
+    rng = np.random.default_rng(1234)
+    p = rng.uniform(0.1, 0.9, 20)
+    keys = (rng.binomial(60, p, size=(args.rk_n, 20)) / 60.0).astype(np.float32)
+    q = (keys[rng.integers(args.rk_n, size=args.rk_q)] + rng.normal(0, 0.02, (args.rk_q, 20))).astype(np.float32)
+    db = RingKeyDB(ctx, capacity=args.rk_n // world + 16, shard_rank=rank, shard_count=world)
+    db.add_points(keys)
+    dq = torch.from_numpy(q).cuda()
+    out = torch.empty((args.rk_q, 3), dtype=torch.int64, device="cuda")
+
+    def allmin(t):
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+
+    def step():
+        db.knn_packed_device(dq.data_ptr(), args.rk_q, out.data_ptr())
+        ctx.sync()
+        return merge_topk_allreduce_min(out, 3, allmin)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = step()
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    if rank == 0:
+        sweep = 80 * args.rk_n + 104 * args.rk_q
+        print(json.dumps({"metric": "ring-key k=3 queries/s over a sharded DB", "value": args.rk_q * args.steps / dt,
+                          "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"ring-key DB N={args.rk_n} x 20 float, Q={args.rk_q}, k=3, thres 0.1",
+                                     "db_sweep_GBps": sweep * args.steps / dt / 1e9}}))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = parse()
+    if a.ringkey:
+        bench_ringkey(a)
+    else:
+        bench_tracking(a)

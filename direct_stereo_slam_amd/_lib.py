@@ -99,6 +99,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: this image's PyTorch bundles its own libamdhip64.so (same SONAME
+    # libamdhip64.so.7 as /opt/rocm's).  If torch is imported AFTER this library, the loader maps a
+    # second copy of the runtime; imported before, ours resolves to the already loaded one.  So when
+    # torch is installed, make sure it is loaded first (bench.py and the RCCL merge use it anyway).
+    import sys
+
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: plain /opt/rocm runtime
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -90,7 +90,9 @@ __device__ __forceinline__ void interp33(const DSM_GLOBAL float *img, float x, f
 // ------------------------------------------------------------------------------------------
 // eval kernel
 // ------------------------------------------------------------------------------------------
-template <int MODE, int LAYOUT>
+// LVL0 = true is the level-0 instantiation (adds the flow indicators); it is also the dominant kernel
+// of the path and shows up under its own symbol in rocprofv3 kernel traces.
+template <int MODE, int LAYOUT, bool LVL0>
 __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
   // handles the 8*P such points of this chunk in a single pass.
   float fT = 0.f, fRT = 0.f, fNum = 0.f;
-  if (lvl == 0 && tid < 8 * P) {
+  if (LVL0 && tid < 8 * P) {
     const int i = chunk_start + 32 * tid;
     if (i < n) {
       const fvec4 p = pts[i];
@@ -308,20 +310,31 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   }
 }
 
+template <int MODE, int LAYOUT>
+static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
+                           float *partials, int partial_stride) {
+  if (lvl == 0)
+    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl);
+  else
+    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl);
+}
+
 void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
                  int partial_stride) {
-  dim3 grid(grid_x, nprob), block(kThreads);
+  dim3 grid(grid_x, nprob);
   if (mode == 0) {
     if (layout == IMG_AOS3)
-      hipLaunchKernelGGL((eval_kernel<0, IMG_AOS3>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+      launch_eval_ml<0, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
     else
-      hipLaunchKernelGGL((eval_kernel<0, IMG_AOS4>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+      launch_eval_ml<0, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
   } else {
     if (layout == IMG_AOS3)
-      hipLaunchKernelGGL((eval_kernel<1, IMG_AOS3>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+      launch_eval_ml<1, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
     else
-      hipLaunchKernelGGL((eval_kernel<1, IMG_AOS4>), grid, block, 0, s, trackers, states, partials, partial_stride, lvl);
+      launch_eval_ml<1, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
   }
 }
 

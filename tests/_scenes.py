@@ -1,0 +1,64 @@
+"""Shared seeded scene builder for the tests (numpy only + the oracle's makeImages)."""
+import numpy as np
+
+from direct_stereo_slam_amd import synth as S
+from oracle import oracle as O
+
+# (w, h, kitti level whose intrinsics are used, nlevels)
+SIZES = {
+    "tiny": (154, 46, 3, 2),     # golden fixture size suggested by SURVEY.md section 8c
+    "small": (308, 92, 2, 3),
+    "medium": (616, 184, 1, 4),
+    "kitti": (1232, 368, 0, 5),  # S1: what the reference actually runs
+}
+
+
+class Scene:
+    pass
+
+
+def make_scene(size="small", seed=3, noise=1.0, template="dense", idepth_scale=1.0, a=0.02, b=3.0, n0=10000,
+               motion_scale=1.0, wavelength_px=(8.0, 128.0)):
+    w, h, klvl, nl = SIZES[size]
+    K = S.level_K(S.kitti_K_work(), klvl)
+    scene = S.PlaneScene(seed=seed, fx_ref=K[0], wavelength_px=wavelength_px)
+    rng = np.random.default_rng(seed + 100)
+    sc = Scene()
+    sc.w, sc.h, sc.nl, sc.K, sc.T = w, h, nl, K, S.KITTI_T_STEREO
+    ref = scene.render(K, w, h, noise=noise, rng=rng)
+    R, t = S.random_motion(rng)
+    if motion_scale != 1.0:
+        R, t = S.random_motion(np.random.default_rng(seed + 7), sigma_t=np.array((0.05, 0.05, 0.2)) * motion_scale,
+                               sigma_r=0.005 * motion_scale)
+    new = scene.render(K, w, h, R, t, a=a, b=b, noise=noise, rng=rng)
+    right = scene.render(K, w, h, sc.T[:3, :3], sc.T[:3, 3], noise=noise, rng=rng)
+    sc.ref_img, sc.new_img, sc.right_img = ref, new, right
+    sc.ref_p, sc.new_p, sc.right_p = (O.make_images(im, nl) for im in (ref, new, right))
+    if template == "dense":
+        sc.tpl = S.dense_template(scene, K, w, h, nl, sc.ref_p, idepth_scale)
+    else:
+        sc.tpl = S.sparse_template(scene, K, w, h, nl, sc.ref_p, n0=n0, seed=seed, idepth_scale=idepth_scale)
+    sc.gt_pose = S.pose_from_Rt(R, t)
+    sc.gt_aff = np.array([a, b])
+    sc.scene = scene
+    return sc
+
+
+def oracle_tracker(sc, params=None):
+    orc = O.OracleTracker(sc.w, sc.h, sc.nl, sc.T, sc.K, params)
+    orc.make_k(*sc.K)
+    orc.set_ref(0, 0.0, 0.0, 1.0, *sc.tpl)
+    orc.set_frame(0, sc.new_p, 1.0)
+    orc.set_frame(1, sc.right_p, 1.0)
+    return orc
+
+
+def hip_tracker(ctx, sc, params=None):
+    from direct_stereo_slam_amd.tracker import TrackerAndScaler
+
+    trk = TrackerAndScaler(ctx, sc.w, sc.h, sc.nl, sc.T, sc.K, params)
+    trk.makeK(*sc.K)
+    trk.setCoarseTrackingRef(0, (0.0, 0.0), 1.0, *sc.tpl)
+    trk.upload_frame(0, sc.new_p, 1.0)
+    trk.upload_frame(1, sc.right_p, 1.0)
+    return trk
