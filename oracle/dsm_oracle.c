@@ -358,6 +358,7 @@ struct orc_tracker {
   float *sb[8];
   int sb_n;
   int64_t res_evals[ORC_MAX_LEVELS], gs_evals[ORC_MAX_LEVELS];
+  double last_E_f64; /* the same per-point float terms summed in double (test aid, see orc_last_energy_f64) */
 };
 
 orc_tracker *orc_tracker_create(int ww, int hh, int nlevels, const double T[16], const float K1[4],
@@ -470,6 +471,7 @@ void orc_tracker_set_frame(orc_tracker *t, int slot, const float *const *dIp, fl
 }
 
 int orc_pose_warped_n(orc_tracker *t) { return t->pb_n; }
+double orc_last_energy_f64(orc_tracker *t) { return t->last_E_f64; }
 int orc_scale_warped_n(orc_tracker *t) { return t->sb_n; }
 void orc_get_eval_counts(orc_tracker *t, int64_t r[ORC_MAX_LEVELS], int64_t g[ORC_MAX_LEVELS]) {
   memcpy(r, t->res_evals, sizeof t->res_evals);
@@ -507,6 +509,7 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
               *lpc_color = t->pc_c[lvl];
   float **B = t->pb;
   t->res_evals[lvl]++;
+  double E64 = 0;
 
   for (int i = 0; i < nl; i++) {
     const float id = lpc_idepth[i], x = lpc_u[i], y = lpc_v[i];
@@ -548,10 +551,12 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
 
     if (fabsf(residual) > cutoffTH) { /* :797-802 */
       E += maxEnergy;
+      E64 += maxEnergy;
       numTermsInE++;
       numSaturated++;
     } else {
       E += hw * residual * residual * (2 - hw); /* :809 */
+      E64 += hw * residual * residual * (2 - hw);
       numTermsInE++;
       B[0][numTermsInWarped] = new_idepth; /* :812-819 */
       B[1][numTermsInWarped] = u;
@@ -569,6 +574,7 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
     numTermsInWarped++;
   }
   t->pb_n = numTermsInWarped;
+  t->last_E_f64 = E64;
 
   rs[0] = E; /* :843-851 */
   rs[1] = numTermsInE;
@@ -840,6 +846,7 @@ void orc_calc_res_scale(orc_tracker *t, int lvl, float scale, float cutoffTH, do
               *lpc_color = t->pc_c[lvl];
   float **B = t->sb;
   t->res_evals[lvl]++;
+  double E64 = 0;
 
   for (int i = 0; i < nl; i++) {
     const float id = lpc_idepth[i], x = lpc_u[i], y = lpc_v[i];
@@ -882,10 +889,12 @@ void orc_calc_res_scale(orc_tracker *t, int lvl, float scale, float cutoffTH, do
     const float hw = fabsf(residual) < huberTH ? 1 : huberTH / fabsf(residual);
     if (fabsf(residual) > cutoffTH) {
       E += maxEnergy;
+      E64 += maxEnergy;
       numTermsInE++;
       numSaturated++;
     } else {
       E += hw * residual * residual * (2 - hw);
+      E64 += hw * residual * residual * (2 - hw);
       numTermsInE++;
       B[0][numTermsInWarped] = rx[0]; /* :1130-1137 */
       B[1][numTermsInWarped] = rx[1];
@@ -903,6 +912,7 @@ void orc_calc_res_scale(orc_tracker *t, int lvl, float scale, float cutoffTH, do
     numTermsInWarped++;
   }
   t->sb_n = numTermsInWarped;
+  t->last_E_f64 = E64;
   rs[0] = E;
   rs[1] = numTermsInE;
   rs[2] = sumSquaredShiftT / (sumSquaredShiftNum + 0.1);

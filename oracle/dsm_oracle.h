@@ -55,6 +55,10 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
 void orc_calc_gs_pose(orc_tracker *t, int lvl, const double pose[7], const double aff[2],
                       double H[64], double b[8]);
 int orc_pose_warped_n(orc_tracker *t);
+/* test aid: the energy of the last calcRes* with the SAME per-point float terms summed in double.
+ * The reference accumulates E in float in point order (quirk Q1); with 1e5..5e5 terms that sum
+ * carries a relative error up to ~n*2^-24, far above the device's tree reduction error. */
+double orc_last_energy_f64(orc_tracker *t);
 /* trackNewestCoarse, TrackerAndScaler.cpp:451-638.  Returns the reference's bool. */
 int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsest_lvl,
               const double *min_res_for_abort, double *last_residuals, double flow_out[3]);

@@ -63,6 +63,8 @@ def lib(native=False):
     L.orc_tracker_set_frame.argtypes = [vp, C.c_int, pp, C.c_float]
     L.orc_calc_res_pose.argtypes = [vp, C.c_int, c_double_p, c_double_p, C.c_float, c_double_p]
     L.orc_calc_gs_pose.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.orc_last_energy_f64.argtypes = [vp]
+    L.orc_last_energy_f64.restype = C.c_double
     L.orc_pose_warped_n.argtypes = [vp]
     L.orc_pose_warped_n.restype = C.c_int
     L.orc_track.argtypes = [vp, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]
@@ -183,6 +185,9 @@ class OracleTracker:
         b = np.zeros(8)
         self.L.orc_calc_gs_pose(self.h_, lvl, _dp(pose), _dp(aff), _dp(H), _dp(b))
         return H.reshape(8, 8), b
+
+    def last_energy_f64(self):
+        return self.L.orc_last_energy_f64(self.h_)
 
     def pose_warped_n(self):
         return self.L.orc_pose_warped_n(self.h_)

@@ -24,12 +24,14 @@ FLOAT_RTOL = 2e-5
 def assert_eval_pose_equal(orc, trk, lvl, pose, aff, cutoff):
     rs_o = orc.calc_res_pose(lvl, pose, aff, cutoff)
     H_o, b_o = orc.calc_gs_pose(lvl, pose, aff)
+    E64 = orc.last_energy_f64()
     rs_g, H_g, b_g, n_g = trk.calcResPose(lvl, pose, aff, cutoff)
     assert rs_g[1] == rs_o[1], "numTermsInE differs"
     assert n_g == orc.pose_warped_n(), "warped count differs"
     if rs_o[1] > 0:
         assert np.float32(rs_g[5]) == np.float32(rs_o[5]), "saturated ratio differs"
-        np.testing.assert_allclose(rs_g[0], rs_o[0], rtol=FLOAT_RTOL)
+        np.testing.assert_allclose(rs_g[0], E64, rtol=2e-6)
+        assert abs(rs_o[0] - E64) <= max(2e-5, rs_o[1] * 2.0 ** -24) * E64  # quirk Q1 error bound
     np.testing.assert_allclose(rs_g[2:5], rs_o[2:5], rtol=FLOAT_RTOL, atol=1e-9)
     if n_g > 0:
         np.testing.assert_allclose(H_g, H_o, rtol=0, atol=FLOAT_RTOL * np.abs(H_o).max())
@@ -40,11 +42,13 @@ def assert_eval_pose_equal(orc, trk, lvl, pose, aff, cutoff):
 def assert_eval_scale_equal(orc, trk, lvl, scale, cutoff):
     rs_o = orc.calc_res_scale(lvl, scale, cutoff)
     H_o, b_o = orc.calc_gs_scale(lvl, scale)
+    E64 = orc.last_energy_f64()
     rs_g, H_g, b_g, n_g = trk.calcResScale(lvl, scale, cutoff)
     assert rs_g[1] == rs_o[1] and n_g == orc.scale_warped_n()
     if rs_o[1] > 0:
         assert np.float32(rs_g[5]) == np.float32(rs_o[5])
-        np.testing.assert_allclose(rs_g[0], rs_o[0], rtol=FLOAT_RTOL)
+        np.testing.assert_allclose(rs_g[0], E64, rtol=2e-6)
+        assert abs(rs_o[0] - E64) <= max(2e-5, rs_o[1] * 2.0 ** -24) * E64
     np.testing.assert_allclose(rs_g[2:5], rs_o[2:5], rtol=FLOAT_RTOL, atol=1e-9)
     if n_g > 0:
         assert abs(H_g - H_o) <= 5e-5 * abs(H_o)
