@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--config", default="S1", choices=["S1", "S2"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--kf-every", type=int, default=5)
-    ap.add_argument("--poll-chunk", type=int, default=4)
+    ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
@@ -102,7 +102,7 @@ def build_workload(args, ctx, rank):
         K = (fx, fy, cx + (1248 - 1241) / 2.0, cy + (384 - 376) / 2.0)
     T = S.KITTI_T_STEREO
     params = default_params()
-    params.poll_chunk = args.poll_chunk
+    params.adaptive_schedule = 0 if args.no_adaptive else 1
     scenes = []
     for i in range(args.scenes):
         seed = 0x5EED0000 + 1000 * rank + i
@@ -198,7 +198,8 @@ def bench_tracking(args):
     good, poses, err, sc, st_track, st_scale = out
 
     # accuracy of the last step against the synthetic ground truth (sanity, not the metric)
-    terr = float(np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max())
+    terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
+    terr = float(terr_all.max())
 
     # roofline of the dominant kernel (level-0 pose eval): one extra step with HIP-event timing
     ctx.set_timing(True)
@@ -233,11 +234,11 @@ def bench_tracking(args):
         "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
-                   "frames_in_flight_per_gpu": B, "replicas": world, "poll_chunk": args.poll_chunk,
+                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,
-                   "max_abs_translation_error_m": terr, "all_tracked": bool(good.all())},
+                   "max_abs_translation_error_m": terr, "translation_error_by_scene_m": [round(float(x), 5) for x in terr_all[:args.scenes]], "all_tracked": bool(good.all())},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -170,7 +170,7 @@ void dsm_params_default(dsm_params *p) {
   p->lambda_extrapolation_limit = 0.001f;
   const int it[DSM_MAX_LEVELS] = {10, 20, 50, 50, 50, 50};
   memcpy(p->max_iterations, it, sizeof it);
-  p->poll_chunk = 4;
+  p->adaptive_schedule = 1;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -532,20 +532,32 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
             ctx->partial_stride, ctx->d_start, nullptr, ctx->d_status);
   size_t ev_used = 0;
   std::vector<int> ev_lvl;
-  for (int L = coarsest; L >= 0; L--) {
+  // Launch schedule.  The LM loop is sequential per problem and its length is data dependent
+  // (TrackerAndScaler.cpp:477,505,588,601); polling the device after every few launches costs a
+  // host round trip each time.  Instead every level gets a speculative number of (eval, lm) launch
+  // pairs -- the largest count any problem needed in recent calls plus slack -- and the state is
+  // read back ONCE per pass.  Problems that finish a level early idle through the remaining
+  // launches (their workgroups exit on the first instruction); problems that need more simply stay
+  // at their level and are continued by the next pass.  Results do not depend on the schedule.
+  int worst[DSM_MAX_LEVELS], grid_x[DSM_MAX_LEVELS];
+  for (int L = 0; L < nlevels; L++) {
     int max_chunks = 1, max_it = 0;
     for (int i = 0; i < n; i++) {
       const int c = num_chunks(ts[i]->desc.lv[L].n);
       if (c > max_chunks) max_chunks = c;
       if (ts[i]->params.max_iterations[L] > max_it) max_it = ts[i]->params.max_iterations[L];
     }
-    const int grid_x = round8(max_chunks);
-    const int worst = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
-    int launched = 0;
-    while (launched < worst) {
-      const int chunk = P.poll_chunk > 0 ? (P.poll_chunk < worst - launched ? P.poll_chunk : worst - launched)
-                                         : worst - launched;
-      for (int k = 0; k < chunk; k++) {
+    grid_x[L] = round8(max_chunks);
+    worst[L] = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
+  }
+  int *sched = ctx->sched[mode];
+  int top = coarsest;
+  for (int pass = 0;; pass++) {
+    for (int L = top; L >= 0; L--) {
+      int steps = P.adaptive_schedule ? sched[L] << (pass > 3 ? 3 : pass) : worst[L];
+      if (steps > worst[L]) steps = worst[L];
+      if (steps < 1) steps = 1;
+      for (int k = 0; k < steps; k++) {
         hipEvent_t ea = nullptr, eb = nullptr;
         if (ctx->timing) {
           ea = get_event(ctx, ev_used++);
@@ -553,23 +565,24 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
           ev_lvl.push_back(L);
           if (ea) DSM_HIP(hipEventRecord(ea, ctx->stream));
         }
-        launch_eval(ctx->stream, mode, layout, L, grid_x, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+        launch_eval(ctx->stream, mode, layout, L, grid_x[L], n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
                     ctx->partial_stride);
         if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, ctx->stream));
         launch_lm(ctx->stream, mode, LM_OP_STEP, L, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
                   ctx->partial_stride, nullptr, nullptr, ctx->d_status);
       }
-      launched += chunk;
-      ctx->stats.launches[L] += chunk;
-      if (P.poll_chunk > 0) {
-        DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
-        DSM_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->stats.polls++;
-        bool any = false;
-        for (int i = 0; i < n; i++)
-          if (ctx->h_status[2 * i] == ST_RUNNING && ctx->h_status[2 * i + 1] == L) any = true;
-        if (!any) break;
-      }
+      ctx->stats.launches[L] += steps;
+    }
+    DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    DSM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stats.polls++;
+    top = -1;
+    for (int i = 0; i < n; i++)
+      if (ctx->h_status[2 * i] == ST_RUNNING && ctx->h_status[2 * i + 1] > top) top = ctx->h_status[2 * i + 1];
+    if (top < 0) break;
+    if (pass > 64) {
+      set_error("internal: LM state machine did not terminate within the launch bound");
+      return DSM_ERR_STATE;
     }
   }
   DSM_HIP(hipMemcpyAsync(ctx->h_states, ctx->d_states, sizeof(LMState) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -585,6 +598,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         ctx->stats.eval_kernel_ms[ev_lvl[i]] += m;
     }
   }
+  int need[DSM_MAX_LEVELS] = {0};
   for (int i = 0; i < n; i++) {
     const LMState &S = ctx->h_states[i];
     if (S.status == ST_RUNNING) {
@@ -592,10 +606,17 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       return DSM_ERR_STATE;
     }
     for (int l = 0; l < nlevels; l++) {
+      if ((int)S.evals[l] > need[l]) need[l] = (int)S.evals[l];
       ctx->stats.evals[l] += S.evals[l];
       ctx->stats.algorithmic_bytes +=
           S.evals[l] * (16ll * ts[i]->desc.lv[l].n + 12ll * (ts[i]->w >> l) * (ts[i]->h >> l));
     }
+  }
+  // next call's schedule: what this batch needed plus one, decaying slowly towards it
+  for (int l = 0; l < nlevels; l++) {
+    const int want = need[l] + 1;
+    const int decayed = sched[l] - (sched[l] + 7) / 8;
+    sched[l] = want > decayed ? want : decayed;
   }
   return DSM_OK;
 }

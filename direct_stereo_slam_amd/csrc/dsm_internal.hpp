@@ -39,6 +39,8 @@ struct dsm_context {
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;
+  // speculative launch schedule per mode (0 = track, 1 = scale) and level, adapted after every call
+  int sched[2][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}};
   // stats / timing
   bool timing = false;
   dsm_stats stats{};

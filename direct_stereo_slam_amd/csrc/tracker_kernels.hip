@@ -339,8 +339,13 @@ void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// LM state machine (one wave per problem; lane 0 runs the serial double precision math)
+// LM state machine.  One workgroup of 256 threads per problem: all four waves reduce the chunk
+// partials (fixed order), then wave 0 advances the state machine: the 8x8 normal equations live
+// one element per lane (lane = 8*row + col), the pivoted LDLT solve runs across the wave with
+// shuffles, lane 0 does the scalar double precision work (SE3 exp, pose composition).
 // ------------------------------------------------------------------------------------------
+constexpr int kLmThreads = 256;
+
 __device__ void make_eval_pose(const TrackerDev &T, LMState &S, int lvl, const double pose[7],
                                const double aff[2], float cutoff) {
   double Rd[9];
@@ -394,6 +399,7 @@ __device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float 
   S.in.max_energy = 2 * h * cutoff - h * h; // :1030-1032
 }
 
+// lane 0 only
 __device__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
   S.lvl = lvl;
   S.phase = PH_INIT;
@@ -419,31 +425,101 @@ __device__ void build_rs(const double *sums, const long long *isums, double rs[6
   rs[5] = n_sat / (float)n_terms;
 }
 
-// H_out / b_out of calcGSSSEPose (:681-696) from the reduced sums
-__device__ void build_Hb_pose(const TrackerDev &T, const double *sums, int n_warped4, double *H, double *b) {
-  float Hf[9][9];
-  int idx = 0;
-#pragma unroll
-  for (int r = 0; r < 9; r++)
-#pragma unroll
-    for (int c = r; c < 9; c++) {
-      const float d = (float)sums[idx++];
-      Hf[r][c] = d;
-      Hf[c][r] = d;
-    }
-  const float invn = 1.0f / n_warped4; // (1.0f / n), n padded to a multiple of 4 (quirk Q3)
-  const double s[8] = {T.p.scale_xi_rot,   T.p.scale_xi_rot,   T.p.scale_xi_rot, T.p.scale_xi_trans,
-                       T.p.scale_xi_trans, T.p.scale_xi_trans, T.p.scale_a,      T.p.scale_b};
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-#pragma unroll
-    for (int c = 0; c < 8; c++) H[r * 8 + c] = (((double)Hf[r][c] * (double)invn) * s[c]) * s[r];
-    b[r] = ((double)Hf[r][8] * (double)invn) * s[r];
-  }
+__device__ __forceinline__ double scale_of(const ParamsDev &p, int i) { // SCALE_* per tangent index (:685-696)
+  return i < 3 ? (double)p.scale_xi_rot : i < 6 ? (double)p.scale_xi_trans : i == 6 ? (double)p.scale_a : (double)p.scale_b;
 }
 
+// index of (r,c), r<=c, in the row-major upper triangle of the 9x9 accumulator
+__device__ __forceinline__ int tri_idx(int r, int c) { return r * 9 - (r * (r - 1)) / 2 + (c - r); }
+
+// H_out(r,c) of calcGSSSEPose (:681-692) for this lane's (r,c); b_out(r) (:683,:693-696)
+__device__ __forceinline__ double build_H_elem(const ParamsDev &p, const double *sums, int n4, int r, int c) {
+  const float hf = (float)sums[r <= c ? tri_idx(r, c) : tri_idx(c, r)];
+  const float invn = 1.0f / n4; // (1.0f / n), n padded to a multiple of 4 (quirk Q3)
+  return (((double)hf * (double)invn) * scale_of(p, c)) * scale_of(p, r);
+}
+__device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double *sums, int n4, int r) {
+  const float hf = (float)sums[tri_idx(r, 8)];
+  const float invn = 1.0f / n4;
+  return ((double)hf * (double)invn) * scale_of(p, r);
+}
+
+// Eigen LDLT<Lower> with diagonal pivoting + solve (call sites :509,:513,:518,:529), one matrix
+// element per lane (lane = 8*r + c, full symmetric storage), right-hand side replicated along
+// rows.  Rows/cols whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves).
+// Returns x_r (replicated along the row).  Same pivot order and the same operations as the
+// textbook (left-looking) form the oracle restates; only the order of the subtractions inside one
+// Schur-complement entry differs (round-off in the last bits of a double).
+__device__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
+  const int r = lane >> 3, c = lane & 7;
+  unsigned done = ~active & 0xFFu;
+  int order[8];
+  bool all_zero = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    double best = -1.0;
+    int p = -1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const double d = fabs(__shfl(a, 9 * i, 64));
+      const bool cand = !((done >> i) & 1u) && d > best; // strict >: first maximum wins (Eigen maxCoeff)
+      best = cand ? d : best;
+      p = cand ? i : p;
+    }
+    order[k] = p;
+    if (p >= 0) { // wave-uniform
+      const double dp = __shfl(a, 9 * p, 64);
+      const double arow = __shfl(a, 8 * p + c, 64);
+      const double acol = __shfl(a, 8 * r + p, 64);
+      const bool valid = fabs(dp) > 0.0;
+      if (k == 0 && !valid) all_zero = true;
+      const bool r_live = !((done >> r) & 1u) && r != p;
+      const bool c_live = !((done >> c) & 1u) && c != p;
+      const double l = valid ? acol / dp : acol;
+      if (r_live && c_live) a = a - l * arow;
+      if (r_live && c == p) a = l; // keep L in the pivot column
+      done |= 1u << p;
+    }
+  }
+  // forward substitution (unit lower), in pivot order
+  unsigned fdone = ~active & 0xFFu;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int p = order[k];
+    if (p >= 0) {
+      const double yp = __shfl(y, 8 * p, 64);
+      const double l = __shfl(a, 8 * r + p, 64);
+      fdone |= 1u << p;
+      if (!((fdone >> r) & 1u)) y = y - l * yp;
+    }
+  }
+  // D^-1 with Eigen's tolerance 1/highest
+  {
+    const double d = __shfl(a, 9 * r, 64);
+    const double tol = 1.0 / 1.7976931348623157e308;
+    y = fabs(d) > tol ? y / d : 0.0;
+  }
+  // back substitution (L^T), reverse pivot order
+  unsigned before = 0; // rows eliminated before the current pivot = all earlier pivots
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (order[k] >= 0) before |= 1u << order[k];
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    const int p = order[k];
+    if (p >= 0) {
+      before &= ~(1u << p);
+      const double xp = __shfl(y, 8 * p, 64);
+      const double l = __shfl(a, 8 * p + r, 64); // L[p][r], r eliminated before p
+      if ((before >> r) & 1u) y = y - l * xp;
+    }
+  }
+  if (all_zero || !((active >> r) & 1u)) y = 0.0;
+  return y;
+}
+
+// lane 0 only: :612-637
 __device__ void finish_track(const TrackerDev &T, LMState &S) {
-  // :612-637.  cur / aff_cur are the outputs.
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   int status = ST_GOOD;
   if ((modeA != 0 && (__builtin_fabsf((float)S.aff_cur[0]) > 1.2)) ||
@@ -463,60 +539,72 @@ __device__ void finish_track(const TrackerDev &T, LMState &S) {
   S.status = status;
 }
 
-// solve + propose for the pose problem (:505-554).  sA: LDS scratch 64 doubles.
-__device__ void propose_pose(const TrackerDev &T, LMState &S, double *sA) {
-  const float lambda = S.lambda;
+// whole wave: solve + propose for the pose problem (:505-554).  h = H(r,c) of this lane,
+// bneg = -b(r) replicated along the row.
+__device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane) {
+  const int r = lane >> 3, c = lane & 7;
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
-  double nb[8], inc[8];
-  for (int i = 0; i < 64; i++) sA[i] = S.H[i];
-  for (int i = 0; i < 8; i++) sA[i * 8 + i] *= (1 + lambda); // :506-508
-  for (int i = 0; i < 8; i++) nb[i] = -S.b[i];
-  // the sub-solves below need the un-factorised Hl, so they are done first on copies
-  if (modeA < 0 && modeB < 0) { // :511-515
-    ldlt_solve(6, sA, nb, inc);
-    inc[6] = inc[7] = 0;
-  } else if (!(modeA < 0) && modeB < 0) { // :516-520
-    ldlt_solve(7, sA, nb, inc);
-    inc[7] = 0;
-  } else if (modeA < 0 && !(modeB < 0)) { // :521-534
-    for (int r = 0; r < 8; r++) sA[r * 8 + 6] = sA[r * 8 + 7];
-    for (int c = 0; c < 8; c++) sA[6 * 8 + c] = sA[7 * 8 + c];
-    nb[6] = nb[7];
-    double x7[8];
-    ldlt_solve(7, sA, nb, x7);
-    for (int i = 0; i < 6; i++) inc[i] = x7[i];
-    inc[6] = 0;
-    inc[7] = x7[6];
-  } else {
-    ldlt_solve(8, sA, nb, inc); // :509
+  double a = h;
+  if (r == c) a *= (1 + lambda); // :506-508
+  double y = bneg;
+  unsigned active = 0xFFu;
+  bool stitch = false;
+  if (modeA < 0 && modeB < 0) { // :511-515 fix a, b
+    active = 0x3Fu;
+  } else if (!(modeA < 0) && modeB < 0) { // :516-520 fix b
+    active = 0x7Fu;
+  } else if (modeA < 0 && !(modeB < 0)) { // :521-534 fix a: row/col 6 := row/col 7
+    stitch = true;
+    active = 0x7Fu;
+    const int mr = r == 6 ? 7 : r, mc = c == 6 ? 7 : c;
+    a = __shfl(a, 8 * mr + mc, 64);
+    y = __shfl(y, 8 * mr, 64);
   }
+  const double x = wave_ldlt_solve(a, y, active, lane);
+  // gather the 8 increments into every lane (row r's value sits in lanes 8r..8r+7)
+  double inc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) inc[i] = __shfl(x, 8 * i, 64);
+  if (stitch) {
+    inc[7] = inc[6];
+    inc[6] = 0;
+  }
+  if (lane != 0) return;
   float extrapFac = 1; // :536-539
   const float lim = T.p.lambda_extrapolation_limit;
   if (lambda < lim) extrapFac = sqrtf(sqrtf(lim / lambda));
+#pragma unroll
   for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
-  const double sc[8] = {T.p.scale_xi_rot,   T.p.scale_xi_rot,   T.p.scale_xi_rot, T.p.scale_xi_trans,
-                        T.p.scale_xi_trans, T.p.scale_xi_trans, T.p.scale_a,      T.p.scale_b};
   double incScaled[8], sum = 0; // :541-548
+#pragma unroll
   for (int i = 0; i < 8; i++) {
-    incScaled[i] = inc[i] * sc[i];
+    incScaled[i] = inc[i] * scale_of(T.p, i);
     sum += incScaled[i];
   }
-  if (!__builtin_isfinite(sum))
+  if (!__builtin_isfinite(sum)) {
+#pragma unroll
     for (int i = 0; i < 8; i++) incScaled[i] = 0;
-  double ex[7];
+  }
+  double ex[7], cur[7], cand[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) cur[i] = S.cur[i];
   se3_exp(incScaled, ex);
-  se3_mul(ex, S.cur, S.cand); // :550-551
-  S.aff_cand[0] = S.aff_cur[0] + incScaled[6];
-  S.aff_cand[1] = S.aff_cur[1] + incScaled[7];
+  se3_mul(ex, cur, cand); // :550-551
+#pragma unroll
+  for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
+  double aff_cand[2] = {S.aff_cur[0] + incScaled[6], S.aff_cur[1] + incScaled[7]};
+  S.aff_cand[0] = aff_cand[0];
+  S.aff_cand[1] = aff_cand[1];
   double nrm = 0;
+#pragma unroll
   for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
   S.inc_norm = sqrt(nrm);
   S.phase = PH_ITER;
-  make_eval_pose(T, S, S.lvl, S.cand, S.aff_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+  make_eval_pose(T, S, S.lvl, cand, aff_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
 }
 
-__device__ void propose_scale(const TrackerDev &T, LMState &S) { // :897-913
-  const float lambda = S.lambda;
+// lane 0 only: :897-913
+__device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
   float Hl = S.Hs;
   Hl *= (1 + lambda);
   float inc = -S.bs / Hl;
@@ -531,6 +619,7 @@ __device__ void propose_scale(const TrackerDev &T, LMState &S) { // :897-913
   make_eval_scale(T, S, S.lvl, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
 }
 
+// lane 0 only
 __device__ void end_level(const TrackerDev &T, LMState &S) {
   const int lvl = S.lvl;
   S.last_residuals[lvl] = sqrtf((float)(S.res_old[0] / S.res_old[1])); // :596 / :945
@@ -558,23 +647,25 @@ __device__ void end_level(const TrackerDev &T, LMState &S) {
   begin_level(T, S, next);
 }
 
-__global__ __launch_bounds__(64) void lm_kernel(int mode, int op, int lvl,
-                                                const TrackerDev *const *__restrict__ trackers,
-                                                LMState *__restrict__ states,
-                                                const float *__restrict__ partials, int partial_stride,
-                                                const StartInfo *__restrict__ start,
-                                                SingleOut *__restrict__ single_out,
-                                                int *__restrict__ status_out) {
+__global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
+                                                        const TrackerDev *const *__restrict__ trackers,
+                                                        LMState *__restrict__ states,
+                                                        const float *__restrict__ partials, int partial_stride,
+                                                        const StartInfo *__restrict__ start,
+                                                        SingleOut *__restrict__ single_out,
+                                                        int *__restrict__ status_out) {
   const int prob = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const TrackerDev &T = *trackers[prob];
   LMState &S = states[prob];
+  __shared__ double psum[4][kNumSlots];
+  __shared__ long long pisum[4][4];
   __shared__ double sums[kNumSlots];
-  __shared__ long long isums[3];
-  __shared__ double sA[64];
+  __shared__ long long isums[4];
 
   if (op == LM_OP_START) {
-    if (lane == 0) {
+    if (tid == 0) {
       const StartInfo &I = start[prob];
       S.is_scale = mode;
       S.coarsest = I.coarsest;
@@ -602,7 +693,7 @@ __global__ __launch_bounds__(64) void lm_kernel(int mode, int op, int lvl,
     return;
   }
   if (op == LM_OP_SINGLE_PREP) {
-    if (lane == 0) {
+    if (tid == 0) {
       const StartInfo &I = start[prob];
       S.is_scale = mode;
       S.status = ST_RUNNING;
@@ -616,117 +707,171 @@ __global__ __launch_bounds__(64) void lm_kernel(int mode, int op, int lvl,
   }
 
   const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
-  if (!active) {
-    if (lane == 0 && status_out) {
+  if (!active) { // block-uniform
+    if (tid == 0 && status_out) {
       status_out[2 * prob] = S.status;
       status_out[2 * prob + 1] = S.lvl;
     }
     return;
   }
-  // fixed-order reduction over the chunk partials (double / int64)
-  const int nch = num_chunks(T.lv[lvl].n);
-  const float *P = partials + (size_t)prob * partial_stride;
-  if (lane < kSlotNTerms) {
-    double s = 0;
-    for (int c = 0; c < nch; c++) s += (double)P[(size_t)c * kPartialStride + lane];
-    sums[lane] = s;
-  } else if (lane < kNumSlots) {
-    long long s = 0;
-    for (int c = 0; c < nch; c++) s += __float_as_int(P[(size_t)c * kPartialStride + lane]);
-    isums[lane - kSlotNTerms] = s;
+  // ---- fixed-order reduction over the chunk partials: wave w sums chunks w, w+4, ... (double /
+  // int64), then the four partial sums are added in order ((p0+p1)+p2)+p3 ----
+  {
+    const int nch = num_chunks(T.lv[lvl].n);
+    const float *P = partials + (size_t)prob * partial_stride;
+    const int part = tid >> 6;
+    if (lane < kSlotNTerms) {
+      double s = 0;
+      for (int c = part; c < nch; c += 4) s += (double)P[(size_t)c * kPartialStride + lane];
+      psum[part][lane] = s;
+    } else if (lane < kNumSlots) {
+      long long s = 0;
+      for (int c = part; c < nch; c += 4) s += __float_as_int(P[(size_t)c * kPartialStride + lane]);
+      pisum[part][lane - kSlotNTerms] = s;
+    }
   }
   __syncthreads();
-  if (lane != 0) return;
+  if (tid >= 64) return; // wave 0 carries on
+  if (lane < kSlotNTerms)
+    sums[lane] = ((psum[0][lane] + psum[1][lane]) + psum[2][lane]) + psum[3][lane];
+  else if (lane < kNumSlots)
+    isums[lane - kSlotNTerms] = ((pisum[0][lane - kSlotNTerms] + pisum[1][lane - kSlotNTerms]) + pisum[2][lane - kSlotNTerms]) + pisum[3][lane - kSlotNTerms];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads(); // only wave 0 is left; keeps the LDS writes ordered before the reads below
 
   double rs[6];
   build_rs(sums, isums, rs);
   const int n_warped = (int)isums[2];
   const int n4 = (n_warped + 3) & ~3; // :824-835 padding counts in n (quirk Q3)
+  const int r = lane >> 3, c = lane & 7;
 
   if (op == LM_OP_SINGLE_FINISH) {
     SingleOut &O = single_out[prob];
-    for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
-    O.n_warped = n4;
     if (mode == 0) {
-      build_Hb_pose(T, sums, n4, O.H, O.b);
-      O.Hs = O.bs = 0;
-    } else {
-      O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
-      O.bs = (float)sums[1] * (1.0f / n4);
+      O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
+      if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
     }
-    S.status = ST_IDLE;
+    if (lane == 0) {
+      for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
+      O.n_warped = n4;
+      if (mode == 0) {
+        O.Hs = O.bs = 0;
+      } else {
+        O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
+        O.bs = (float)sums[1] * (1.0f / n4);
+      }
+      S.status = ST_IDLE;
+    }
     return;
   }
 
-  // ---- LM_OP_STEP ----
-  S.evals[lvl]++;
+  // ---- LM_OP_STEP: every lane of wave 0 evaluates the same (uniform) decisions; lane 0 writes ----
   const int max_it = T.p.max_iterations[lvl];
   const float lim = T.p.lambda_extrapolation_limit;
-  bool level_done = false;
-  if (S.phase == PH_INIT) {
+  const int phase = S.phase;
+  bool level_done = false, do_propose = false;
+  double h = 0, bneg = 0; // this lane's H(r,c) and -b(r) for a following proposal
+  float lambda_next = 0.01f; // computed by every lane: nothing lane 0 writes below is re-read by the wave
+  if (phase == PH_INIT) {
     if (rs[5] > 0.6 && S.level_cutoff_repeat < 50) { // :477-485 / :875-883
-      S.level_cutoff_repeat *= 2;
-      const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-      if (mode)
-        make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
-      else
-        make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
-    } else {
-      for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
-      if (mode == 0)
-        build_Hb_pose(T, sums, n4, S.H, S.b); // :487
-      else {
-        S.Hs = (float)sums[0] * (1.0f / n4); // :885
-        S.bs = (float)sums[1] * (1.0f / n4);
+      if (lane == 0) {
+        S.evals[lvl]++;
+        S.level_cutoff_repeat *= 2;
+        const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
+        if (mode)
+          make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
+        else
+          make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
       }
-      S.lambda = 0.01f; // :489
-      S.iteration = 0;
+    } else {
+      if (mode == 0) {
+        h = build_H_elem(T.p, sums, n4, r, c); // :487
+        bneg = -build_b_elem(T.p, sums, n4, r);
+        S.H[lane] = h;
+        if (c == 0) S.b[r] = -bneg;
+      }
+      if (lane == 0) {
+        S.evals[lvl]++;
+        for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
+        if (mode) {
+          S.Hs = (float)sums[0] * (1.0f / n4); // :885
+          S.bs = (float)sums[1] * (1.0f / n4);
+        }
+        S.lambda = lambda_next; // 0.01, :489
+        S.iteration = 0;
+      }
       if (max_it <= 0)
         level_done = true;
-      else if (mode == 0)
-        propose_pose(T, S, sA);
       else
-        propose_scale(T, S);
+        do_propose = true;
     }
   } else {
     const bool accept = (rs[0] / rs[1]) < (S.res_old[0] / S.res_old[1]); // :559 / :915
-    if (accept) { // :576-581 / :926-930
-      for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
-      if (mode == 0) {
-        build_Hb_pose(T, sums, n4, S.H, S.b);
-        for (int i = 0; i < 7; i++) S.cur[i] = S.cand[i];
-        S.aff_cur[0] = S.aff_cand[0];
-        S.aff_cur[1] = S.aff_cand[1];
-      } else {
-        S.Hs = (float)sums[0] * (1.0f / n4);
-        S.bs = (float)sums[1] * (1.0f / n4);
-        S.scale_cur = S.scale_cand;
-      }
-      S.lambda *= 0.5f;
-    } else { // :583-585 / :932-934
-      S.lambda *= 4;
-      if (S.lambda < lim) S.lambda = lim;
-    }
     const bool small = mode == 0 ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
-    S.iteration++;
-    if (small || S.iteration >= max_it)
+    const int iteration = S.iteration + 1;
+    {
+      const float l_old = S.lambda;
+      float l4 = l_old * 4;
+      if (l4 < lim) l4 = lim;
+      lambda_next = accept ? l_old * 0.5f : l4; // :581 / :583-585
+    }
+    if (mode == 0) {
+      if (accept) { // :576-577
+        h = build_H_elem(T.p, sums, n4, r, c);
+        bneg = -build_b_elem(T.p, sums, n4, r);
+        S.H[lane] = h;
+        if (c == 0) S.b[r] = -bneg;
+      } else {
+        h = S.H[lane];
+        bneg = -S.b[r];
+      }
+    }
+    if (lane == 0) {
+      S.evals[lvl]++;
+      if (accept) { // :576-581 / :926-930
+        for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
+        if (mode == 0) {
+          for (int i = 0; i < 7; i++) S.cur[i] = S.cand[i];
+          S.aff_cur[0] = S.aff_cand[0];
+          S.aff_cur[1] = S.aff_cand[1];
+        } else {
+          S.Hs = (float)sums[0] * (1.0f / n4);
+          S.bs = (float)sums[1] * (1.0f / n4);
+          S.scale_cur = S.scale_cand;
+        }
+      }
+      S.lambda = lambda_next;
+      S.iteration = iteration;
+    }
+    if (small || iteration >= max_it)
       level_done = true;
-    else if (mode == 0)
-      propose_pose(T, S, sA);
     else
-      propose_scale(T, S);
+      do_propose = true;
   }
-  if (level_done) end_level(T, S);
-  if (status_out) {
-    status_out[2 * prob] = S.status;
-    status_out[2 * prob + 1] = S.lvl;
+  // make lane 0's state writes (lambda, cur, ...) visible to the whole wave before proposing
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (do_propose) {
+    if (mode == 0)
+      propose_pose(T, S, h, bneg, lambda_next, lane);
+    else if (lane == 0)
+      propose_scale(T, S, lambda_next);
+  }
+  if (lane == 0) {
+    if (level_done) end_level(T, S);
+    if (status_out) {
+      status_out[2 * prob] = S.status;
+      status_out[2 * prob + 1] = S.lvl;
+    }
   }
 }
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
                SingleOut *single_out, int *status_out) {
-  hipLaunchKernelGGL(lm_kernel, dim3(nprob), dim3(64), 0, s, mode, op, lvl, trackers, states, partials,
+  hipLaunchKernelGGL(lm_kernel, dim3(nprob), dim3(kLmThreads), 0, s, mode, op, lvl, trackers, states, partials,
                      partial_stride, start, single_out, status_out);
 }
 

@@ -63,9 +63,9 @@ typedef struct dsm_params {
   float affine_opt_mode_b;            /* setting_affineOptModeB                                      0    */
   float lambda_extrapolation_limit;   /* literal                    (TrackerAndScaler.cpp:464,863)   0.001*/
   int max_iterations[DSM_MAX_LEVELS]; /* literal {10,20,50,50,50}   (TrackerAndScaler.cpp:463,862); [5]=50 is an extension */
-  int poll_chunk;                     /* launches enqueued between host polls of the LM state; 0 = never poll
-                                         (enqueue the worst case, finished problems early-exit).  Not a
-                                         reference parameter; does not change results. */
+  int adaptive_schedule;              /* 1 (default): speculative per-level launch counts learnt from previous calls, one
+                                         host read-back per pass; 0: enqueue the worst case (2*(7+max_iterations) launch
+                                         pairs per level) and never poll.  Scheduling only -- results are identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
@@ -75,7 +75,7 @@ typedef struct dsm_stats {
   int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + 12*w_l*h_l   */
   double eval_kernel_ms[DSM_MAX_LEVELS];/* HIP-event time of the eval kernels per level (only when timing enabled) */
   double total_ms;                      /* HIP-event time of the whole call */
-  int64_t polls;                        /* host polls of the device LM state */
+  int64_t polls;                        /* host read-backs of the device LM state (passes) */
 } dsm_stats;
 
 const char *dsm_last_error(void);
