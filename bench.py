@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--evals-only", action="store_true",
+                    help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
@@ -103,6 +105,9 @@ def build_workload(args, ctx, rank):
     T = S.KITTI_T_STEREO
     params = default_params()
     params.adaptive_schedule = 0 if args.no_adaptive else 1
+    if args.evals_only:
+        for l in range(6):
+            params.max_iterations[l] = 0
     scenes = []
     for i in range(args.scenes):
         seed = 0x5EED0000 + 1000 * rank + i
@@ -216,6 +221,13 @@ def bench_tracking(args):
                 "traffic": None, "kernel": "eval_kernel<pose, LVL0>",
                 "bytes_per_launch": l0_evals * bytes_eval0 / max(1, l0_launches),
                 "avg_launch_us": 1e3 * l0_ms / max(1, l0_launches), "launches": int(l0_launches)}
+    per_level = []
+    for l in range(wl["nl"]):
+        nl_ = len(wl["trackers"][0].get_template(l)[0])
+        by = 16 * nl_ + 12 * (wl["w"] >> l) * (wl["h"] >> l)
+        ms = stt.eval_kernel_ms[l]
+        per_level.append({"lvl": l, "evals": int(stt.evals[l]), "launches": int(stt.launches[l]), "kernel_ms": round(ms, 4),
+                          "GBps": round(stt.evals[l] * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     all_bytes = stt.algorithmic_bytes + out_t[5].algorithmic_bytes
     frames = world * B * args.steps
     res = {
@@ -238,7 +250,7 @@ def bench_tracking(args):
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,
-                   "max_abs_translation_error_m": terr, "translation_error_by_scene_m": [round(float(x), 5) for x in terr_all[:args.scenes]], "all_tracked": bool(good.all())},
+                   "pose_eval_kernels_by_level": per_level, "max_abs_translation_error_m": terr, "translation_error_by_scene_m": [round(float(x), 5) for x in terr_all[:args.scenes]], "all_tracked": bool(good.all())},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -57,6 +57,14 @@ struct TrackerDev {
 
 // Inputs of one fused evaluation, produced on the device by the LM kernel.
 struct EvalIn {
+  // level data copied from the tracker descriptor so that an eval workgroup needs ONE dependent
+  // (scalar) read of this struct instead of chasing tracker -> level -> pointer
+  const float4 *pts;
+  const float *img;
+  int n, w, h, pad;
+  float fx, fy, cx, cy; // intrinsics of the camera the points are projected into (cam0 pose / cam1 scale)
+  float Ki[9];          // K^-1 of camera 0 at this level (flow indicators)
+  float huber;
   float M[9];   // pose: R*Ki ("RKi", :715) ; scale: R10*Ki ("rot_f1_f0_K0_i", :1022)
   float t[3];   // pose: translation (:716) ; scale: tsl_f1_f0 (:1024)
   float aff0, aff1; // affLL (:717-720) (pose only)

@@ -98,12 +98,11 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
                                                         float *__restrict__ partials,
                                                         int partial_stride, int lvl) {
   const int prob = blockIdx.y;
-  // uniform, read-only descriptors: global address space so they become scalar (s_load) reads
+  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
   const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
   if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
-  const DSM_GLOBAL TrackerDev &T = *(const DSM_GLOBAL TrackerDev *)trackers[prob];
-  const DSM_GLOBAL LevelDev &L = T.lv[lvl];
-  const int n = L.n;
+  const DSM_GLOBAL EvalIn &in = S.in;
+  const int n = in.n;
   const int P = pts_per_thread(n);
   const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
   // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
@@ -112,19 +111,16 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (chunk >= nchunks) return;
 
-  const DSM_GLOBAL EvalIn &in = S.in;
   const float M0 = in.M[0], M1 = in.M[1], M2 = in.M[2], M3 = in.M[3], M4 = in.M[4], M5 = in.M[5],
               M6 = in.M[6], M7 = in.M[7], M8 = in.M[8];
   const float t0 = in.t[0], t1 = in.t[1], t2 = in.t[2];
   const float cutoff = in.cutoff, max_energy = in.max_energy;
-  const float huber = T.p.huber_th;
-  const float fxl = MODE == 0 ? L.fx : L.fx1, fyl = MODE == 0 ? L.fy : L.fy1;
-  const float cxl = MODE == 0 ? L.cx : L.cx1, cyl = MODE == 0 ? L.cy : L.cy1;
-  const int wl = L.w, hl = L.h;
+  const float huber = in.huber;
+  const float fxl = in.fx, fyl = in.fy, cxl = in.cx, cyl = in.cy;
+  const int wl = in.w, hl = in.h;
   const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
-  // pointers read from the descriptor are generic; tell the compiler they are global (global_load, not flat_load)
-  const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)L.img[MODE];
-  const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)L.pts;
+  const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)in.img;
+  const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)in.pts;
   // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
   const float sc = in.scale;
   const float S0 = sc * M0, S1 = sc * M1, S2 = sc * M2, S3 = sc * M3, S4 = sc * M4, S5 = sc * M5,
@@ -237,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     if (i < n) {
       const fvec4 p = pts[i];
       const float x = p.x, y = p.y, id = p.z;
-      const DSM_GLOBAL float *Ki = L.Ki;
+      const DSM_GLOBAL float *Ki = in.Ki;
       float kx0, kx1, kx2, rx0, rx1, rx2;
       if (MODE == 0) {
         kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
@@ -360,6 +356,21 @@ __device__ void make_eval_pose(const TrackerDev &T, LMState &S, int lvl, const d
   mat3f_mul(Rf, Ki, M); // :715
 #pragma unroll
   for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.Ki[i] = Ki[i];
+  {
+    const LevelDev &L = T.lv[lvl];
+    S.in.pts = L.pts;
+    S.in.img = L.img[0]; // new left frame (:709)
+    S.in.n = L.n;
+    S.in.w = L.w;
+    S.in.h = L.h;
+    S.in.fx = L.fx;
+    S.in.fy = L.fy;
+    S.in.cx = L.cx;
+    S.in.cy = L.cy;
+    S.in.huber = T.p.huber_th;
+  }
   S.in.t[0] = (float)pose[4]; // :716
   S.in.t[1] = (float)pose[5];
   S.in.t[2] = (float)pose[6];
@@ -387,6 +398,21 @@ __device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float 
   mat3f_mul(Rf, Ki, M); // :1022-1023
 #pragma unroll
   for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.Ki[i] = Ki[i];
+  {
+    const LevelDev &L = T.lv[lvl];
+    S.in.pts = L.pts;
+    S.in.img = L.img[1]; // right frame fh1_ (:1016)
+    S.in.n = L.n;
+    S.in.w = L.w;
+    S.in.h = L.h;
+    S.in.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
+    S.in.fy = L.fy1;
+    S.in.cx = L.cx1;
+    S.in.cy = L.cy1;
+    S.in.huber = T.p.huber_th;
+  }
   S.in.t[0] = (float)T.T10[4]; // :1024
   S.in.t[1] = (float)T.T10[5];
   S.in.t[2] = (float)T.T10[6];
@@ -659,8 +685,8 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   const int lane = tid & 63;
   const TrackerDev &T = *trackers[prob];
   LMState &S = states[prob];
-  __shared__ double psum[4][kNumSlots];
-  __shared__ long long pisum[4][4];
+  __shared__ double psum[19][kNumSlots];
+  __shared__ long long pisum[19][4];
   __shared__ double sums[kNumSlots];
   __shared__ long long isums[4];
 
@@ -714,28 +740,56 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     }
     return;
   }
-  // ---- fixed-order reduction over the chunk partials: wave w sums chunks w, w+4, ... (double /
-  // int64), then the four partial sums are added in order ((p0+p1)+p2)+p3 ----
+  // ---- fixed-order reduction over the chunk partials (double / int64).  Thread (g, q) sums the
+  // slot quad q (one float4 = 4 of the 52 slots) over chunks g, g+19, g+38, ...: every load is a
+  // coalesced 16-byte read and up to kRedBatch of them are in flight per thread, so a level-0
+  // reduction (219 chunks) costs two memory round trips.  The 19 group sums are then added in
+  // group order by the slot's lane. ----
   {
+    constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
     const int nch = num_chunks(T.lv[lvl].n);
-    const float *P = partials + (size_t)prob * partial_stride;
-    const int part = tid >> 6;
-    if (lane < kSlotNTerms) {
-      double s = 0;
-      for (int c = part; c < nch; c += 4) s += (double)P[(size_t)c * kPartialStride + lane];
-      psum[part][lane] = s;
-    } else if (lane < kNumSlots) {
-      long long s = 0;
-      for (int c = part; c < nch; c += 4) s += __float_as_int(P[(size_t)c * kPartialStride + lane]);
-      pisum[part][lane - kSlotNTerms] = s;
+    const DSM_GLOBAL fvec4 *P4 = (const DSM_GLOBAL fvec4 *)(partials + (size_t)prob * partial_stride);
+    const int q = tid % kQuads, g = tid / kQuads;
+    if (g < kGroups) {
+      double sd[4] = {0, 0, 0, 0};
+      long long si[4] = {0, 0, 0, 0};
+      for (int c0 = g; c0 < nch; c0 += kGroups * kRedBatch) {
+        fvec4 v[kRedBatch];
+#pragma unroll
+        for (int j = 0; j < kRedBatch; j++) {
+          const int cc = c0 + j * kGroups;
+          v[j] = cc < nch ? P4[(size_t)cc * (kPartialStride / 4) + q] : fvec4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < kRedBatch; j++) {
+          sd[0] += (double)v[j].x, sd[1] += (double)v[j].y, sd[2] += (double)v[j].z, sd[3] += (double)v[j].w;
+          si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
+              si[3] += __float_as_int(v[j].w);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int slot = 4 * q + e;
+        if (slot < kSlotNTerms)
+          psum[g][slot] = sd[e];
+        else
+          pisum[g][slot - kSlotNTerms] = si[e];
+      }
     }
   }
   __syncthreads();
   if (tid >= 64) return; // wave 0 carries on
-  if (lane < kSlotNTerms)
-    sums[lane] = ((psum[0][lane] + psum[1][lane]) + psum[2][lane]) + psum[3][lane];
-  else if (lane < kNumSlots)
-    isums[lane - kSlotNTerms] = ((pisum[0][lane - kSlotNTerms] + pisum[1][lane - kSlotNTerms]) + pisum[2][lane - kSlotNTerms]) + pisum[3][lane - kSlotNTerms];
+  if (lane < kSlotNTerms) {
+    double s = psum[0][lane];
+#pragma unroll
+    for (int g = 1; g < 19; g++) s += psum[g][lane];
+    sums[lane] = s;
+  } else if (lane < kNumSlots) {
+    long long s = 0;
+#pragma unroll
+    for (int g = 0; g < 19; g++) s += pisum[g][lane - kSlotNTerms];
+    isums[lane - kSlotNTerms] = s;
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   __syncthreads(); // only wave 0 is left; keeps the LDS writes ordered before the reads below
