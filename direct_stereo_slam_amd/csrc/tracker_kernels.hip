@@ -52,40 +52,57 @@ typedef float fvec4 __attribute__((ext_vector_type(4)));
 typedef float fvec3u __attribute__((ext_vector_type(3), aligned(4))); // 12-byte texel, dword aligned
 #define DSM_GLOBAL __attribute__((address_space(1)))
 
-// getInterpolatedElement33 (upstream DSO), call sites TrackerAndScaler.cpp:790,1106
+// getInterpolatedElement33 (upstream DSO), call sites TrackerAndScaler.cpp:790,1106, split in two
+// so that the four tap loads of one point can be in flight while the previous point is consumed.
+struct Taps {
+  float t00[3], t10[3], t01[3], t11[3];
+  float dx, dy; // fractional position
+};
+
 template <int LAYOUT>
-__device__ __forceinline__ void interp33(const DSM_GLOBAL float *img, float x, float y, int w, float &h0,
-                                         float &h1, float &h2) {
+__device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
   const int iy = (int)y;
-  const float dx = x - ix;
-  const float dy = y - iy;
-  const float dxdy = dx * dy;
-  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-  const int base = ix + iy * w;
-  float t00[3], t10[3], t01[3], t11[3];
+  T.dx = x - ix;
+  T.dy = y - iy;
+  const unsigned base = (unsigned)(ix + iy * w);
   if (LAYOUT == IMG_AOS3) {
-    const DSM_GLOBAL float *bp = img + 3 * base;
+    const DSM_GLOBAL float *bp = img + 3u * base;
     const fvec3u a = *(const DSM_GLOBAL fvec3u *)(bp);
     const fvec3u b = *(const DSM_GLOBAL fvec3u *)(bp + 3);
     const fvec3u c = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w);
     const fvec3u d = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w + 3);
-    t00[0] = a.x, t00[1] = a.y, t00[2] = a.z;
-    t10[0] = b.x, t10[1] = b.y, t10[2] = b.z;
-    t01[0] = c.x, t01[1] = c.y, t01[2] = c.z;
-    t11[0] = d.x, t11[1] = d.y, t11[2] = d.z;
+    T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
+    T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
+    T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
+    T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
   } else {
     const DSM_GLOBAL fvec4 *bp = (const DSM_GLOBAL fvec4 *)img + base;
     const fvec4 a = bp[0], b = bp[1], c = bp[w], d = bp[w + 1];
-    t00[0] = a.x, t00[1] = a.y, t00[2] = a.z;
-    t10[0] = b.x, t10[1] = b.y, t10[2] = b.z;
-    t01[0] = c.x, t01[1] = c.y, t01[2] = c.z;
-    t11[0] = d.x, t11[1] = d.y, t11[2] = d.z;
+    T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
+    T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
+    T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
+    T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
   }
-  h0 = ((w11 * t11[0] + w01 * t01[0]) + w10 * t10[0]) + w00 * t00[0];
-  h1 = ((w11 * t11[1] + w01 * t01[1]) + w10 * t10[1]) + w00 * t00[1];
-  h2 = ((w11 * t11[2] + w01 * t01[2]) + w10 * t10[2]) + w00 * t00[2];
 }
+
+// h0 (the intensity) decides in/out, Huber and cut-off: exact reference operation order.  h1/h2
+// (the gradients) only enter the Jacobian sums, which are compared to float tolerance: FMA allowed.
+__device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &h1, float &h2) {
+  const float dx = T.dx, dy = T.dy;
+  const float dxdy = dx * dy;
+  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+  h0 = ((w11 * T.t11[0] + w01 * T.t01[0]) + w10 * T.t10[0]) + w00 * T.t00[0];
+  h1 = __builtin_fmaf(w00, T.t00[1], __builtin_fmaf(w10, T.t10[1], __builtin_fmaf(w01, T.t01[1], w11 * T.t11[1])));
+  h2 = __builtin_fmaf(w00, T.t00[2], __builtin_fmaf(w10, T.t10[2], __builtin_fmaf(w01, T.t01[2], w11 * T.t11[2])));
+}
+
+// per-point state carried from the warp stage to the consume stage
+struct Warped {
+  float u, v, new_idepth, refColor;
+  float x, y, id; // scale mode only (rx = M (x,y,1) / id, :1068)
+  bool inb;
+};
 
 // ------------------------------------------------------------------------------------------
 // eval kernel
@@ -137,17 +154,12 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   const int tid = threadIdx.x;
   const int chunk_start = chunk * kThreads * P;
 
-  // The loop body is branch-free: out-of-range lanes are clamped to a safe address and masked
-  // by selects, so the accumulators never cross a divergent join (no PHI copies of 45 VGPRs)
-  // and the gathers of one point can be in flight while the next template point is fetched.
-  int i = chunk_start + tid;
-  fvec4 p = pts[i < n ? i : n - 1];
-  __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads here so the loop-header wait can be relaxed
-  for (int k = 0; k < P; k++) {
-    const bool in_list = i < n;
-    const int i_next = i + kThreads;
-    const fvec4 p_next = pts[i_next < n ? i_next : n - 1]; // prefetch (clamped)
-    const float x = p.x, y = p.y, id = p.z, refColor = p.w;
+  // Software-pipelined, branch-free loop.  Stage A warps template point k+1 and issues its four
+  // bilinear tap loads; stage B consumes the taps of point k (residual, Huber, Jacobian, 45 FMAs)
+  // while those loads are in flight.  Out-of-range lanes are clamped to a safe address and masked
+  // by selects, so the accumulators never cross a divergent join.
+  auto stage_a = [&](const fvec4 &p, bool in_list, Warped &W, Taps &T) {
+    const float x = p.x, y = p.y, id = p.z;
     float pt0, pt1, pt2;
     if (MODE == 0) { // :747
       pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
@@ -158,15 +170,21 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
       pt2 = ((S6 * x + S7 * y) + S8) + t2 * id;
     }
-    const float u = pt0 / pt2;
-    const float v = pt1 / pt2;
-    const float Ku = fxl * u + cxl;
-    const float Kv = fyl * v + cyl;
-    const float new_idepth = id / pt2;
-    const bool inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && new_idepth > 0); // :786 / :1102
+    W.u = pt0 / pt2;
+    W.v = pt1 / pt2;
+    const float Ku = fxl * W.u + cxl;
+    const float Kv = fyl * W.v + cyl;
+    W.new_idepth = id / pt2;
+    W.refColor = p.w;
+    W.x = x, W.y = y, W.id = id;
+    W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
+    taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
+  };
+  auto stage_b = [&](const Warped &W, const Taps &T) {
     float h0, h1, h2;
-    interp33<LAYOUT>(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, wl, h0, h1, h2);
-    const bool fin = inb && __builtin_isfinite(h0); // :791
+    taps_interp(T, h0, h1, h2);
+    const float refColor = W.refColor;
+    const bool fin = W.inb && __builtin_isfinite(h0); // :791
     const float residual = MODE == 0 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
     const float ar = __builtin_fabsf(residual);
     const float hw = ar < huber ? 1.0f : huber / ar; // :794-795
@@ -177,22 +195,22 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     n_terms += fin ? 1 : 0;
     n_sat += (fin && sat) ? 1 : 0;
     n_warped += use ? 1 : 0;
+    const float wgt = use ? hw : 0.0f;
     if (MODE == 0) {
-      // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819)
-      const float dx = h1 * fxl, dy = h2 * fyl;
+      // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
+      // lanes get all-zero inputs so that they add exact zeros
+      const float u = use ? W.u : 0.0f, v = use ? W.v : 0.0f, nid = use ? W.new_idepth : 0.0f;
+      const float dx = use ? h1 * fxl : 0.0f, dy = use ? h2 * fyl : 0.0f;
       float J[9];
-      J[0] = new_idepth * dx;
-      J[1] = new_idepth * dy;
-      J[2] = 0.0f - new_idepth * (u * dx + v * dy);
-      J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
-      J[4] = (u * v) * dy + dx * (1.0f + u * u);
-      J[5] = u * dy - v * dx;
-      J[6] = aff0 * (b0 - refColor);
+      J[0] = nid * dx;
+      J[1] = nid * dy;
+      J[2] = -(nid * __builtin_fmaf(u, dx, v * dy));
+      J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
+      J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
+      J[5] = __builtin_fmaf(u, dy, -(v * dx));
+      J[6] = use ? aff0 * (b0 - refColor) : 0.0f;
       J[7] = -1.0f;
-      J[8] = residual;
-      const float wgt = use ? hw : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 9; r++) J[r] = use ? J[r] : 0.0f; // masked lanes contribute exact zeros
+      J[8] = use ? residual : 0.0f;
       int idx = 0;
 #pragma unroll
       for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       }
     } else {
       // calcResScale :1068 and calcGSSSEScale :983-999
+      const float x = W.x, y = W.y, id = W.id;
       const float rx1 = ((M0 * x + M1 * y) + M2) / id;
       const float rx2 = ((M3 * x + M4 * y) + M5) / id;
       const float rx3 = ((M6 * x + M7 * y) + M8) / id;
@@ -215,14 +234,37 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       const float yno = rx2 * t2 - rx3 * t1;
       const float J0 = use ? dxfx * (deno * xno) + dyfy * (deno * yno) : 0.0f;
       const float J1 = use ? residual : 0.0f;
-      const float wgt = use ? hw : 0.0f;
       const float J0w = J0 * wgt;
       acc[0] = __builtin_fmaf(J0w, J0, acc[0]);
       acc[1] = __builtin_fmaf(J0w, J1, acc[1]);
       acc[2] = __builtin_fmaf(J1 * wgt, J1, acc[2]);
     }
-    p = p_next;
-    i = i_next;
+  };
+
+  {
+    int i = chunk_start + tid;
+    const fvec4 p0 = pts[i < n ? i : n - 1];
+    int i2 = i + kThreads;
+    fvec4 p_next = pts[i2 < n ? i2 : n - 1];
+    __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+    Warped Wc;
+    Taps Tc;
+    stage_a(p0, i < n, Wc, Tc);
+    for (int k = 0; k < P; k++) {
+      // stage A for point k+1 (its template entry was prefetched one iteration ago)
+      const fvec4 p = p_next;
+      const bool in_next = i2 < n && k + 1 < P;
+      const int i3 = i2 + kThreads;
+      p_next = pts[i3 < n ? i3 : n - 1];
+      Warped Wn;
+      Taps Tn;
+      stage_a(p, in_next, Wn, Tn);
+      // stage B for point k
+      stage_b(Wc, Tc);
+      Wc = Wn;
+      Tc = Tn;
+      i2 = i3;
+    }
   }
 
   // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
