@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdsm_hotpath.so")
+# DSM_HOTPATH_LIB: developer override used for A/B builds of the same sources (e.g. other compiler flags)
+LIB_PATH = os.environ.get("DSM_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libdsm_hotpath.so")
 MAX_LEVELS = 6
 
 c_float_p = C.POINTER(C.c_float)

@@ -63,15 +63,19 @@ template <int LAYOUT>
 __device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
   const int iy = (int)y;
-  T.dx = x - ix;
-  T.dy = y - iy;
+  // x - (float)(int)x for x >= 0 is exact and equals v_fract_f32(x) (= x - floor(x))
+  T.dx = __builtin_amdgcn_fractf(x);
+  T.dy = __builtin_amdgcn_fractf(y);
   const unsigned base = (unsigned)(ix + iy * w);
   if (LAYOUT == IMG_AOS3) {
-    const DSM_GLOBAL float *bp = img + 3u * base;
-    const fvec3u a = *(const DSM_GLOBAL fvec3u *)(bp);
-    const fvec3u b = *(const DSM_GLOBAL fvec3u *)(bp + 3);
-    const fvec3u c = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w);
-    const fvec3u d = *(const DSM_GLOBAL fvec3u *)(bp + 3 * w + 3);
+    // 32-bit byte offsets from the (scalar) image base: global_load with saddr + voffset, no
+    // 64-bit vector address arithmetic
+    const unsigned off0 = 12u * base, off1 = off0 + 12u * (unsigned)w;
+    const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
+    const fvec3u a = *(const DSM_GLOBAL fvec3u *)(cb + off0);
+    const fvec3u b = *(const DSM_GLOBAL fvec3u *)(cb + off0 + 12u);
+    const fvec3u c = *(const DSM_GLOBAL fvec3u *)(cb + off1);
+    const fvec3u d = *(const DSM_GLOBAL fvec3u *)(cb + off1 + 12u);
     T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
     T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
     T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
@@ -170,11 +174,35 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
       pt2 = ((S6 * x + S7 * y) + S8) + t2 * id;
     }
-    W.u = pt0 / pt2;
-    W.v = pt1 / pt2;
+    // u = pt0/pt2, v = pt1/pt2, new_idepth = id/pt2 (:748-752).  u and v position the bilinear
+    // taps and decide in/out, so they must equal the IEEE quotients bit for bit; new_idepth only
+    // enters the sign test and the Jacobian.  The three quotients share one refined reciprocal
+    // and use the hardware's own correction sequence (what `a / d` expands to) without the
+    // range scaling / fix-up instructions, which are identities for ordinary operands.  A wave
+    // that holds a lane outside that range takes the full IEEE divisions instead.
+    {
+      const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
+      const bool ordinary = (unsigned)(ex + 32) <= 64u && (__builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
+                            __builtin_fabsf(pt2) >= 0x1p-34f;
+      if (__builtin_expect(__ballot(!ordinary) != 0ull, 0)) {
+        W.u = pt0 / pt2;
+        W.v = pt1 / pt2;
+        W.new_idepth = id / pt2;
+      } else {
+        const float r0 = __builtin_amdgcn_rcpf(pt2);
+        const float r1 = __builtin_fmaf(__builtin_fmaf(-pt2, r0, 1.0f), r0, r0);
+        auto quot = [pt2, r1](float a) {
+          const float q0 = a * r1;
+          const float q1 = __builtin_fmaf(__builtin_fmaf(-pt2, q0, a), r1, q0);
+          return __builtin_fmaf(__builtin_fmaf(-pt2, q1, a), r1, q1);
+        };
+        W.u = quot(pt0);
+        W.v = quot(pt1);
+        W.new_idepth = id * r1;
+      }
+    }
     const float Ku = fxl * W.u + cxl;
     const float Kv = fyl * W.v + cyl;
-    W.new_idepth = id / pt2;
     W.refColor = p.w;
     W.x = x, W.y = y, W.id = id;
     W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
@@ -187,20 +215,25 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     const bool fin = W.inb && __builtin_isfinite(h0); // :791
     const float residual = MODE == 0 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
     const float ar = __builtin_fabsf(residual);
-    const float hw = ar < huber ? 1.0f : huber / ar; // :794-795
+    // Huber weight (:794-795).  It scales E and the normal equations only (no decision depends
+    // on it), so the hardware reciprocal (1 ulp) replaces the IEEE division.
+    const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
     const bool sat = ar > cutoff;                    // :797
     const bool use = fin && !sat;
     const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
     E += fin ? e_term : 0.0f;
-    n_terms += fin ? 1 : 0;
-    n_sat += (fin && sat) ? 1 : 0;
-    n_warped += use ? 1 : 0;
+    // integer outputs are counted per wave on the scalar unit (s_bcnt1 of the lane masks)
+    n_terms += __builtin_popcountll(__ballot(fin));
+    n_sat += __builtin_popcountll(__ballot(fin && sat));
+    n_warped += __builtin_popcountll(__ballot(use));
     const float wgt = use ? hw : 0.0f;
     if (MODE == 0) {
       // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
       // lanes get all-zero inputs so that they add exact zeros
-      const float u = use ? W.u : 0.0f, v = use ? W.v : 0.0f, nid = use ? W.new_idepth : 0.0f;
-      const float dx = use ? h1 * fxl : 0.0f, dy = use ? h2 * fyl : 0.0f;
+      const unsigned m = use ? 0xFFFFFFFFu : 0u;
+      auto keep = [m](float f) { return __uint_as_float(__float_as_uint(f) & m); };
+      const float u = keep(W.u), v = keep(W.v), nid = keep(W.new_idepth);
+      const float dx = keep(h1 * fxl), dy = keep(h2 * fyl);
       float J[9];
       J[0] = nid * dx;
       J[1] = nid * dy;
@@ -208,9 +241,9 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
       J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
       J[5] = __builtin_fmaf(u, dy, -(v * dx));
-      J[6] = use ? aff0 * (b0 - refColor) : 0.0f;
+      J[6] = keep(aff0 * (b0 - refColor));
       J[7] = -1.0f;
-      J[8] = use ? residual : 0.0f;
+      J[8] = keep(residual);
       int idx = 0;
 #pragma unroll
       for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
@@ -242,10 +275,12 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   };
 
   {
+    const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
+    auto load_pt = [pb, n](int idx) { return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)); };
     int i = chunk_start + tid;
-    const fvec4 p0 = pts[i < n ? i : n - 1];
+    const fvec4 p0 = load_pt(i);
     int i2 = i + kThreads;
-    fvec4 p_next = pts[i2 < n ? i2 : n - 1];
+    fvec4 p_next = load_pt(i2);
     __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
     Warped Wc;
     Taps Tc;
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       const fvec4 p = p_next;
       const bool in_next = i2 < n && k + 1 < P;
       const int i3 = i2 + kThreads;
-      p_next = pts[i3 < n ? i3 : n - 1];
+      p_next = load_pt(i3);
       Warped Wn;
       Taps Tn;
       stage_a(p, in_next, Wn, Tn);
@@ -321,7 +356,9 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
   }
   {
     const float sE = row16_sum(E), sT = row16_sum(fT), sRT = row16_sum(fRT), sN = row16_sum(fNum);
-    const int iT = row16_sum(n_terms), iS = row16_sum(n_sat), iW = row16_sum(n_warped);
+    // n_terms / n_sat / n_warped are wave totals (identical in every lane): count them once per wave
+    const bool first = lane == 0;
+    const int iT = row16_sum(first ? n_terms : 0), iS = row16_sum(first ? n_sat : 0), iW = row16_sum(first ? n_warped : 0);
     if (writer) {
       red[row][kSlotE] = sE;
       red[row][kSlotFlowT] = sT;
