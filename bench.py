@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
+    ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidth and exit")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
@@ -318,6 +319,12 @@ def bench_ringkey(args):
 
 if __name__ == "__main__":
     a = parse()
+    if a.membw:
+        from direct_stereo_slam_amd.tracker import Context
+
+        c = Context(0)
+        print(json.dumps({"read_bandwidth_GBps": {f"{mb}MiB": round(c.read_bandwidth(mb << 20, 10), 1) for mb in (512, 1024, 4096)}}))
+        sys.exit(0)
     if a.ringkey:
         bench_ringkey(a)
     else:

@@ -18,6 +18,13 @@
 #include "dsm_kernels.hpp"
 #include "lm_math.hpp"
 
+// DSM_ABLATE: developer-only ablation switches for roofline diagnosis (never set in the shipped
+// build): 1 = drop the 45-entry accumulation, 2 = gather all taps from one texel, 4 = read all
+// template points from one address.
+#ifndef DSM_ABLATE
+#define DSM_ABLATE 0
+#endif
+
 namespace dsm {
 
 // ------------------------------------------------------------------------------------------
@@ -206,7 +213,10 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     W.refColor = p.w;
     W.x = x, W.y = y, W.id = id;
     W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-    taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
+    if (DSM_ABLATE & 2)
+      taps_load<LAYOUT>(img, W.inb ? 2.25f : 2.5f, W.inb ? 2.75f : 2.5f, wl, T);
+    else
+      taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
   };
   auto stage_b = [&](const Warped &W, const Taps &T) {
     float h0, h1, h2;
@@ -244,9 +254,15 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       J[6] = keep(aff0 * (b0 - refColor));
       J[7] = -1.0f;
       J[8] = keep(residual);
+      if (DSM_ABLATE & 1) {
+        float t = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) t += J[r];
+        acc[0] = __builtin_fmaf(t, wgt, acc[0]);
+      }
       int idx = 0;
 #pragma unroll
-      for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
+      for (int r = 0; r < ((DSM_ABLATE & 1) ? 0 : 9); r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
         const float Jw = J[r] * wgt;
 #pragma unroll
         for (int c = r; c < 9; c++) {
@@ -276,7 +292,10 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
 
   {
     const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
-    auto load_pt = [pb, n](int idx) { return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)); };
+    auto load_pt = [pb, n](int idx) {
+      if (DSM_ABLATE & 4) idx &= 255;
+      return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1));
+    };
     int i = chunk_start + tid;
     const fvec4 p0 = load_pt(i);
     int i2 = i + kThreads;

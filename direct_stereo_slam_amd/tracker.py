@@ -64,6 +64,12 @@ class Context:
         check(self.L.dsm_context_get_stats(self.h, C.byref(s)))
         return s
 
+    def read_bandwidth(self, nbytes=1 << 30, iters=10):
+        """measurement aid: read-only streaming bandwidth in GB/s"""
+        g = C.c_double()
+        check(self.L.dsm_diag_read_bandwidth(self.h, nbytes, iters, C.byref(g)))
+        return g.value
+
     # ---- batched forms -----------------------------------------------------------------
     def track_batch(self, trackers, poses, affs, coarsest, min_res=None):
         n = len(trackers)

@@ -92,6 +92,10 @@ int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out);
 /* raw hipStream_t of the context (for callers that order their own device work) */
 void *dsm_context_stream(dsm_context *ctx);
 
+/* measurement aid (no reference counterpart): read-only streaming bandwidth of the device in GB/s,
+ * `bytes` per pass (choose > 256 MiB to defeat the Infinity Cache), `iters` timed passes */
+int dsm_diag_read_bandwidth(dsm_context *ctx, size_t bytes, int iters, double *gbps_out);
+
 /* ---- TrackerAndScaler ---------------------------------------------------------------- */
 /* replaces TrackerAndScaler::TrackerAndScaler(w,h,tfm_vec,K1)  (TrackerAndScaler.cpp:47-109).
  * T_f1_f0: row-major 4x4 stereo extrinsic (cams/<set>/T_stereo.yaml); K1 = {fx,fy,cx,cy} of camera 1. */
