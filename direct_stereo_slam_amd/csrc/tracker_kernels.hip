@@ -296,28 +296,55 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       if (DSM_ABLATE & 4) idx &= 255;
       return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1));
     };
-    int i = chunk_start + tid;
-    const fvec4 p0 = load_pt(i);
-    int i2 = i + kThreads;
-    fvec4 p_next = load_pt(i2);
-    __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-    Warped Wc;
-    Taps Tc;
-    stage_a(p0, i < n, Wc, Tc);
-    for (int k = 0; k < P; k++) {
-      // stage A for point k+1 (its template entry was prefetched one iteration ago)
-      const fvec4 p = p_next;
-      const bool in_next = i2 < n && k + 1 < P;
-      const int i3 = i2 + kThreads;
-      p_next = load_pt(i3);
-      Warped Wn;
-      Taps Tn;
-      stage_a(p, in_next, Wn, Tn);
-      // stage B for point k
-      stage_b(Wc, Tc);
-      Wc = Wn;
-      Tc = Tn;
-      i2 = i3;
+    const int i = chunk_start + tid;
+    if (P >= 4) {
+      // Deep prefetch of the template stream: a 4-entry register ring keeps the float4 of points
+      // k+2..k+5 in flight (4 KiB per wave) while point k+1 is warped and point k is consumed.
+      // Measured (ablation): with a one-deep prefetch the kernel was bound by
+      // the latency of this perfectly coalesced stream, not by HBM bandwidth or VALU.
+      const fvec4 p0 = load_pt(i);
+      fvec4 q[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) q[(j + 1) & 3] = load_pt(i + (j + 1) * kThreads); // points 1..4
+      Warped Wc;
+      Taps Tc;
+      stage_a(p0, i < n, Wc, Tc);
+      for (int k0 = 0; k0 < P; k0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int k = k0 + j;                     // point consumed by stage B in this step
+          const int inext = i + (k + 1) * kThreads; // point warped by stage A in this step
+          const fvec4 p = q[(j + 1) & 3];
+          q[(j + 1) & 3] = load_pt(i + (k + 5) * kThreads); // refill the slot just read
+          Warped Wn;
+          Taps Tn;
+          stage_a(p, inext < n && k + 1 < P, Wn, Tn);
+          stage_b(Wc, Tc);
+          Wc = Wn;
+          Tc = Tn;
+          __builtin_amdgcn_sched_barrier(0); // keep the four steps apart: no cross-step hoisting (register pressure)
+        }
+      }
+    } else {
+      const fvec4 p0 = load_pt(i);
+      int i2 = i + kThreads;
+      fvec4 p_next = load_pt(i2);
+      Warped Wc;
+      Taps Tc;
+      stage_a(p0, i < n, Wc, Tc);
+      for (int k = 0; k < P; k++) {
+        const fvec4 p = p_next;
+        const bool in_next = i2 < n && k + 1 < P;
+        const int i3 = i2 + kThreads;
+        p_next = load_pt(i3);
+        Warped Wn;
+        Taps Tn;
+        stage_a(p, in_next, Wn, Tn);
+        stage_b(Wc, Tc);
+        Wc = Wn;
+        Tc = Tn;
+        i2 = i3;
+      }
     }
   }
 
