@@ -157,8 +157,6 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
 
   constexpr int NACC = MODE == 0 ? kNumAcc : 3;
   float acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; i++) acc[i] = 0.f;
   float E = 0.f;
   int n_terms = 0, n_sat = 0, n_warped = 0;
 
@@ -296,55 +294,40 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       if (DSM_ABLATE & 4) idx &= 255;
       return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1));
     };
+    // Phase 1: the whole template stream of this workgroup (P points per thread, <= 32 KiB) is
+    // requested at once -- P independent 16-byte loads per lane, the only HBM-latency-bound loads
+    // of the kernel -- and parked in thread-private LDS slots.  Vector loads return in order
+    // (vmcnt), so a slow HBM load issued inside the loop would stall every younger, fast (L2-hit)
+    // tap load behind it; with the stream out of the loop the loop's vmcnt only ever covers taps.
+    // No barrier is needed: every thread reads back only what it wrote.
+    __shared__ fvec4 stage[kMaxPtsPerThread * kThreads];
     const int i = chunk_start + tid;
-    if (P >= 4) {
-      // Deep prefetch of the template stream: a 4-entry register ring keeps the float4 of points
-      // k+2..k+5 in flight (4 KiB per wave) while point k+1 is warped and point k is consumed.
-      // Measured (ablation): with a one-deep prefetch the kernel was bound by
-      // the latency of this perfectly coalesced stream, not by HBM bandwidth or VALU.
-      const fvec4 p0 = load_pt(i);
-      fvec4 q[4];
+    {
+      fvec4 v[kMaxPtsPerThread];
 #pragma unroll
-      for (int j = 0; j < 4; j++) q[(j + 1) & 3] = load_pt(i + (j + 1) * kThreads); // points 1..4
-      Warped Wc;
-      Taps Tc;
-      stage_a(p0, i < n, Wc, Tc);
-      for (int k0 = 0; k0 < P; k0 += 4) {
+      for (int k = 0; k < kMaxPtsPerThread; k++) v[k] = load_pt(i + (k < P ? k : 0) * kThreads); // straight-line: no per-load branch
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int k = k0 + j;                     // point consumed by stage B in this step
-          const int inext = i + (k + 1) * kThreads; // point warped by stage A in this step
-          const fvec4 p = q[(j + 1) & 3];
-          q[(j + 1) & 3] = load_pt(i + (k + 5) * kThreads); // refill the slot just read
-          Warped Wn;
-          Taps Tn;
-          stage_a(p, inext < n && k + 1 < P, Wn, Tn);
-          stage_b(Wc, Tc);
-          Wc = Wn;
-          Tc = Tn;
-          __builtin_amdgcn_sched_barrier(0); // keep the four steps apart: no cross-step hoisting (register pressure)
-        }
-      }
-    } else {
-      const fvec4 p0 = load_pt(i);
-      int i2 = i + kThreads;
-      fvec4 p_next = load_pt(i2);
-      Warped Wc;
-      Taps Tc;
-      stage_a(p0, i < n, Wc, Tc);
-      for (int k = 0; k < P; k++) {
-        const fvec4 p = p_next;
-        const bool in_next = i2 < n && k + 1 < P;
-        const int i3 = i2 + kThreads;
-        p_next = load_pt(i3);
-        Warped Wn;
-        Taps Tn;
-        stage_a(p, in_next, Wn, Tn);
-        stage_b(Wc, Tc);
-        Wc = Wn;
-        Tc = Tn;
-        i2 = i3;
-      }
+      for (int k = 0; k < kMaxPtsPerThread; k++) stage[k * kThreads + tid] = v[k];
+    }
+    __builtin_amdgcn_sched_barrier(0); // the P staging registers die here, before the accumulators go live
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.f;
+    // Phase 2: software pipeline over the staged points
+    fvec4 p_next = stage[tid];
+    Warped Wc;
+    Taps Tc;
+    stage_a(p_next, i < n, Wc, Tc);
+    p_next = stage[(P > 1 ? kThreads : 0) + tid];
+    for (int k = 0; k < P; k++) {
+      const fvec4 p = p_next;
+      const bool in_next = i + (k + 1) * kThreads < n && k + 1 < P;
+      p_next = stage[(k + 2 < P ? k + 2 : 0) * kThreads + tid]; // LDS prefetch (lgkmcnt, not vmcnt)
+      Warped Wn;
+      Taps Tn;
+      stage_a(p, in_next, Wn, Tn);
+      stage_b(Wc, Tc);
+      Wc = Wn;
+      Tc = Tn;
     }
   }
 
