@@ -9,9 +9,8 @@ namespace dsm {
 // Reduction geometry (part of the documented numerics): a workgroup of
 // 256 threads owns a chunk of 256*P consecutive template points, thread t handles points
 // chunk*256*P + k*256 + t for k = 0..P-1.
-constexpr int kMaxPtsPerThread = 8;
 __host__ __device__ inline int pts_per_thread(int n) {
-  return n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
+  return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
 }
 __host__ __device__ inline int num_chunks(int n) {
   const int per = kThreads * pts_per_thread(n);

@@ -294,40 +294,33 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       if (DSM_ABLATE & 4) idx &= 255;
       return *(const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1));
     };
-    // Phase 1: the whole template stream of this workgroup (P points per thread, <= 32 KiB) is
-    // requested at once -- P independent 16-byte loads per lane, the only HBM-latency-bound loads
-    // of the kernel -- and parked in thread-private LDS slots.  Vector loads return in order
-    // (vmcnt), so a slow HBM load issued inside the loop would stall every younger, fast (L2-hit)
-    // tap load behind it; with the stream out of the loop the loop's vmcnt only ever covers taps.
-    // No barrier is needed: every thread reads back only what it wrote.
-    __shared__ fvec4 stage[kMaxPtsPerThread * kThreads];
+    // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
+    // (Deeper register rings and bulk staging through LDS were measured and bought nothing -- the
+    // kernel is not bound by the latency of this stream)
     const int i = chunk_start + tid;
-    {
-      fvec4 v[kMaxPtsPerThread];
-#pragma unroll
-      for (int k = 0; k < kMaxPtsPerThread; k++) v[k] = load_pt(i + (k < P ? k : 0) * kThreads); // straight-line: no per-load branch
-#pragma unroll
-      for (int k = 0; k < kMaxPtsPerThread; k++) stage[k * kThreads + tid] = v[k];
-    }
-    __builtin_amdgcn_sched_barrier(0); // the P staging registers die here, before the accumulators go live
+    const fvec4 p0 = load_pt(i);
+    int i2 = i + kThreads;
+    fvec4 p_next = load_pt(i2);
+    __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.f;
-    // Phase 2: software pipeline over the staged points
-    fvec4 p_next = stage[tid];
     Warped Wc;
     Taps Tc;
-    stage_a(p_next, i < n, Wc, Tc);
-    p_next = stage[(P > 1 ? kThreads : 0) + tid];
+    stage_a(p0, i < n, Wc, Tc);
     for (int k = 0; k < P; k++) {
+      // stage A for point k+1 (its template entry was prefetched one iteration ago)
       const fvec4 p = p_next;
-      const bool in_next = i + (k + 1) * kThreads < n && k + 1 < P;
-      p_next = stage[(k + 2 < P ? k + 2 : 0) * kThreads + tid]; // LDS prefetch (lgkmcnt, not vmcnt)
+      const bool in_next = i2 < n && k + 1 < P;
+      const int i3 = i2 + kThreads;
+      p_next = load_pt(i3);
       Warped Wn;
       Taps Tn;
       stage_a(p, in_next, Wn, Tn);
+      // stage B for point k
       stage_b(Wc, Tc);
       Wc = Wn;
       Tc = Tn;
+      i2 = i3;
     }
   }
 
