@@ -37,13 +37,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="independent stereo frames in flight per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="independent stereo frames in flight per GPU")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes (cycled over the batch)")
     ap.add_argument("--config", default="S1", choices=["S1", "S2"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--kf-every", type=int, default=5)
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
@@ -218,8 +218,17 @@ def bench_tracking(args):
     l0_launches = stt.launches[0]
     l0_evals = stt.evals[0]
     achieved = (l0_evals * bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); scaled to
+    # this run's bytes per launch.  None when the summary is absent.
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        traffic = pm["hbm_bytes_per_algorithmic_byte_level0_pose_eval"] * l0_evals * bytes_eval0 / max(1, l0_launches)
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "eval_kernel<pose, LVL0>",
+                "traffic": traffic, "kernel": "eval_kernel<pose, LVL0>",
                 "bytes_per_launch": l0_evals * bytes_eval0 / max(1, l0_launches),
                 "avg_launch_us": 1e3 * l0_ms / max(1, l0_launches), "launches": int(l0_launches)}
     per_level = []

@@ -1,0 +1,119 @@
+"""Golden fixtures (tests/golden/*.npz, minted by tests/golden/make_golden.py from the oracle).
+CPU: the oracle must reproduce them bit for bit.  GPU: the HIP path must match them to the
+parity bars (integer outputs exact, sums 2e-5 relative, LM results 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+from direct_stereo_slam_amd import synth as S
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_tracker_fixture():
+    d = np.load(os.path.join(G, "tracker_tiny.npz"))
+    nl = int(d["nl"])
+    tpl = [[d[f"tpl_{n}{l}"] for l in range(nl)] for n in ("u", "v", "id", "c")]
+    new_p = [d[f"new{l}"] for l in range(nl)]
+    right_p = [d[f"right{l}"] for l in range(nl)]
+    return d, nl, tpl, new_p, right_p
+
+
+def test_oracle_reproduces_golden_tracker():
+    d, nl, tpl, new_p, right_p = load_tracker_fixture()
+    w, h, K, T = int(d["w"]), int(d["h"]), tuple(d["K"]), d["T"]
+    orc = O.OracleTracker(w, h, nl, T, K)
+    orc.make_k(*K)
+    orc.set_ref(0, 0.0, 0.0, 1.0, *tpl)
+    orc.set_frame(0, new_p, 1.0)
+    orc.set_frame(1, right_p, 1.0)
+    for lvl in range(nl):
+        for tag in ("id", "gt"):
+            x = d[f"pose_{tag}{lvl}_in"]
+            rs = orc.calc_res_pose(lvl, x[:7], x[7:], 20.0)
+            H, b = orc.calc_gs_pose(lvl, x[:7], x[7:])
+            np.testing.assert_array_equal(rs, d[f"pose_{tag}{lvl}_rs"])
+            np.testing.assert_array_equal(H, d[f"pose_{tag}{lvl}_H"])
+            np.testing.assert_array_equal(b, d[f"pose_{tag}{lvl}_b"])
+            assert orc.pose_warped_n() == int(d[f"pose_{tag}{lvl}_n"])
+        for s in (1.0, 0.8):
+            rs = orc.calc_res_scale(lvl, s, 20.0)
+            Hs, bs = orc.calc_gs_scale(lvl, s)
+            np.testing.assert_array_equal(rs, d[f"scale_{s}_{lvl}_rs"])
+            np.testing.assert_array_equal(np.array([Hs, bs], np.float32), d[f"scale_{s}_{lvl}_Hb"])
+    good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+    assert good == bool(d["track_good"])
+    # libm's exp/sin/cos may differ in the last bit between machines: 1e-12, not bit equality
+    np.testing.assert_allclose(pose, d["track_pose"], atol=1e-12)
+    np.testing.assert_allclose(aff, d["track_aff"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(last, d["track_last"], rtol=1e-6, equal_nan=True)
+    assert orc.eval_counts()[0] == list(d["track_evals"])
+    err, s = orc.optimize_scale(1.0, nl - 1)
+    assert np.float32(s) == d["scale_out"] and np.float32(err) == d["scale_err"]
+    # and the tracked pose is the ground truth of the synthetic scene
+    np.testing.assert_allclose(pose[4:], d["gt_pose"][4:], atol=5e-3)
+
+
+def test_oracle_reproduces_golden_ringkey():
+    d = np.load(os.path.join(G, "ringkey_500.npz"))
+    db = O.OracleRingDB(dummy=d["dummy"])
+    for k, exp in zip(d["keys"], d["candidates"]):
+        assert db.query_then_enqueue(k) == [int(x) for x in exp if x >= 0]
+    dbinf = O.OracleRingDB(dummy=d["dummy"], thres=np.inf)
+    dbinf.add_points(d["keys"])
+    for q, ei, ed in zip(d["queries"], d["knn_idx"], d["knn_dist"]):
+        ii, dd = dbinf.knn(q)
+        assert ii == list(ei) and [np.float32(x) for x in dd] == list(ed)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_tracker(ctx):
+    from direct_stereo_slam_amd.tracker import TrackerAndScaler
+
+    d, nl, tpl, new_p, right_p = load_tracker_fixture()
+    w, h, K, T = int(d["w"]), int(d["h"]), tuple(d["K"]), d["T"]
+    trk = TrackerAndScaler(ctx, w, h, nl, T, K)
+    trk.makeK(*K)
+    trk.setCoarseTrackingRef(0, (0.0, 0.0), 1.0, *tpl)
+    trk.upload_frame(0, new_p, 1.0)
+    trk.upload_frame(1, right_p, 1.0)
+    for lvl in range(nl):
+        for tag in ("id", "gt"):
+            x = d[f"pose_{tag}{lvl}_in"]
+            rs, H, b, n = trk.calcResPose(lvl, x[:7], x[7:], 20.0)
+            g_rs, g_H, g_b = d[f"pose_{tag}{lvl}_rs"], d[f"pose_{tag}{lvl}_H"], d[f"pose_{tag}{lvl}_b"]
+            assert rs[1] == g_rs[1] and n == int(d[f"pose_{tag}{lvl}_n"]) and np.float32(rs[5]) == np.float32(g_rs[5])
+            np.testing.assert_allclose(rs[0], float(d[f"pose_{tag}{lvl}_E64"]), rtol=2e-6)
+            np.testing.assert_allclose(rs[2:5], g_rs[2:5], rtol=2e-5, atol=1e-9)
+            np.testing.assert_allclose(H, g_H, rtol=0, atol=2e-5 * np.abs(g_H).max())
+            np.testing.assert_allclose(b, g_b, rtol=0, atol=2e-5 * max(np.abs(g_b).max(), 1e-3 * np.sqrt(np.abs(g_H).max())))
+        for s in (1.0, 0.8):
+            rs, Hs, bs, n = trk.calcResScale(lvl, s, 20.0)
+            g_rs, g_Hb = d[f"scale_{s}_{lvl}_rs"], d[f"scale_{s}_{lvl}_Hb"]
+            assert rs[1] == g_rs[1] and n == int(d[f"scale_{s}_{lvl}_n"])
+            np.testing.assert_allclose(rs[0], float(d[f"scale_{s}_{lvl}_E64"]), rtol=2e-6)
+            assert abs(Hs - g_Hb[0]) <= 5e-5 * abs(g_Hb[0]) and abs(bs - g_Hb[1]) <= 5e-5 * max(abs(g_Hb[1]), 1e-3 * abs(g_Hb[0]))
+    good, pose, aff, last = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], nl - 1)
+    assert good == bool(d["track_good"])
+    np.testing.assert_allclose(pose, d["track_pose"], atol=1e-4)
+    np.testing.assert_allclose(last[:nl], d["track_last"][:nl], rtol=1e-4)
+    assert list(ctx.stats().evals)[:nl] == list(d["track_evals"])[:nl]
+    err, s = trk.optimizeScale(1.0, nl - 1)
+    assert abs(s - float(d["scale_out"])) < 1e-4 and abs(err - float(d["scale_err"])) < 1e-4 * float(d["scale_err"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_ringkey(ctx):
+    from direct_stereo_slam_amd.ringdb import RingKeyDB, unpack
+
+    d = np.load(os.path.join(G, "ringkey_500.npz"))
+    db = RingKeyDB(ctx, dummy=d["dummy"])
+    for k, exp in zip(d["keys"], d["candidates"]):
+        assert db.search_ringkey(k) == [int(x) for x in exp if x >= 0]  # match indices bit exact
+    dbinf = RingKeyDB(ctx, dummy=d["dummy"], thres=np.inf)
+    dbinf.add_points(d["keys"])
+    dist, idx = unpack(dbinf.knn_packed_host(d["queries"]))
+    np.testing.assert_array_equal(idx, d["knn_idx"])
+    np.testing.assert_array_equal(dist, d["knn_dist"])
