@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--device-override", type=int, default=-1, help="testing: put every rank on this device")
     ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidth and exit")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
@@ -54,18 +56,28 @@ def parse():
     return ap.parse_args()
 
 
-def dist_setup(n):
+_BACKEND = "nccl"
+
+
+def dist_setup(args):
     import torch
 
+    global _BACKEND
+    _BACKEND = args.dist_backend
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.device_override >= 0:
+        local = args.device_override
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if _BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(_BACKEND)
     return rank, local, world
 
 
@@ -86,7 +98,7 @@ def max_over_ranks(x, world):
         return x
     import torch.distributed as dist
 
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if _BACKEND == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -187,7 +199,7 @@ def bench_tracking(args):
 
     from direct_stereo_slam_amd.tracker import Context
 
-    rank, local, world = dist_setup(args.gpus)
+    rank, local, world = dist_setup(args)
     ctx = Context(local)
     wl = build_workload(args, ctx, rank)
     B = args.batch
@@ -282,7 +294,7 @@ def bench_ringkey(args):
     from direct_stereo_slam_amd.ringdb import RingKeyDB, merge_topk_allreduce_min
     from direct_stereo_slam_amd.tracker import Context
 
-    rank, local, world = dist_setup(args.gpus)
+    rank, local, world = dist_setup(args)
     ctx = Context(local)
     rng = np.random.default_rng(1234)
     p = rng.uniform(0.1, 0.9, 20)
@@ -297,7 +309,12 @@ def bench_ringkey(args):
         if world > 1:
             import torch.distributed as dist
 
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if _BACKEND == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            else:  # plumbing test on one GPU: reduce through the host
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MIN)
+                t.copy_(c)
 
     def step():
         db.knn_packed_device(dq.data_ptr(), args.rk_q, out.data_ptr())
