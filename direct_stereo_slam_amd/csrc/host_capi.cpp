@@ -2,6 +2,7 @@
 // search_sc (<= 3 candidates per query, src/loop_closure/loop_detection/search_place.h:59-84).
 // Plain C++; no device code.
 #include "../../include/dsm_hotpath.h"
+#include <algorithm>
 
 extern "C" {
 
@@ -39,6 +40,222 @@ int dsm_search_sc(const int *sig_idx, const double *sig_val, int n_sig, int n_ca
       *res_idx = cand_ids[c];
       *res_diff = cur;
     }
+  }
+  return DSM_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// ScanContext::generate, ScanContext.cpp:78-141 (+ align_points_PCA :19-66)
+// ---------------------------------------------------------------------------------------------
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi, double), eigenvalues ascending as
+// Eigen::SelfAdjointEigenSolver returns them (:43-47); columns of V are the eigenvectors
+void eig3_sym(const double A_in[9], double evals[3], double V[9]) {
+  double A[9];
+  memcpy(A, A_in, sizeof A);
+  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-300 || off <= 1e-32 * diag) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; k++) { // A <- A J
+          const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) { // A <- J^T A
+          const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) { // V <- V J
+          const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq;
+          V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  const double d[3] = {A[0], A[4], A[8]};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2 - i; j++)
+      if (d[idx[j]] > d[idx[j + 1]]) {
+        const int t = idx[j];
+        idx[j] = idx[j + 1];
+        idx[j + 1] = t;
+      }
+  double Vs[9];
+  for (int c = 0; c < 3; c++) {
+    evals[c] = d[idx[c]];
+    int big = 0;
+    for (int r = 1; r < 3; r++)
+      if (std::fabs(V[r * 3 + idx[c]]) > std::fabs(V[big * 3 + idx[c]])) big = r;
+    const double sgn = V[big * 3 + idx[c]] < 0 ? -1.0 : 1.0; // orientation convention, see header
+    for (int r = 0; r < 3; r++) Vs[r * 3 + c] = sgn * V[r * 3 + idx[c]];
+  }
+  memcpy(V, Vs, sizeof Vs);
+}
+
+} // namespace
+
+extern "C" {
+
+int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int num_s, int num_r, float *ringkey,
+                             int *sig_idx, double *sig_val, int *n_sig_out, double *tfm) {
+  if (!pts || n < 1 || num_s < 1 || num_r < 1 || !ringkey || !sig_idx || !sig_val || !n_sig_out || !tfm)
+    return DSM_ERR_INVALID;
+  // align_points_PCA :19-66
+  double mx = 0, my = 0, mz = 0;
+  for (int i = 0; i < n; i++) {
+    mx += pts[3 * i];
+    my += pts[3 * i + 1];
+    mz += pts[3 * i + 2];
+  }
+  mx /= n;
+  my /= n;
+  mz /= n;
+  double cov[9] = {0};
+  for (int i = 0; i < n; i++) {
+    const double x = pts[3 * i] - mx, y = pts[3 * i + 1] - my, z = pts[3 * i + 2] - mz;
+    cov[0] += x * x, cov[1] += x * y, cov[2] += x * z, cov[4] += y * y, cov[5] += y * z, cov[8] += z * z;
+  }
+  cov[3] = cov[1], cov[6] = cov[2], cov[7] = cov[5];
+  double ev[3], V[9];
+  eig3_sym(cov, ev, V);
+  for (int i = 0; i < 16; i++) tfm[i] = (i % 5 == 0) ? 1.0 : 0.0; // :55-64
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) tfm[r * 4 + c] = V[c * 3 + r]; // row r = v_r^T
+  for (int r = 0; r < 3; r++) tfm[r * 4 + 3] = -(tfm[r * 4 + 0] * mx + tfm[r * 4 + 1] * my + tfm[r * 4 + 2] * mz);
+
+  // generate :78-141
+  for (int i = 0; i < num_r; i++) ringkey[i] = 0.0f;
+  std::vector<double> max_height((size_t)num_s * num_r, -lidar_range - 1.0);
+  for (int i = 0; i < n; i++) {
+    const double x = pts[3 * i] - mx, y = pts[3 * i + 1] - my, z = pts[3 * i + 2] - mz;
+    const double xp = x * V[0] + y * V[3] + z * V[6]; // pts_mat * v0  (x: up)
+    const double yp = x * V[1] + y * V[4] + z * V[7];
+    const double zp = x * V[2] + y * V[5] + z * V[8];
+    const double rho = std::sqrt(yp * yp + zp * zp);
+    double theta = std::atan2(zp, yp);
+    while (theta < 0) theta += 2.0 * M_PI;
+    while (theta >= 2.0 * M_PI) theta -= 2.0 * M_PI;
+    const int si = theta / (2.0 * M_PI) * num_s;
+    const int ri = rho / lidar_range * num_r;
+    if (ri >= num_r) continue; // :113-114
+    if (si >= num_s) continue; // the reference only asserts this (:112, compiled out); never write out of bounds
+    double &mh = max_height[(size_t)si * num_r + ri];
+    mh = std::max(mh, xp);
+  }
+  std::vector<double> norm(num_s, 0.0);
+  int ns = 0;
+  for (int i = 0; i < num_s * num_r; i++)
+    if (max_height[i] >= -lidar_range) { // :124-131
+      ringkey[i % num_r] += 1.0f;
+      sig_idx[ns] = i;
+      sig_val[ns] = max_height[i];
+      ns++;
+      norm[i / num_r] += max_height[i] * max_height[i];
+    }
+  for (int i = 0; i < num_r; i++) ringkey[i] /= num_s; // :134-136
+  for (int s = 0; s < num_s; s++) norm[s] = std::sqrt(norm[s]);
+  for (int k = 0; k < ns; k++) sig_val[k] /= norm[sig_idx[k] / num_r]; // :139-141
+  *n_sig_out = ns;
+  return DSM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// makeCoarseDepthL0, TrackerAndScaler.cpp:143-315 (flat-array form)
+// ---------------------------------------------------------------------------------------------
+int dsm_make_coarse_depth_l0(int w0, int h0, int nl, int npts, const float *pu, const float *pv, const float *pidepth,
+                             const float *pweight, const float *const *ref_dIp, int *n_out, float *const *pc_u,
+                             float *const *pc_v, float *const *pc_idepth, float *const *pc_color) {
+  if (nl < 1 || nl > DSM_MAX_LEVELS || npts < 0 || !ref_dIp || !n_out || !pc_u || !pc_v || !pc_idepth || !pc_color)
+    return DSM_ERR_INVALID;
+  std::vector<std::vector<float>> idepth(nl), wsum(nl), bak(nl);
+  int w[DSM_MAX_LEVELS], h[DSM_MAX_LEVELS];
+  for (int l = 0; l < nl; l++) {
+    w[l] = w0 >> l;
+    h[l] = h0 >> l;
+    idepth[l].assign((size_t)w[l] * h[l], 0.f);
+    wsum[l].assign((size_t)w[l] * h[l], 0.f);
+    bak[l].assign((size_t)w[l] * h[l], 0.f);
+  }
+  for (int k = 0; k < npts; k++) { // :149-164
+    const int u = pu[k] + 0.5f;
+    const int v = pv[k] + 0.5f;
+    if (u < 0 || v < 0 || u >= w[0] || v >= h[0]) return DSM_ERR_INVALID; // the reference would write out of bounds
+    idepth[0][u + w[0] * v] += pidepth[k] * pweight[k];
+    wsum[0][u + w[0] * v] += pweight[k];
+  }
+  for (int lvl = 1; lvl < nl; lvl++) { // :166-187 (2x2 sums)
+    const int wl = w[lvl], hl = h[lvl], wlm1 = w[lvl - 1];
+    const float *idm = idepth[lvl - 1].data(), *wsm = wsum[lvl - 1].data();
+    for (int y = 0; y < hl; y++)
+      for (int x = 0; x < wl; x++) {
+        const int b = 2 * x + 2 * y * wlm1;
+        idepth[lvl][x + y * wl] = idm[b] + idm[b + 1] + idm[b + wlm1] + idm[b + wlm1 + 1];
+        wsum[lvl][x + y * wl] = wsm[b] + wsm[b + 1] + wsm[b + wlm1] + wsm[b + wlm1 + 1];
+      }
+  }
+  for (int lvl = 0; lvl < nl; lvl++) { // dilation :190-275
+    const int wl = w[lvl], wh = w[lvl] * h[lvl] - w[lvl];
+    float *ws = wsum[lvl].data(), *bk = bak[lvl].data(), *idl = idepth[lvl].data();
+    memcpy(bk, ws, sizeof(float) * (size_t)w[lvl] * h[lvl]);
+    const int diag[4] = {1 + wl, -1 - wl, wl - 1, -wl + 1}, axis[4] = {1, -1, wl, -wl};
+    const int *off = lvl < 2 ? diag : axis;
+    for (int i = wl; i < wh; i++)
+      if (bk[i] <= 0) {
+        float sum = 0, num = 0, numn = 0;
+        for (int k = 0; k < 4; k++)
+          if (bk[i + off[k]] > 0) {
+            sum += idl[i + off[k]];
+            num += bk[i + off[k]];
+            numn++;
+          }
+        if (numn > 0) {
+          idl[i] = sum / numn;
+          ws[i] = num / numn;
+        }
+      }
+  }
+  for (int lvl = 0; lvl < nl; lvl++) { // :278-314
+    float *ws = wsum[lvl].data(), *idl = idepth[lvl].data();
+    const float *ref = ref_dIp[lvl];
+    const int wl = w[lvl], hl = h[lvl];
+    int n = 0;
+    for (int y = 2; y < hl - 2; y++)
+      for (int x = 2; x < wl - 2; x++) {
+        const int i = x + y * wl;
+        if (ws[i] > 0) {
+          idl[i] /= ws[i];
+          pc_u[lvl][n] = x;
+          pc_v[lvl][n] = y;
+          pc_idepth[lvl][n] = idl[i];
+          pc_color[lvl][n] = ref[3 * i];
+          if (!std::isfinite(pc_color[lvl][n]) || !(idl[i] > 0)) {
+            idl[i] = -1;
+            continue;
+          }
+          n++;
+        } else
+          idl[i] = -1;
+        ws[i] = 1;
+      }
+    n_out[lvl] = n;
   }
   return DSM_OK;
 }

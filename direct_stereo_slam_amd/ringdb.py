@@ -110,3 +110,19 @@ class RingKeyDB:
         """queries / output are raw device pointers (e.g. torch tensors' data_ptr()); asynchronous on
         the context stream -- call ctx.sync() before another stream consumes the result."""
         check(self.L.dsm_ringdb_knn_packed_dev(self.h, C.c_void_p(d_queries_ptr), nq, C.c_void_p(d_out_ptr)))
+
+
+def scancontext_generate(pts_spherical, lidar_range, num_s=60, num_r=20):
+    """ScanContext::generate (ScanContext.cpp:78-141) through the C ABI (host code by design).
+    Returns (ringkey[num_r] float32, sig_idx int32, sig_val float64, tfm_pca_rig 4x4)."""
+    L = _lib.load()
+    pts = np.ascontiguousarray(pts_spherical, np.float64).reshape(-1, 3)
+    ringkey = np.zeros(num_r, np.float32)
+    sig_idx = np.zeros(num_s * num_r, np.int32)
+    sig_val = np.zeros(num_s * num_r, np.float64)
+    n_sig = C.c_int()
+    tfm = np.zeros(16)
+    check(L.dsm_scancontext_generate(pts.ctypes.data_as(_lib.c_double_p), len(pts), lidar_range, num_s, num_r, _fp(ringkey),
+                                     sig_idx.ctypes.data_as(c_int_p), sig_val.ctypes.data_as(_lib.c_double_p), C.byref(n_sig),
+                                     tfm.ctypes.data_as(_lib.c_double_p)))
+    return ringkey, sig_idx[: n_sig.value].copy(), sig_val[: n_sig.value].copy(), tfm.reshape(4, 4)

@@ -137,18 +137,23 @@ class PlaneScene:
             img = img + (rng or np.random.default_rng(0)).normal(0, noise, img.shape)
         return img.astype(np.float32)
 
-    def idepth(self, K, w, h):
+    def idepth(self, K, w, h, R=None, t=None):
+        """inverse depth seen by a camera with x_cam = R x_ref + t (default: the reference camera)"""
         r = self._rays(K, w, h)
-        return ((r @ self.n) / self.d).astype(np.float32)
+        if R is None:
+            return ((r @ self.n) / self.d).astype(np.float32)
+        t = np.asarray(t, np.float64)
+        return ((r @ (R @ self.n)) / (self.d + self.n @ (R.T @ t))).astype(np.float32)
 
 
-def dense_template(scene, K, w, h, nlevels, ref_pyr, idepth_scale=1.0):
+def dense_template(scene, K, w, h, nlevels, ref_pyr, idepth_scale=1.0, R=None, t=None):
     """every interior pixel 2<=x<wl-2, 2<=y<hl-2 is a template point (the emit rule of
-    makeCoarseDepthL0, TrackerAndScaler.cpp:291-314), row-major order as the reference emits."""
+    makeCoarseDepthL0, TrackerAndScaler.cpp:291-314), row-major order as the reference emits.
+    (R, t): pose of the keyframe camera in the scene's reference frame (default identity)."""
     us, vs, ids, cs = [], [], [], []
     for l in range(nlevels):
         wl, hl = w >> l, h >> l
-        idl = scene.idepth(level_K(K, l), wl, hl) * np.float32(idepth_scale)
+        idl = scene.idepth(level_K(K, l), wl, hl, R, t) * np.float32(idepth_scale)
         ys, xs = np.mgrid[2:hl - 2, 2:wl - 2]
         us.append(xs.astype(np.float32).ravel())
         vs.append(ys.astype(np.float32).ravel())

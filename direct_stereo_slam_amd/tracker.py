@@ -191,3 +191,17 @@ class TrackerAndScaler:
         t, p, c = C.c_int(), C.c_int(), C.c_int()
         check(self.L.dsm_reduction_geometry(self.h, lvl, n, C.byref(t), C.byref(p), C.byref(c)))
         return t.value, p.value, c.value
+
+
+def make_coarse_depth_l0(w, h, nlevels, pu, pv, pidepth, pweight, ref_dIp):
+    """TrackerAndScaler::makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) from flat active-point arrays,
+    through the C ABI (host code in this round).  Returns [pc_u, pc_v, pc_idepth, pc_color] lists per level,
+    i.e. the arguments of setCoarseTrackingRef."""
+    L = _lib.load()
+    pu, pv, pidepth, pweight = [np.ascontiguousarray(a, np.float32) for a in (pu, pv, pidepth, pweight)]
+    ref = [np.ascontiguousarray(a, np.float32) for a in ref_dIp]
+    n_out = (C.c_int * nlevels)()
+    outs = [[np.zeros((w >> l) * (h >> l), np.float32) for l in range(nlevels)] for _ in range(4)]
+    check(L.dsm_make_coarse_depth_l0(w, h, nlevels, len(pu), _fp(pu), _fp(pv), _fp(pidepth), _fp(pweight), _ptr_array(ref),
+                                     n_out, *[_ptr_array(o) for o in outs]))
+    return [[o[l][: n_out[l]].copy() for l in range(nlevels)] for o in outs]

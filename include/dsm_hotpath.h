@@ -197,6 +197,26 @@ int dsm_ringdb_knn_packed_dev(dsm_ringdb *db, const void *d_queries, int nq, voi
 /* same, result copied to host memory (nq*k int64) */
 int dsm_ringdb_knn_packed_host(dsm_ringdb *db, const float *queries, int nq, int64_t *packed_out);
 
+/* replaces ScanContext::generate (src/loop_closure/loop_detection/ScanContext.cpp:78-141, with
+ * align_points_PCA :19-66).  Host side by design: a few 10^3 points per
+ * keyframe.  pts: n x 3 doubles.  ringkey_out: num_r floats.  sig_idx_out / sig_val_out: capacity
+ * num_s*num_r, *n_sig_out entries written (sparse signature, ascending bin index).  tfm_pca_rig_out:
+ * row-major 4x4.  Eigenvector signs are not defined by the reference (Eigen's solver); here every
+ * eigenvector is oriented so that its largest-magnitude component is positive. */
+int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int num_s, int num_r,
+                             float *ringkey_out, int *sig_idx_out, double *sig_val_out, int *n_sig_out,
+                             double *tfm_pca_rig_out);
+
+/* replaces TrackerAndScaler::makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) for callers that hold
+ * the active points as flat arrays: (pu,pv) = centerProjectedTo[0..1], pidepth = centerProjectedTo[2],
+ * pweight = sqrtf(1e-3/(HdiF+1e-12)) (:155-158).  ref_dIp[lvl]: the keyframe's (I,dx,dy) pyramid.
+ * Outputs: n_out[lvl] and the four template lists (capacity w_l*h_l each) -- exactly the arguments of
+ * dsm_tracker_set_ref.  Host side in this round (row A4 / N3). */
+int dsm_make_coarse_depth_l0(int w, int h, int nlevels, int npts, const float *pu, const float *pv,
+                             const float *pidepth, const float *pweight, const float *const *ref_dIp,
+                             int *n_out, float *const *pc_u, float *const *pc_v, float *const *pc_idepth,
+                             float *const *pc_color);
+
 /* replaces the inner loop of search_sc (search_place.h:67-79): sparse merge-join distance of
  * two ScanContext signatures.  Host side by design (<= 3 candidates per query). */
 float dsm_sc_distance(const int *sigA_idx, const double *sigA_val, int nA, const int *sigB_idx,

@@ -1,0 +1,195 @@
+"""GPU: replay of a synthetic stereo sequence with keyframe changes, scale optimisation and ring-key
+place recognition through the C ABI, against the same replay on the CPU oracle.
+
+This is the "trajectory ATE vs the CPU reference" check of BASELINE.md (north_star: ATE within 1 %):
+real bags are not available here, so the sequence is the ray-cast plane scene with a known camera
+path.  The driver loop below plays the role of FrontEnd (keyframe every 5th frame, initial guess =
+last relative pose, FrontEnd.cpp:644-667 simplified) and LoopHandler (one ring key per keyframe).
+The trajectory is also written in the reference's dslam.txt format (LoopHandler.cpp:66-77)."""
+import io
+
+import numpy as np
+import pytest
+
+from direct_stereo_slam_amd import synth as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def inv_pose(p):
+    R = S.quat_to_rot(p[:4])
+    return S.pose_from_Rt(R.T, -R.T @ p[4:])
+
+
+def mul_pose(a, b):
+    Ra, Rb = S.quat_to_rot(a[:4]), S.quat_to_rot(b[:4])
+    return S.pose_from_Rt(Ra @ Rb, Ra @ b[4:] + a[4:])
+
+
+def camera_path(n, seed):
+    """smooth forward motion with gentle yaw: list of (R, t) with x_cam = R x_world + t"""
+    rng = np.random.default_rng(seed)
+    poses = []
+    R, c = np.eye(3), np.zeros(3)
+    for i in range(n):
+        poses.append((R.copy(), -R @ c))
+        step = np.array([0.03 * np.sin(i / 7.0), 0.01 * np.cos(i / 5.0), 0.12]) + rng.normal(0, 0.004, 3)
+        c = c + R.T @ step
+        R = S.so3_exp(np.array([0.001, 0.004 * np.sin(i / 9.0), 0.0005]) + rng.normal(0, 0.0005, 3)) @ R
+    return poses
+
+
+def ate(a, b):
+    return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(1).mean()))
+
+
+def write_dslam(traj):
+    f = io.StringIO()
+    for i, t in enumerate(traj):  # "incoming_id x y z", setprecision(6) (LoopHandler.cpp:62-77)
+        f.write(f"{i} {t[0]:.6g} {t[1]:.6g} {t[2]:.6g}\n")
+    return f.getvalue()
+
+
+class Replay:
+    """FrontEnd-like driver over either backend (same code for the oracle and the HIP path)"""
+
+    def __init__(self, backend, w, h, nl, K, T):
+        self.b, self.w, self.h, self.nl, self.K, self.T = backend, w, h, nl, K, T
+
+    def run(self, scene, path, kf_every=5, noise=1.0, seed=0):
+        rng = np.random.default_rng(seed)
+        w, h, nl, K, T = self.w, self.h, self.nl, self.K, self.T
+        traj, scales, evals = [], [], []
+        T_kf_w = None      # pose of the current keyframe (x_kf = R x_w + t) as estimated
+        last_rel = S.IDENTITY_POSE.copy()
+        for i, (R, t) in enumerate(path):
+            img = scene.render(K, w, h, R, t, noise=noise, rng=rng)
+            pyr = O.make_images(img, nl)
+            if i == 0:
+                est = S.pose_from_Rt(R, t)  # first frame: ground truth (the initializer is out of scope)
+            else:
+                self.b.set_new_frame(pyr)
+                good, rel, aff, last = self.b.track(last_rel, [0.0, 0.0], nl - 1)
+                assert good, f"tracking lost at frame {i}"
+                evals.append(self.b.track_evals())
+                last_rel = rel
+                est = mul_pose(rel, T_kf_w)  # x_f = rel * x_kf
+            traj.append(-S.quat_to_rot(est[:4]).T @ est[4:])  # camera centre in the world
+            if i % kf_every == 0:
+                # new keyframe: template from the (known) scene depth at the TRUE pose, colours from this image;
+                # right image for the scale optimiser
+                tpl = S.dense_template(scene, K, w, h, nl, pyr, R=R, t=t)
+                self.b.set_ref(i, tpl)
+                Rr, tr = T[:3, :3] @ R, T[:3, :3] @ t + T[:3, 3]
+                right = scene.render(K, w, h, Rr, tr, noise=noise, rng=rng)
+                self.b.set_right_frame(O.make_images(right, nl))
+                err, s = self.b.optimize_scale(1.0, nl - 1)
+                scales.append((err, s))
+                T_kf_w = est
+                last_rel = S.IDENTITY_POSE.copy()
+        return np.array(traj), scales, evals
+
+
+class OracleBackend:
+    def __init__(self, w, h, nl, K, T):
+        self.t = O.OracleTracker(w, h, nl, T, K)
+        self.t.make_k(*K)
+
+    def set_ref(self, i, tpl):
+        self.t.set_ref(i, 0.0, 0.0, 1.0, *tpl)
+
+    def set_new_frame(self, pyr):
+        self.t.set_frame(0, pyr, 1.0)
+
+    def set_right_frame(self, pyr):
+        self.t.set_frame(1, pyr, 1.0)
+
+    def track(self, pose, aff, lvl):
+        good, p, a, last, _ = self.t.track(pose, aff, lvl)
+        return good, p, a, last
+
+    def track_evals(self):
+        return self.t.eval_counts()[0]
+
+    def optimize_scale(self, s, lvl):
+        return self.t.optimize_scale(s, lvl)
+
+
+class HipBackend:
+    def __init__(self, ctx, w, h, nl, K, T):
+        from direct_stereo_slam_amd.tracker import TrackerAndScaler
+
+        self.ctx = ctx
+        self.t = TrackerAndScaler(ctx, w, h, nl, T, K)
+        self.t.makeK(*K)
+
+    def set_ref(self, i, tpl):
+        self.t.setCoarseTrackingRef(i, (0.0, 0.0), 1.0, *tpl)
+
+    def set_new_frame(self, pyr):
+        self.t.upload_frame(0, pyr, 1.0)
+
+    def set_right_frame(self, pyr):
+        self.t.upload_frame(1, pyr, 1.0)
+
+    def track(self, pose, aff, lvl):
+        return self.t.trackNewestCoarse(pose, aff, lvl)
+
+    def track_evals(self):
+        return list(self.ctx.stats().evals)
+
+    def optimize_scale(self, s, lvl):
+        return self.t.optimizeScale(s, lvl)
+
+
+def test_replay_trajectory_matches_cpu_reference(ctx):
+    w, h, klvl, nl = 308, 92, 2, 3
+    K = S.level_K(S.kitti_K_work(), klvl)
+    T = S.KITTI_T_STEREO
+    scene = S.PlaneScene(seed=77, fx_ref=K[0], dist=9.0)
+    path = camera_path(36, seed=3)
+    gt = np.array([-R.T @ t for R, t in path])
+    traj_o, scales_o, evals_o = Replay(OracleBackend(w, h, nl, K, T), w, h, nl, K, T).run(scene, path)
+    traj_g, scales_g, evals_g = Replay(HipBackend(ctx, w, h, nl, K, T), w, h, nl, K, T).run(scene, path)
+    ate_o, ate_g = ate(traj_o, gt), ate(traj_g, gt)
+    # both follow the ground truth; the HIP trajectory is within 1 % of the CPU path's ATE and the two
+    # trajectories differ by far less than either differs from the truth
+    assert ate_o < 0.02 and ate_g < 0.02, (ate_o, ate_g)
+    assert abs(ate_g - ate_o) <= 0.01 * ate_o + 1e-5, (ate_g, ate_o)
+    assert ate(traj_g, traj_o) < 2e-4
+    rpe = np.abs(np.diff(traj_g, axis=0) - np.diff(traj_o, axis=0)).max()
+    assert rpe < 2e-4
+    # same LM behaviour frame by frame
+    assert evals_g == evals_o
+    for (eo, so), (eg, sg) in zip(scales_o, scales_g):
+        assert abs(sg - so) < 1e-4 and abs(eg - eo) < 1e-3 * eo
+        assert abs(so - 1.0) < 0.02
+    # trajectory surface of the reference (dslam.txt): identical text up to the 6 significant digits written
+    lo, lg = write_dslam(traj_o).splitlines(), write_dslam(traj_g).splitlines()
+    diff = sum(a != b for a, b in zip(lo, lg))
+    assert diff <= len(lo) // 4  # last-digit flips only
+    for a, b in zip(lo, lg):
+        np.testing.assert_allclose([float(x) for x in a.split()[1:]], [float(x) for x in b.split()[1:]], atol=5e-4)
+
+
+def test_replay_loop_closure_candidates_bit_exact(ctx):
+    """ring keys of a 260-keyframe loop (revisiting the start) through search_ringkey: the GPU database
+    returns exactly the oracle's candidate lists, and the revisits are detected"""
+    from direct_stereo_slam_amd.ringdb import RingKeyDB, scancontext_generate
+
+    rng = np.random.default_rng(11)
+    base = [np.vstack([np.stack([rng.uniform(-35, 35, 1500), rng.uniform(-30, 30, 1500), rng.normal(0, 0.05, 1500)], 1),
+                       np.stack([rng.uniform(-35, 35, 500), np.full(500, rng.uniform(5, 12)), rng.uniform(0, rng.uniform(2, 9), 500)], 1)])
+            for _ in range(130)]
+    clouds = base + [c + rng.normal(0, 0.02, c.shape) for c in base]  # second lap: same places, small noise
+    dummy = np.full(20, 0.5, np.float32)
+    orc, db = O.OracleRingDB(dummy=dummy), RingKeyDB(ctx, dummy=dummy)
+    hits = 0
+    for i, c in enumerate(clouds):
+        rk = scancontext_generate(c, 40.0)[0]
+        co, cg = orc.query_then_enqueue(rk), db.search_ringkey(rk)
+        assert cg == co
+        if i >= 130 and (i - 130) in cg:
+            hits += 1
+    assert hits > 100  # the second lap recognises the first
