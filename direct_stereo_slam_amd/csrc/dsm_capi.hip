@@ -440,6 +440,7 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
     if (l > 0) launch_pyr_down(ctx->stream, t->w >> (l - 1), wl, hl, t->d_img[slot][l - 1], t->d_img[slot][l], layout);
     launch_pyr_grad(ctx->stream, wl, hl, t->d_img[slot][l], layout);
   }
+  DSM_HIP(hipGetLastError());
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   t->desc.exposure[slot] = ab_exposure;
   t->have_frame[slot] = true;
@@ -573,6 +574,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       }
       ctx->stats.launches[L] += steps;
     }
+    DSM_HIP(hipGetLastError()); // launch-configuration errors of the kernels enqueued above
     DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
     DSM_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stats.polls++;
@@ -710,10 +712,11 @@ static int single_eval(dsm_tracker *t, int mode, int lvl, const double *pose, co
   DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo), hipMemcpyHostToDevice, ctx->stream));
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_PREP, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, nullptr);
-  launch_eval(ctx->stream, mode, t->desc.layout, lvl, round8(num_chunks(t->desc.lv[lvl].n)), 1, ctx->d_tracker_ptrs,
+  launch_eval(ctx->stream, mode, t->desc.layout, lvl, round8(num_chunks(t->desc.lv[lvl].n) > 0 ? num_chunks(t->desc.lv[lvl].n) : 1), 1, ctx->d_tracker_ptrs,
               ctx->d_states, ctx->d_partials, ctx->partial_stride);
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_FINISH, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, nullptr, ctx->d_single, nullptr);
+  DSM_HIP(hipGetLastError());
   DSM_HIP(hipMemcpyAsync(ctx->h_single, ctx->d_single, sizeof(SingleOut), hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   *out = ctx->h_single[0];
