@@ -80,6 +80,9 @@ SYMBOLS = {
     "dsm_optimize_scale_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_float_p, C.c_int, c_float_p]),
     "dsm_tracker_ref_frame_id": (C.c_int, [_vp]),
     "dsm_reduction_geometry": (C.c_int, [_vp, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "dsm_pose_estimator_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(_vp)]),
+    "dsm_pose_estimator_destroy": (C.c_int, [_vp]),
+    "dsm_pose_estimator_estimate": (C.c_int, [_vp, C.c_int, c_double_p, _pp_f, C.c_float, _pp_f, C.c_float, c_float_p, C.c_int, c_double_p, c_float_p, c_int_p]),
     "dsm_ringdb_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, c_float_p, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "dsm_ringdb_destroy": (C.c_int, [_vp]),
     "dsm_ringdb_size": (C.c_int64, [_vp]),

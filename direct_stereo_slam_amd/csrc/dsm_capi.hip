@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <vector>
 
 #include "dsm_internal.hpp"
 
@@ -271,6 +272,7 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
     D.lv[l].w = wl;
     D.lv[l].h = hl;
     DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)wl * hl));
+    t->pts_cap[l] = wl * hl;
     for (int s = 0; s < 2; s++) {
       DSM_HIP(hipMalloc(&t->d_img[s][l], sizeof(float) * ts * (size_t)wl * hl));
       DSM_HIP(hipMemsetAsync(t->d_img[s][l], 0, sizeof(float) * ts * (size_t)wl * hl, ctx->stream));
@@ -340,7 +342,7 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
   for (int l = 0; l < t->nlevels; l++)
-    if (n[l] < 0 || n[l] > (t->w >> l) * (t->h >> l)) return invalid("dsm_tracker_set_ref: n[lvl] out of range");
+    if (n[l] < 0 || n[l] > t->pts_cap[l]) return invalid("dsm_tracker_set_ref: n[lvl] out of range");
   int rc = ensure_stage(ctx, 4 * (size_t)t->w * t->h);
   if (rc) return rc;
   for (int l = 0; l < t->nlevels; l++) {
@@ -478,7 +480,7 @@ int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pt
 
 // ---- common batch plumbing ------------------------------------------------------------------
 static int check_ready(dsm_tracker *t, int mode) {
-  if (!t->have_k || !t->have_ref || !t->have_frame[mode]) {
+  if (!t->have_k || !t->have_ref || !t->have_frame[mode == 1 ? 1 : 0]) {
     set_error(mode ? "optimize_scale needs make_k, set_ref and the right frame (slot 1)"
                    : "track needs make_k, set_ref and the new left frame (slot 0)");
     return DSM_ERR_STATE;
@@ -497,7 +499,7 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
       return invalid("batch: all trackers must share image size, levels and layout");
     int rc = check_ready(t, mode);
     if (rc) return rc;
-    const int need = num_chunks(t->w * t->h) * kPartialStride;
+    const int need = max_chunks_upto(t->w * t->h) * kPartialStride;
     if (need > ps) ps = need;
   }
   int rc = ensure_batch_capacity(ctx, n, ps);
@@ -691,6 +693,104 @@ int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl
   if (!t) return invalid("null tracker");
   dsm_tracker *ts[1] = {t};
   return dsm_optimize_scale_batch(t->ctx, 1, ts, scale_io, coarsest_lvl, err_out);
+}
+
+// ---- loop-closure pose estimation (row N2): PoseEstimator::estimate, PoseEstimator.cpp:298-506 ----
+} // extern "C"
+
+struct dsm_pose_estimator {
+  dsm_tracker *t = nullptr;
+  std::vector<float> x, y, z;
+};
+
+extern "C" {
+
+int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const dsm_params *params,
+                              dsm_pose_estimator **out) {
+  if (!out) return invalid("dsm_pose_estimator_create: out is NULL");
+  const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float k1[4] = {1, 1, 0, 0};
+  dsm_tracker *t = nullptr;
+  int rc = dsm_tracker_create(ctx, w, h, nlevels, I4, k1, params, &t);
+  if (rc) return rc;
+  // the loop-closure point set is the same on every level: give every level the level-0 capacity
+  for (int l = 1; l < nlevels; l++) {
+    DSM_HIP(hipFree(t->d_pts[l]));
+    t->d_pts[l] = nullptr;
+    DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)w * h));
+    t->pts_cap[l] = w * h;
+    t->desc.lv[l].pts = t->d_pts[l];
+  }
+  t->desc_dirty = true;
+  dsm_pose_estimator *pe = new dsm_pose_estimator();
+  pe->t = t;
+  *out = pe;
+  return DSM_OK;
+}
+
+int dsm_pose_estimator_destroy(dsm_pose_estimator *pe) {
+  if (!pe) return DSM_OK;
+  dsm_tracker_destroy(pe->t);
+  delete pe;
+  return DSM_OK;
+}
+
+int dsm_pose_estimator_estimate(dsm_pose_estimator *pe, int n_pts, const double *xyz, const float *const *ref_colors,
+                                float ref_ab_exposure, const float *const *new_dIp, float new_ab_exposure,
+                                const float new_cam[4], int coarsest_lvl, double ref_to_new_io[16], float *pose_error,
+                                int *ok) {
+  if (!pe || n_pts < 1 || !xyz || !ref_colors || !new_dIp || !new_cam || !ref_to_new_io)
+    return invalid("dsm_pose_estimator_estimate: bad argument");
+  dsm_tracker *t = pe->t;
+  if (n_pts > t->w * t->h) return invalid("dsm_pose_estimator_estimate: more points than pixels");
+  int rc = dsm_tracker_make_k(t, new_cam[0], new_cam[1], new_cam[2], new_cam[3]); // makeK(new_cam), :306
+  if (rc) return rc;
+  pe->x.resize(n_pts), pe->y.resize(n_pts), pe->z.resize(n_pts);
+  for (int i = 0; i < n_pts; i++) { // `float x = pts_[i].first(0)` ..., PoseEstimator.cpp:183-185
+    pe->x[i] = (float)xyz[3 * i];
+    pe->y[i] = (float)xyz[3 * i + 1];
+    pe->z[i] = (float)xyz[3 * i + 2];
+  }
+  int n[DSM_MAX_LEVELS];
+  const float *px[DSM_MAX_LEVELS], *py[DSM_MAX_LEVELS], *pz[DSM_MAX_LEVELS];
+  for (int l = 0; l < t->nlevels; l++) {
+    n[l] = n_pts; // the same point set on every level, one reference colour per level (:238)
+    px[l] = pe->x.data(), py[l] = pe->y.data(), pz[l] = pe->z.data();
+  }
+  // the float4 template slot holds (x, y, z, refColor[lvl]); ref_aff_g2l_ = (0,0) (:317)
+  rc = dsm_tracker_set_ref(t, 0, 0.0, 0.0, ref_ab_exposure, n, px, py, pz, ref_colors);
+  if (rc) return rc;
+  rc = dsm_tracker_upload_frame(t, DSM_SLOT_NEW_LEFT, new_dIp, new_ab_exposure);
+  if (rc) return rc;
+  dsm_context *ctx = t->ctx;
+  dsm_tracker *ts[1] = {t};
+  rc = prepare_batch(ctx, 1, ts, 2);
+  if (rc) return rc;
+  StartInfo &I = ctx->h_start[0];
+  memset(&I, 0, sizeof I);
+  se3_from_matrix(ref_to_new_io, I.pose); // SE3(R, t) constructor, :321-322
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) I.min_res[l] = std::numeric_limits<double>::quiet_NaN();
+  I.scale = 1.0f;
+  I.coarsest = coarsest_lvl;
+  rc = run_lm_batch(ctx, 1, ts, 2, coarsest_lvl);
+  if (rc) return rc;
+  const LMState &S = ctx->h_states[0];
+  { // refToNew_current.matrix(), :466
+    const double x = S.cur[0], y = S.cur[1], z = S.cur[2], w = S.cur[3];
+    double *M = ref_to_new_io;
+    M[0] = 1 - 2 * (y * y + z * z), M[1] = 2 * (x * y - z * w), M[2] = 2 * (x * z + y * w), M[3] = S.cur[4];
+    M[4] = 2 * (x * y + z * w), M[5] = 1 - 2 * (x * x + z * z), M[6] = 2 * (y * z - x * w), M[7] = S.cur[5];
+    M[8] = 2 * (x * z - y * w), M[9] = 2 * (y * z + x * w), M[10] = 1 - 2 * (x * x + y * y), M[11] = S.cur[6];
+    M[12] = M[13] = M[14] = 0, M[15] = 1;
+  }
+  const float err = (float)S.last_residuals[0]; // :467
+  if (pose_error) *pose_error = err;
+  const bool aff_good = S.status == ST_GOOD;                                        // :469-482
+  const bool low_res = err < 10.0f;                                                 // RES_THRES, PoseEstimator.h:26
+  const int inlier_percent = 100 * float((int)S.last_inners[0]) / (float)n_pts;     // :486
+  const bool enough_inlier = inlier_percent > 90;                                   // INNER_PERCENT, PoseEstimator.h:27
+  if (ok) *ok = (aff_good && low_res && enough_inlier) ? 1 : 0;                     // :505
+  return DSM_OK;
 }
 
 // single fused evaluation

@@ -81,7 +81,7 @@ enum LMStatus { ST_IDLE = 0, ST_RUNNING = 1, ST_GOOD = 2, ST_ABORTED = 3, ST_BAD
 // optimizeScale :854-964), resident in device memory for the whole call.
 struct LMState {
   int status, lvl, phase, iteration;
-  int have_repeated, coarsest, is_scale, pad0;
+  int have_repeated, coarsest, is_scale /* problem kind: 0 pose, 1 scale, 2 loop-closure pose (3-D points) */, pad0;
   float lambda, level_cutoff_repeat;
   float inc_f;      // scale: last increment (for the signed break test :937)
   float scale_cur, scale_cand;
@@ -93,6 +93,7 @@ struct LMState {
   double H[64], b[8];
   double res_old[6];
   double last_residuals[DSM_MAX_LEVELS];
+  double last_inners[DSM_MAX_LEVELS]; // numTermsInE at the end of each level (PoseEstimator.cpp:463)
   double min_res[DSM_MAX_LEVELS];
   double flow[3];
   long long evals[DSM_MAX_LEVELS];

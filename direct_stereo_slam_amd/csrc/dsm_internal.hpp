@@ -39,8 +39,8 @@ struct dsm_context {
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;
-  // speculative launch schedule per mode (0 = track, 1 = scale) and level, adapted after every call
-  int sched[2][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}};
+  // speculative launch schedule per mode (0 = track, 1 = scale, 2 = loop-closure pose) and level, adapted after every call
+  int sched[3][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}, {6, 8, 10, 12, 16, 16}};
   // stats / timing
   bool timing = false;
   dsm_stats stats{};
@@ -55,6 +55,7 @@ struct dsm_tracker {
   dsm::TrackerDev desc{}; // host copy of the device descriptor
   dsm::TrackerDev *d_desc = nullptr;
   float4 *d_pts[DSM_MAX_LEVELS] = {};
+  int pts_cap[DSM_MAX_LEVELS] = {}; // template capacity per level (w_l*h_l; w*h on every level for the pose estimator)
   float *d_img[2][DSM_MAX_LEVELS] = {};
   bool have_k = false, have_ref = false, have_frame[2] = {false, false};
   int ref_frame_id = -1;

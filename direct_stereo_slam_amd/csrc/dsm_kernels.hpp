@@ -17,6 +17,15 @@ __host__ __device__ inline int num_chunks(int n) {
   return (n + per - 1) / per;
 }
 
+// largest chunk count any n <= cap can produce (P grows with n, so num_chunks is not monotone)
+inline int max_chunks_upto(int cap) {
+  int best = num_chunks(cap);
+  const int edges[4] = {256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1};
+  for (int e : edges)
+    if (e <= cap && num_chunks(e) > best) best = num_chunks(e);
+  return best;
+}
+
 enum LMOp {
   LM_OP_STEP = 0,          // consume the evaluation of level `lvl`, advance the LM state machine
   LM_OP_START = 1,         // initialise the state machine at the coarsest level

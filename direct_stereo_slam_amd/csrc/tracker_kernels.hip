@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
               S6 = sc * M6, S7 = sc * M7, S8 = sc * M8;
   const float aff0 = in.aff0, aff1 = in.aff1, b0 = in.b0;
 
-  constexpr int NACC = MODE == 0 ? kNumAcc : 3;
+  constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
   float acc[NACC];
   float E = 0.f;
   int n_terms = 0, n_sat = 0, n_warped = 0;
@@ -174,6 +174,10 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
       pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
       pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
+    } else if (MODE == 2) { // PoseEstimator.cpp:192: pt = R (x,y,z) + t ; the float4 is (x, y, z, refColor[lvl])
+      pt0 = ((M0 * x + M1 * y) + M2 * id) + t0;
+      pt1 = ((M3 * x + M4 * y) + M5 * id) + t1;
+      pt2 = ((M6 * x + M7 * y) + M8 * id) + t2;
     } else { // :1061
       pt0 = ((S0 * x + S1 * y) + S2) + t0 * id;
       pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
@@ -187,12 +191,12 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     // that holds a lane outside that range takes the full IEEE divisions instead.
     {
       const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
-      const bool ordinary = (unsigned)(ex + 32) <= 64u && (__builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
+      const bool ordinary = (unsigned)(ex + 32) <= 64u && (MODE == 2 || __builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
                             __builtin_fabsf(pt2) >= 0x1p-34f;
       if (__builtin_expect(__ballot(!ordinary) != 0ull, 0)) {
         W.u = pt0 / pt2;
         W.v = pt1 / pt2;
-        W.new_idepth = id / pt2;
+        W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2; // PoseEstimator.cpp:197: 1 / pt[2]
       } else {
         const float r0 = __builtin_amdgcn_rcpf(pt2);
         const float r1 = __builtin_fmaf(__builtin_fmaf(-pt2, r0, 1.0f), r0, r0);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
         };
         W.u = quot(pt0);
         W.v = quot(pt1);
-        W.new_idepth = id * r1;
+        W.new_idepth = MODE == 2 ? r1 : id * r1;
       }
     }
     const float Ku = fxl * W.u + cxl;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     taps_interp(T, h0, h1, h2);
     const float refColor = W.refColor;
     const bool fin = W.inb && __builtin_isfinite(h0); // :791
-    const float residual = MODE == 0 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
+    const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
     const float ar = __builtin_fabsf(residual);
     // Huber weight (:794-795).  It scales E and the normal equations only (no decision depends
     // on it), so the hardware reciprocal (1 ulp) replaces the IEEE division.
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     n_sat += __builtin_popcountll(__ballot(fin && sat));
     n_warped += __builtin_popcountll(__ballot(use));
     const float wgt = use ? hw : 0.0f;
-    if (MODE == 0) {
+    if (MODE != 1) {
       // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
       // lanes get all-zero inputs so that they add exact zeros
       const unsigned m = use ? 0xFFFFFFFFu : 0u;
@@ -334,35 +338,54 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
       const fvec4 p = pts[i];
       const float x = p.x, y = p.y, id = p.z;
       const DSM_GLOBAL float *Ki = in.Ki;
-      float kx0, kx1, kx2, rx0, rx1, rx2;
-      if (MODE == 0) {
-        kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
-        kx1 = (Ki[3] * x + Ki[4] * y) + Ki[5];
-        kx2 = (Ki[6] * x + Ki[7] * y) + Ki[8];
-        rx0 = (M0 * x + M1 * y) + M2;
-        rx1 = (M3 * x + M4 * y) + M5;
-        rx2 = (M6 * x + M7 * y) + M8;
+      if (MODE == 2) {
+        // PoseEstimator.cpp:185-229, as written: shifts are measured against the reference
+        // projection (Ku0,Kv0) and the "translation only" points use (x, y, 1)
+        const float z = id;
+        const float Ku0 = fxl * (x / z) + cxl, Kv0 = fyl * (y / z) + cyl;
+        const float ptz = ((M6 * x + M7 * y) + M8 * z) + t2;
+        const float Ku = fxl * ((((M0 * x + M1 * y) + M2 * z) + t0) / ptz) + cxl;
+        const float Kv = fyl * ((((M3 * x + M4 * y) + M5 * z) + t1) / ptz) + cyl;
+        const float KuT = fxl * ((x + t0) / (1.0f + t2)) + cxl, KvT = fyl * ((y + t1) / (1.0f + t2)) + cyl;
+        const float KuT2 = fxl * ((x - t0) / (1.0f - t2)) + cxl, KvT2 = fyl * ((y - t1) / (1.0f - t2)) + cyl;
+        const float p3z = ((M6 * x + M7 * y) + M8) - t2;
+        const float Ku3 = fxl * ((((M0 * x + M1 * y) + M2) - t0) / p3z) + cxl;
+        const float Kv3 = fyl * ((((M3 * x + M4 * y) + M5) - t1) / p3z) + cyl;
+        fT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
+        fT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
+        fRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
+        fRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
       } else {
-        kx0 = ((sc * Ki[0]) * x + (sc * Ki[1]) * y) + (sc * Ki[2]);
-        kx1 = ((sc * Ki[3]) * x + (sc * Ki[4]) * y) + (sc * Ki[5]);
-        kx2 = ((sc * Ki[6]) * x + (sc * Ki[7]) * y) + (sc * Ki[8]);
-        rx0 = (S0 * x + S1 * y) + S2;
-        rx1 = (S3 * x + S4 * y) + S5;
-        rx2 = (S6 * x + S7 * y) + S8;
+        float kx0, kx1, kx2, rx0, rx1, rx2;
+        if (MODE == 0) {
+          kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
+          kx1 = (Ki[3] * x + Ki[4] * y) + Ki[5];
+          kx2 = (Ki[6] * x + Ki[7] * y) + Ki[8];
+          rx0 = (M0 * x + M1 * y) + M2;
+          rx1 = (M3 * x + M4 * y) + M5;
+          rx2 = (M6 * x + M7 * y) + M8;
+        } else {
+          kx0 = ((sc * Ki[0]) * x + (sc * Ki[1]) * y) + (sc * Ki[2]);
+          kx1 = ((sc * Ki[3]) * x + (sc * Ki[4]) * y) + (sc * Ki[5]);
+          kx2 = ((sc * Ki[6]) * x + (sc * Ki[7]) * y) + (sc * Ki[8]);
+          rx0 = (S0 * x + S1 * y) + S2;
+          rx1 = (S3 * x + S4 * y) + S5;
+          rx2 = (S6 * x + S7 * y) + S8;
+        }
+        const float a0 = t0 * id, a1 = t1 * id, a2 = t2 * id;
+        const float ptz = rx2 + a2;
+        const float Ku = fxl * ((rx0 + a0) / ptz) + cxl, Kv = fyl * ((rx1 + a1) / ptz) + cyl;
+        const float pTz = kx2 + a2;
+        const float KuT = fxl * ((kx0 + a0) / pTz) + cxl, KvT = fyl * ((kx1 + a1) / pTz) + cyl;
+        const float pT2z = kx2 - a2;
+        const float KuT2 = fxl * ((kx0 - a0) / pT2z) + cxl, KvT2 = fyl * ((kx1 - a1) / pT2z) + cyl;
+        const float p3z = rx2 - a2;
+        const float Ku3 = fxl * ((rx0 - a0) / p3z) + cxl, Kv3 = fyl * ((rx1 - a1) / p3z) + cyl;
+        fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+        fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+        fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+        fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
       }
-      const float a0 = t0 * id, a1 = t1 * id, a2 = t2 * id;
-      const float ptz = rx2 + a2;
-      const float Ku = fxl * ((rx0 + a0) / ptz) + cxl, Kv = fyl * ((rx1 + a1) / ptz) + cyl;
-      const float pTz = kx2 + a2;
-      const float KuT = fxl * ((kx0 + a0) / pTz) + cxl, KvT = fyl * ((kx1 + a1) / pTz) + cyl;
-      const float pT2z = kx2 - a2;
-      const float KuT2 = fxl * ((kx0 - a0) / pT2z) + cxl, KvT2 = fyl * ((kx1 - a1) / pT2z) + cyl;
-      const float p3z = rx2 - a2;
-      const float Ku3 = fxl * ((rx0 - a0) / p3z) + cxl, Kv3 = fyl * ((rx1 - a1) / p3z) + cyl;
-      fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-      fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-      fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-      fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
       fNum += 2;
     }
   }
@@ -428,6 +451,11 @@ void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int n
       launch_eval_ml<0, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
     else
       launch_eval_ml<0, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
+  } else if (mode == 2) {
+    if (layout == IMG_AOS3)
+      launch_eval_ml<2, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
+    else
+      launch_eval_ml<2, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
   } else {
     if (layout == IMG_AOS3)
       launch_eval_ml<1, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
@@ -527,6 +555,51 @@ __device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float 
   S.in.max_energy = 2 * h * cutoff - h * h; // :1030-1032
 }
 
+// loop-closure pose (PoseEstimator::calcRes, PoseEstimator.cpp:155-163): M = R (no K^-1), reference
+// affine parameters (0,0) (:317), exposure handed over by the caller
+__device__ void make_eval_points3d(const TrackerDev &T, LMState &S, int lvl, const double pose[7], const double aff[2],
+                                   float cutoff) {
+  double Rd[9];
+  quat_to_rot(pose, Rd);
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.M[i] = (float)Rd[i];
+  S.in.t[0] = (float)pose[4];
+  S.in.t[1] = (float)pose[5];
+  S.in.t[2] = (float)pose[6];
+  double affd[2];
+  aff_from_to(T.ref_exposure, T.exposure[0], 0.0, 0.0, aff[0], aff[1], affd);
+  S.in.aff0 = (float)affd[0];
+  S.in.aff1 = (float)affd[1];
+  S.in.b0 = 0.0f; // ref_aff_g2l_.b (:90)
+  S.in.scale = 1.0f;
+  S.in.cutoff = cutoff;
+  const float h = T.p.huber_th;
+  S.in.max_energy = 2 * h * cutoff - h * h;
+  const LevelDev &L = T.lv[lvl];
+#pragma unroll
+  for (int i = 0; i < 9; i++) S.in.Ki[i] = L.Ki[i];
+  S.in.pts = L.pts;
+  S.in.img = L.img[0];
+  S.in.n = L.n;
+  S.in.w = L.w;
+  S.in.h = L.h;
+  S.in.fx = L.fx;
+  S.in.fy = L.fy;
+  S.in.cx = L.cx;
+  S.in.cy = L.cy;
+  S.in.huber = T.p.huber_th;
+}
+
+__device__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
+                              float scale, float cutoff) {
+  if (mode == 1)
+    make_eval_scale(T, S, lvl, scale, cutoff);
+  else if (mode == 2)
+    make_eval_points3d(T, S, lvl, pose, aff, cutoff);
+  else
+    make_eval_pose(T, S, lvl, pose, aff, cutoff);
+}
+
 // lane 0 only
 __device__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
   S.lvl = lvl;
@@ -534,10 +607,7 @@ __device__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
   S.iteration = 0;
   S.level_cutoff_repeat = 1.0f;
   const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-  if (S.is_scale)
-    make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
-  else
-    make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
+  make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
 }
 
 // Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
@@ -728,7 +798,7 @@ __device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double b
   for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
   S.inc_norm = sqrt(nrm);
   S.phase = PH_ITER;
-  make_eval_pose(T, S, S.lvl, cand, aff_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
 }
 
 // lane 0 only: :897-913
@@ -751,7 +821,8 @@ __device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
 __device__ void end_level(const TrackerDev &T, LMState &S) {
   const int lvl = S.lvl;
   S.last_residuals[lvl] = sqrtf((float)(S.res_old[0] / S.res_old[1])); // :596 / :945
-  if (!S.is_scale) {
+  S.last_inners[lvl] = S.res_old[1];                                     // PoseEstimator.cpp:463
+  if (S.is_scale == 0) {
     S.flow[0] = S.res_old[2]; // :597
     S.flow[1] = S.res_old[3];
     S.flow[2] = S.res_old[4];
@@ -766,10 +837,10 @@ __device__ void end_level(const TrackerDev &T, LMState &S) {
     S.have_repeated = 1;
   }
   if (next < 0) {
-    if (S.is_scale)
+    if (S.is_scale == 1)
       S.status = ST_GOOD;
     else
-      finish_track(T, S);
+      finish_track(T, S); // the same affine plausibility checks end PoseEstimator::estimate (:470-482)
     return;
   }
   begin_level(T, S, next);
@@ -783,6 +854,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
                                                         SingleOut *__restrict__ single_out,
                                                         int *__restrict__ status_out) {
   const int prob = blockIdx.x;
+  const bool pose_like = mode != 1; // 0: frame tracking, 2: loop-closure pose -- same 8-DoF LM; 1: stereo scale
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const TrackerDev &T = *trackers[prob];
@@ -826,10 +898,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       S.is_scale = mode;
       S.status = ST_RUNNING;
       S.lvl = I.lvl;
-      if (mode)
-        make_eval_scale(T, S, I.lvl, I.scale, I.cutoff);
-      else
-        make_eval_pose(T, S, I.lvl, I.pose, I.aff, I.cutoff);
+      make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff);
     }
     return;
   }
@@ -904,14 +973,14 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
 
   if (op == LM_OP_SINGLE_FINISH) {
     SingleOut &O = single_out[prob];
-    if (mode == 0) {
+    if (pose_like) {
       O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
       if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
     }
     if (lane == 0) {
       for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
       O.n_warped = n4;
-      if (mode == 0) {
+      if (pose_like) {
         O.Hs = O.bs = 0;
       } else {
         O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
@@ -935,13 +1004,10 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
         S.evals[lvl]++;
         S.level_cutoff_repeat *= 2;
         const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-        if (mode)
-          make_eval_scale(T, S, lvl, S.scale_cur, cutoff);
-        else
-          make_eval_pose(T, S, lvl, S.cur, S.aff_cur, cutoff);
+        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
       }
     } else {
-      if (mode == 0) {
+      if (pose_like) {
         h = build_H_elem(T.p, sums, n4, r, c); // :487
         bneg = -build_b_elem(T.p, sums, n4, r);
         S.H[lane] = h;
@@ -950,7 +1016,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       if (lane == 0) {
         S.evals[lvl]++;
         for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
-        if (mode) {
+        if (!pose_like) {
           S.Hs = (float)sums[0] * (1.0f / n4); // :885
           S.bs = (float)sums[1] * (1.0f / n4);
         }
@@ -964,7 +1030,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     }
   } else {
     const bool accept = (rs[0] / rs[1]) < (S.res_old[0] / S.res_old[1]); // :559 / :915
-    const bool small = mode == 0 ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
+    const bool small = pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
     const int iteration = S.iteration + 1;
     {
       const float l_old = S.lambda;
@@ -972,7 +1038,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       if (l4 < lim) l4 = lim;
       lambda_next = accept ? l_old * 0.5f : l4; // :581 / :583-585
     }
-    if (mode == 0) {
+    if (pose_like) {
       if (accept) { // :576-577
         h = build_H_elem(T.p, sums, n4, r, c);
         bneg = -build_b_elem(T.p, sums, n4, r);
@@ -987,7 +1053,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       S.evals[lvl]++;
       if (accept) { // :576-581 / :926-930
         for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
-        if (mode == 0) {
+        if (pose_like) {
           for (int i = 0; i < 7; i++) S.cur[i] = S.cand[i];
           S.aff_cur[0] = S.aff_cand[0];
           S.aff_cur[1] = S.aff_cand[1];
@@ -1010,7 +1076,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (do_propose) {
-    if (mode == 0)
+    if (pose_like)
       propose_pose(T, S, h, bneg, lambda_next, lane);
     else if (lane == 0)
       propose_scale(T, S, lambda_next);

@@ -205,3 +205,35 @@ def make_coarse_depth_l0(w, h, nlevels, pu, pv, pidepth, pweight, ref_dIp):
     check(L.dsm_make_coarse_depth_l0(w, h, nlevels, len(pu), _fp(pu), _fp(pv), _fp(pidepth), _fp(pweight), _ptr_array(ref),
                                      n_out, *[_ptr_array(o) for o in outs]))
     return [[o[l][: n_out[l]].copy() for l in range(nlevels)] for o in outs]
+
+
+class PoseEstimator:
+    """Python mirror of the reference's `dso::PoseEstimator` (PoseEstimator.h:34-83) on the C ABI."""
+
+    def __init__(self, ctx, w, h, nlevels, params=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.params = params if params is not None else default_params()
+        hnd = C.c_void_p()
+        check(self.L.dsm_pose_estimator_create(ctx.h, w, h, nlevels, C.byref(self.params), C.byref(hnd)))
+        self.h = hnd
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.L.dsm_pose_estimator_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def estimate(self, pts_xyz, ref_colors, ref_ab_exposure, new_dIp, new_ab_exposure, new_cam, coarsest_lvl, ref_to_new):
+        """returns (ok, ref_to_new 4x4, pose_error) like `bool estimate(pts, ref_ab_exposure, new_fh, new_cam,
+        coarsest_lvl, Matrix4d& ref_to_new, float& pose_error)`"""
+        xyz = np.ascontiguousarray(pts_xyz, np.float64).reshape(-1, 3)
+        cols = [np.ascontiguousarray(c, np.float32) for c in ref_colors]
+        dIp = [np.ascontiguousarray(a, np.float32) for a in new_dIp]
+        cam = np.ascontiguousarray(new_cam, np.float32)
+        T = np.ascontiguousarray(ref_to_new, np.float64).reshape(16).copy()
+        err, ok = C.c_float(), C.c_int()
+        check(self.L.dsm_pose_estimator_estimate(self.h, len(xyz), _dp(xyz), _ptr_array(cols), ref_ab_exposure, _ptr_array(dIp),
+                                                 new_ab_exposure, _fp(cam), coarsest_lvl, _dp(T), C.byref(err), C.byref(ok)))
+        return bool(ok.value), T.reshape(4, 4), err.value

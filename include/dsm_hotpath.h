@@ -48,6 +48,7 @@ typedef enum dsm_status {
 typedef struct dsm_context dsm_context; /* device + stream + workspaces */
 typedef struct dsm_tracker dsm_tracker; /* one TrackerAndScaler instance */
 typedef struct dsm_ringdb dsm_ringdb;   /* ring-key database + delay queue */
+typedef struct dsm_pose_estimator dsm_pose_estimator; /* loop-closure direct alignment (PoseEstimator) */
 
 /* Runtime parameters.  These are DSO globals / literals in the reference; the values
  * written by dsm_params_default() are the upstream DSO defaults as used by the
@@ -163,6 +164,22 @@ int dsm_tracker_ref_frame_id(dsm_tracker *t);
  * threads per workgroup, points per thread, number of chunks. */
 int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pts_per_thread,
                            int *chunks);
+
+/* ---- loop-closure pose estimation ("next" row N2) ------------------------------------- */
+/* replaces PoseEstimator::PoseEstimator(w,h) / ~PoseEstimator (PoseEstimator.cpp:41-60) */
+int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const dsm_params *params,
+                              dsm_pose_estimator **out);
+int dsm_pose_estimator_destroy(dsm_pose_estimator *pe);
+/* replaces PoseEstimator::estimate (PoseEstimator.h:42, PoseEstimator.cpp:298-506): direct alignment of a
+ * matched keyframe's 3-D points (xyz: n x 3 doubles in the matched frame, ref_colors[lvl][i] = the
+ * per-level reference intensities of LoopFrame::pts_dso, LoopHandler.cpp:172-180) into the current
+ * keyframe's pyramid new_dIp with intrinsics new_cam = {fx,fy,cx,cy}.  ref_to_new_io: row-major 4x4,
+ * initial guess in, result out (always written, as at :466).  *ok = aff_good && pose_error < RES_THRES(10)
+ * && inlier_percent > INNER_PERCENT(90)  (:469-505). */
+int dsm_pose_estimator_estimate(dsm_pose_estimator *pe, int n_pts, const double *xyz,
+                                const float *const *ref_colors, float ref_ab_exposure,
+                                const float *const *new_dIp, float new_ab_exposure, const float new_cam[4],
+                                int coarsest_lvl, double ref_to_new_io[16], float *pose_error, int *ok);
 
 /* ---- ring-key database (ScanContext place recognition) ------------------------------- */
 /* replaces the flann::Index built at LoopHandler.cpp:35-39 plus the function-static delay

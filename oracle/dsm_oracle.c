@@ -1272,3 +1272,308 @@ void orc_search_sc(const int *sig_idx, const double *sig_val, int n_sig, int n_c
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* PoseEstimator ("next" row N2): src/loop_closure/pose_estimation/PoseEstimator.cpp     */
+/* ------------------------------------------------------------------------------------ */
+struct orc_pose_estimator {
+  orc_params p;
+  int nlevels, w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+  float fx[ORC_MAX_LEVELS], fy[ORC_MAX_LEVELS], cx[ORC_MAX_LEVELS], cy[ORC_MAX_LEVELS];
+  int n;
+  const double *xyz;            /* pts_[i].first */
+  const float *const *colors;   /* pts_[i].second[lvl] as colors[lvl][i] */
+  const float *const *dIp;      /* new_frame_->dIp */
+  float ref_exposure, new_exposure;
+  float *B[8];
+  int bn;
+};
+
+orc_pose_estimator *orc_pe_create(int w, int h, int nlevels, const orc_params *p) {
+  orc_pose_estimator *e = (orc_pose_estimator *)xcalloc(1, sizeof *e);
+  e->p = *p;
+  e->nlevels = nlevels;
+  for (int l = 0; l < nlevels; l++) {
+    e->w[l] = w >> l;
+    e->h[l] = h >> l;
+  }
+  for (int i = 0; i < 8; i++) e->B[i] = (float *)xcalloc((size_t)w * h + 4, 4); /* :41-50 */
+  return e;
+}
+void orc_pe_destroy(orc_pose_estimator *e) {
+  if (!e) return;
+  for (int i = 0; i < 8; i++) free(e->B[i]);
+  free(e);
+}
+
+/* PoseEstimator::calcRes, :141-296 */
+static void pe_calc_res(orc_pose_estimator *e, int lvl, const double pose[7], const double aff[2], float cutoffTH,
+                        double rs[6]) {
+  float E = 0;
+  int numTermsInE = 0, numTermsInWarped = 0, numSaturated = 0;
+  const int wl = e->w[lvl], hl = e->h[lvl];
+  const float *dINewl = e->dIp[lvl];
+  const float fxl = e->fx[lvl], fyl = e->fy[lvl], cxl = e->cx[lvl], cyl = e->cy[lvl];
+  double Rd[9];
+  orc_quat_to_rot(pose, Rd);
+  float R[9];
+  for (int i = 0; i < 9; i++) R[i] = (float)Rd[i]; /* :155 */
+  const float t[3] = {(float)pose[4], (float)pose[5], (float)pose[6]};
+  double affd[2];
+  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd); /* :157-160, ref_aff_g2l_ = (0,0) */
+  const float affLL0 = (float)affd[0], affLL1 = (float)affd[1];
+  float sumSquaredShiftT = 0, sumSquaredShiftRT = 0, sumSquaredShiftNum = 0;
+  const float huberTH = e->p.huber_th;
+  const float maxEnergy = 2 * huberTH * cutoffTH - huberTH * huberTH;
+  float **B = e->B;
+  for (int i = 0; i < e->n; i++) {
+    const float x = e->xyz[3 * i], y = e->xyz[3 * i + 1], z = e->xyz[3 * i + 2]; /* :183-185 */
+    const float u0 = x / z, v0 = y / z;
+    const float Ku0 = fxl * u0 + cxl, Kv0 = fyl * v0 + cyl;
+    float pt[3];
+    for (int r = 0; r < 3; r++) pt[r] = ((R[r * 3] * x + R[r * 3 + 1] * y) + R[r * 3 + 2] * z) + t[r]; /* :192 */
+    const float u = pt[0] / pt[2], v = pt[1] / pt[2];
+    const float Ku = fxl * u + cxl, Kv = fyl * v + cyl;
+    const float new_idepth = 1 / pt[2];
+    if (lvl == 0 && i % 32 == 0) { /* :199-230 */
+      const float ptT[3] = {x + t[0], y + t[1], 1 + t[2]};
+      const float ptT2[3] = {x - t[0], y - t[1], 1 - t[2]};
+      float pt3[3];
+      for (int r = 0; r < 3; r++) pt3[r] = ((R[r * 3] * x + R[r * 3 + 1] * y) + R[r * 3 + 2]) - t[r];
+      const float KuT = fxl * (ptT[0] / ptT[2]) + cxl, KvT = fyl * (ptT[1] / ptT[2]) + cyl;
+      const float KuT2 = fxl * (ptT2[0] / ptT2[2]) + cxl, KvT2 = fyl * (ptT2[1] / ptT2[2]) + cyl;
+      const float Ku3 = fxl * (pt3[0] / pt3[2]) + cxl, Kv3 = fyl * (pt3[1] / pt3[2]) + cyl;
+      sumSquaredShiftT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
+      sumSquaredShiftT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
+      sumSquaredShiftRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
+      sumSquaredShiftRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
+      sumSquaredShiftNum += 2;
+    }
+    if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue; /* :235 */
+    const float refColor = e->colors[lvl][i];
+    float hit[3];
+    interp33(dINewl, Ku, Kv, wl, hit);
+    if (!isfinite(hit[0])) continue;
+    const float residual = hit[0] - (float)(affLL0 * refColor + affLL1);
+    const float hw = fabsf(residual) < huberTH ? 1 : huberTH / fabsf(residual);
+    if (fabsf(residual) > cutoffTH) {
+      E += maxEnergy;
+      numTermsInE++;
+      numSaturated++;
+    } else {
+      E += hw * residual * residual * (2 - hw);
+      numTermsInE++;
+      B[0][numTermsInWarped] = new_idepth;
+      B[1][numTermsInWarped] = u;
+      B[2][numTermsInWarped] = v;
+      B[3][numTermsInWarped] = hit[1];
+      B[4][numTermsInWarped] = hit[2];
+      B[5][numTermsInWarped] = residual;
+      B[6][numTermsInWarped] = hw;
+      B[7][numTermsInWarped] = refColor;
+      numTermsInWarped++;
+    }
+  }
+  while (numTermsInWarped % 4 != 0) {
+    for (int k = 0; k < 8; k++) B[k][numTermsInWarped] = 0;
+    numTermsInWarped++;
+  }
+  e->bn = numTermsInWarped;
+  rs[0] = E;
+  rs[1] = numTermsInE;
+  rs[2] = sumSquaredShiftT / (sumSquaredShiftNum + 0.1);
+  rs[3] = 0;
+  rs[4] = sumSquaredShiftRT / (sumSquaredShiftNum + 0.1);
+  rs[5] = numSaturated / (float)numTermsInE;
+}
+
+/* PoseEstimator::calcGSSSE, :84-139 (same arithmetic as calcGSSSEPose with b0 = 0) */
+static void pe_calc_gs(orc_pose_estimator *e, int lvl, const double aff[2], double H_out[64], double b_out[8]) {
+  static lane_acc acc;
+  acc_init(&acc, 45);
+  const float fxl = e->fx[lvl], fyl = e->fy[lvl];
+  const float b0 = 0.0f;
+  double affd[2];
+  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd);
+  const float a = (float)affd[0];
+  float **B = e->B;
+  const int n = e->bn;
+  for (int i = 0; i < n; i += 4) {
+    float J[9][4], w[4];
+    for (int k = 0; k < 4; k++) {
+      const float dx = B[3][i + k] * fxl, dy = B[4][i + k] * fyl;
+      const float u = B[1][i + k], v = B[2][i + k], id = B[0][i + k];
+      J[0][k] = id * dx;
+      J[1][k] = id * dy;
+      J[2][k] = 0.0f - id * (u * dx + v * dy);
+      J[3][k] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+      J[4][k] = (u * v) * dy + dx * (1.0f + u * u);
+      J[5][k] = u * dy - v * dx;
+      J[6][k] = a * (b0 - B[7][i + k]);
+      J[7][k] = -1.0f;
+      J[8][k] = B[5][i + k];
+      w[k] = B[6][i + k];
+    }
+    int idx = 0;
+    for (int r = 0; r < 9; r++) {
+      float Jw[4];
+      for (int k = 0; k < 4; k++) Jw[k] = J[r][k] * w[k];
+      for (int c = r; c < 9; c++) {
+        for (int k = 0; k < 4; k++) acc.d[idx][k] = acc.d[idx][k] + Jw[k] * J[c][k];
+        idx++;
+      }
+    }
+    acc.n1++;
+    acc_shift(&acc, 0);
+  }
+  acc_shift(&acc, 1);
+  float Hf[9][9];
+  int idx = 0;
+  for (int r = 0; r < 9; r++)
+    for (int c = r; c < 9; c++) {
+      const float d = acc_finish_entry(&acc, idx++);
+      Hf[r][c] = Hf[c][r] = d;
+    }
+  const float invn = 1.0f / n;
+  const double s[8] = {e->p.scale_xi_rot,   e->p.scale_xi_rot,   e->p.scale_xi_rot, e->p.scale_xi_trans,
+                       e->p.scale_xi_trans, e->p.scale_xi_trans, e->p.scale_a,      e->p.scale_b};
+  for (int r = 0; r < 8; r++) {
+    for (int c = 0; c < 8; c++) H_out[r * 8 + c] = (((double)Hf[r][c] * (double)invn) * s[c]) * s[r];
+    b_out[r] = ((double)Hf[r][8] * (double)invn) * s[r];
+  }
+}
+
+/* PoseEstimator::estimate, :298-506.  Returns the reference's bool. */
+int orc_pe_estimate(orc_pose_estimator *e, int n, const double *xyz, const float *const *colors, float ref_ab_exposure,
+                    const float *const *new_dIp, float new_ab_exposure, const float new_cam[4], int coarsest_lvl,
+                    double ref_to_new_io[16], float *pose_error, int *inlier_percent_out) {
+  const int *maxIterations = e->p.max_iterations;
+  const float lambdaExtrapolationLimit = e->p.lambda_extrapolation_limit;
+  const float cutoff0 = e->p.coarse_cutoff_th;
+  e->fx[0] = new_cam[0], e->fy[0] = new_cam[1], e->cx[0] = new_cam[2], e->cy[0] = new_cam[3]; /* makeK :62-82 */
+  for (int l = 1; l < e->nlevels; l++) {
+    e->fx[l] = e->fx[l - 1] * 0.5;
+    e->fy[l] = e->fy[l - 1] * 0.5;
+    e->cx[l] = (e->cx[0] + 0.5) / ((int)1 << l) - 0.5;
+    e->cy[l] = (e->cy[0] + 0.5) / ((int)1 << l) - 0.5;
+  }
+  e->n = n, e->xyz = xyz, e->colors = colors, e->dIp = new_dIp;
+  e->ref_exposure = ref_ab_exposure, e->new_exposure = new_ab_exposure;
+  int lastInners[ORC_MAX_LEVELS] = {0};
+  double lastResiduals[ORC_MAX_LEVELS];
+  for (int i = 0; i < ORC_MAX_LEVELS; i++) lastResiduals[i] = NAN;
+  double cur[7], aff_cur[2] = {0, 0};
+  orc_se3_from_matrix(ref_to_new_io, cur); /* :321-322 */
+  int haveRepeated = 0;
+  const float modeA = e->p.affine_opt_mode_a, modeB = e->p.affine_opt_mode_b;
+  const double sc[8] = {e->p.scale_xi_rot,   e->p.scale_xi_rot,   e->p.scale_xi_rot, e->p.scale_xi_trans,
+                        e->p.scale_xi_trans, e->p.scale_xi_trans, e->p.scale_a,      e->p.scale_b};
+  for (int lvl = coarsest_lvl; lvl >= 0; lvl--) {
+    double H[64], b[8], resOld[6];
+    float levelCutoffRepeat = 1;
+    pe_calc_res(e, lvl, cur, aff_cur, cutoff0 * levelCutoffRepeat, resOld);
+    while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+      levelCutoffRepeat *= 2;
+      pe_calc_res(e, lvl, cur, aff_cur, cutoff0 * levelCutoffRepeat, resOld);
+    }
+    pe_calc_gs(e, lvl, aff_cur, H, b);
+    float lambda = 0.01;
+    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+      double Hl[64], inc[8], nb[8];
+      memcpy(Hl, H, sizeof Hl);
+      for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda);
+      for (int i = 0; i < 8; i++) nb[i] = -b[i];
+      orc_ldlt_solve(8, Hl, nb, inc);
+      if (modeA < 0 && modeB < 0) {
+        double A6[36], x6[6];
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) A6[r * 6 + c] = Hl[r * 8 + c];
+        orc_ldlt_solve(6, A6, nb, x6);
+        for (int i = 0; i < 6; i++) inc[i] = x6[i];
+        inc[6] = inc[7] = 0;
+      }
+      if (!(modeA < 0) && modeB < 0) {
+        double A7[49], x7[7];
+        for (int r = 0; r < 7; r++)
+          for (int c = 0; c < 7; c++) A7[r * 7 + c] = Hl[r * 8 + c];
+        orc_ldlt_solve(7, A7, nb, x7);
+        for (int i = 0; i < 7; i++) inc[i] = x7[i];
+        inc[7] = 0;
+      }
+      if (modeA < 0 && !(modeB < 0)) {
+        double Hs[64], bs[8], A7[49], nbs[7], x7[7];
+        memcpy(Hs, Hl, sizeof Hs);
+        memcpy(bs, b, sizeof bs);
+        for (int r = 0; r < 8; r++) Hs[r * 8 + 6] = Hs[r * 8 + 7];
+        for (int c = 0; c < 8; c++) Hs[6 * 8 + c] = Hs[7 * 8 + c];
+        bs[6] = bs[7];
+        for (int r = 0; r < 7; r++) {
+          for (int c = 0; c < 7; c++) A7[r * 7 + c] = Hs[r * 8 + c];
+          nbs[r] = -bs[r];
+        }
+        orc_ldlt_solve(7, A7, nbs, x7);
+        for (int i = 0; i < 8; i++) inc[i] = 0;
+        for (int i = 0; i < 6; i++) inc[i] = x7[i];
+        inc[7] = x7[6];
+      }
+      float extrapFac = 1;
+      if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
+      for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+      double incScaled[8], sum = 0;
+      for (int i = 0; i < 8; i++) {
+        incScaled[i] = inc[i] * sc[i];
+        sum += incScaled[i];
+      }
+      if (!isfinite(sum))
+        for (int i = 0; i < 8; i++) incScaled[i] = 0;
+      double ex[7], newp[7], aff_new[2];
+      orc_se3_exp(incScaled, ex);
+      orc_se3_mul(ex, cur, newp);
+      aff_new[0] = aff_cur[0] + incScaled[6];
+      aff_new[1] = aff_cur[1] + incScaled[7];
+      double resNew[6];
+      pe_calc_res(e, lvl, newp, aff_new, cutoff0 * levelCutoffRepeat, resNew);
+      const int accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      if (accept) {
+        pe_calc_gs(e, lvl, aff_new, H, b);
+        memcpy(resOld, resNew, sizeof resOld);
+        memcpy(aff_cur, aff_new, sizeof aff_cur);
+        memcpy(cur, newp, sizeof cur);
+        lambda *= 0.5;
+      } else {
+        lambda *= 4;
+        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+      }
+      double nrm = 0;
+      for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+      if (!(sqrt(nrm) > 1e-3)) break;
+    }
+    lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1])); /* :462 */
+    lastInners[lvl] = resOld[1];                                /* :463 */
+    if (levelCutoffRepeat > 1 && !haveRepeated) {
+      lvl++;
+      haveRepeated = 1;
+    }
+  }
+  { /* ref_to_new = refToNew_current.matrix(), :466 */
+    double R[9];
+    orc_quat_to_rot(cur, R);
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) ref_to_new_io[r * 4 + c] = R[r * 3 + c];
+      ref_to_new_io[r * 4 + 3] = cur[4 + r];
+    }
+    ref_to_new_io[12] = ref_to_new_io[13] = ref_to_new_io[14] = 0;
+    ref_to_new_io[15] = 1;
+  }
+  *pose_error = lastResiduals[0];
+  int aff_good = 1; /* :469-482 */
+  if ((modeA != 0 && (fabsf((float)aff_cur[0]) > 1.2)) || (modeB != 0 && (fabsf((float)aff_cur[1]) > 200))) aff_good = 0;
+  double rel[2];
+  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff_cur[0], aff_cur[1], rel);
+  const float rel0 = (float)rel[0], rel1 = (float)rel[1];
+  if ((modeA == 0 && (fabsf(logf(rel0)) > 1.5)) || (modeB == 0 && (fabsf(rel1) > 200))) aff_good = 0;
+  const int low_res = *pose_error < 10.0; /* RES_THRES, PoseEstimator.h:26 */
+  const int inlier_percent = 100 * (float)lastInners[0] / n; /* :486 */
+  if (inlier_percent_out) *inlier_percent_out = inlier_percent;
+  return aff_good && low_res && (inlier_percent > 90); /* INNER_PERCENT, PoseEstimator.h:27 */
+}

@@ -83,6 +83,16 @@ void orc_make_coarse_depth_l0(orc_tracker *t, int npts, const float *pu, const f
                               const float *const *ref_dIp, int *n_out, float *const *pc_u,
                               float *const *pc_v, float *const *pc_idepth, float *const *pc_color);
 
+/* PoseEstimator (src/loop_closure/pose_estimation/PoseEstimator.cpp): calcRes :141-296, calcGSSSE :84-139,
+ * estimate :298-506.  colors[lvl][i] = pts_[i].second[lvl]. */
+typedef struct orc_pose_estimator orc_pose_estimator;
+orc_pose_estimator *orc_pe_create(int w, int h, int nlevels, const orc_params *p);
+void orc_pe_destroy(orc_pose_estimator *e);
+int orc_pe_estimate(orc_pose_estimator *e, int n, const double *xyz, const float *const *colors,
+                    float ref_ab_exposure, const float *const *new_dIp, float new_ab_exposure,
+                    const float new_cam[4], int coarsest_lvl, double ref_to_new_io[16], float *pose_error,
+                    int *inlier_percent_out);
+
 /* Sophus restatements exposed for property tests */
 void orc_se3_exp(const double xi[6], double pose_out[7]);
 void orc_se3_mul(const double a[7], const double b[7], double out[7]);

@@ -79,6 +79,12 @@ def lib(native=False):
     L.orc_make_images.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, pp]
     L.orc_make_coarse_depth_l0.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, pp,
                                            c_int_p, pp, pp, pp, pp]
+    L.orc_pe_create.restype = vp
+    L.orc_pe_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Params)]
+    L.orc_pe_destroy.argtypes = [vp]
+    L.orc_pe_estimate.argtypes = [vp, C.c_int, c_double_p, pp, C.c_float, pp, C.c_float, c_float_p, C.c_int, c_double_p,
+                                  c_float_p, c_int_p]
+    L.orc_pe_estimate.restype = C.c_int
     L.orc_se3_exp.argtypes = [c_double_p, c_double_p]
     L.orc_se3_mul.argtypes = [c_double_p, c_double_p, c_double_p]
     L.orc_quat_to_rot.argtypes = [c_double_p, c_double_p]
@@ -277,3 +283,29 @@ def sc_distance(a_idx, a_val, b_idx, b_val, sc_width=60, native=False):
     b_val = np.ascontiguousarray(b_val, np.float64)
     return lib(native).orc_sc_distance(a_idx.ctypes.data_as(c_int_p), _dp(a_val), len(a_idx),
                                        b_idx.ctypes.data_as(c_int_p), _dp(b_val), len(b_idx), sc_width)
+
+
+class OraclePoseEstimator:
+    """PoseEstimator (PoseEstimator.h:34-83) on the CPU oracle"""
+
+    def __init__(self, w, h, nlevels, params=None, native=False):
+        self.L = lib(native)
+        self.params = params if params is not None else default_params(native)
+        self.nlevels = nlevels
+        self.h_ = self.L.orc_pe_create(w, h, nlevels, C.byref(self.params))
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            self.L.orc_pe_destroy(self.h_)
+            self.h_ = None
+
+    def estimate(self, xyz, colors, ref_ab_exposure, new_dIp, new_ab_exposure, new_cam, coarsest_lvl, ref_to_new):
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        colors = [np.ascontiguousarray(c, np.float32) for c in colors]
+        new_dIp = [np.ascontiguousarray(a, np.float32) for a in new_dIp]
+        cam = np.ascontiguousarray(new_cam, np.float32)
+        T = np.ascontiguousarray(ref_to_new, np.float64).reshape(16).copy()
+        err, inl = C.c_float(), C.c_int()
+        ok = self.L.orc_pe_estimate(self.h_, len(xyz), _dp(xyz), _ptr_array(colors), ref_ab_exposure, _ptr_array(new_dIp),
+                                    new_ab_exposure, _fp(cam), coarsest_lvl, _dp(T), C.byref(err), C.byref(inl))
+        return bool(ok), T.reshape(4, 4), err.value, inl.value

@@ -317,3 +317,22 @@ def test_call_order_errors(ctx):
     trk.upload_frame(0, sc.new_p)
     with pytest.raises(DsmError):
         trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl)  # coarsestLvl >= pyrLevelsUsed (:457)
+
+
+def test_sparse_template_just_below_a_chunking_threshold(ctx):
+    """points-per-thread grows with n, so the chunk count is not monotone in n: n = 65535 uses 4 points
+    per thread and 64 chunks although the level holds up to 113k points (8 per thread, 56 chunks).
+    The partial-sum workspace must be sized for the worst n, not for the largest."""
+    sc = make_scene("medium", seed=50)
+    assert len(sc.tpl[0][0]) > 65535
+    for a in sc.tpl:
+        a[0] = a[0][:65535].copy()
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    t, p, c = trk.reduction_geometry(0, 65535)
+    assert (t, p, c) == (256, 4, 64)
+    assert trk.reduction_geometry(0, sc.w * sc.h)[2] < c
+    assert_eval_pose_equal(orc, trk, 0, sc.gt_pose, sc.gt_aff, 20.0)
+    good_o, pose_o, _, _, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    good_g, pose_g, _, _ = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    assert good_g == good_o
+    np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
