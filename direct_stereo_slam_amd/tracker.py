@@ -237,3 +237,62 @@ class PoseEstimator:
         check(self.L.dsm_pose_estimator_estimate(self.h, len(xyz), _dp(xyz), _ptr_array(cols), ref_ab_exposure, _ptr_array(dIp),
                                                  new_ab_exposure, _fp(cam), coarsest_lvl, _dp(T), C.byref(err), C.byref(ok)))
         return bool(ok.value), T.reshape(4, 4), err.value
+
+
+def track_hypotheses(ctx, trk, tries, aff_last_2_l, coarsestLvl, last_coarse_rmse0, reTrackThreshold=1.5):
+    """The hypothesis loop of FrontEnd::trackNewCoarse (FrontEnd.cpp:194-247) with the same results as
+    the reference's sequential loop, but evaluated as ONE batched launch sequence ("next" row N4).
+
+    Reference semantics: try i is tracked with minResForAbort = achievedRes of the earlier tries and is
+    aborted at the first level whose residual exceeds 1.5x that value (TrackerAndScaler.cpp:598); the
+    loop ends at the first success below last_coarse_rmse*reTrackThreshold.  Here try 0 runs alone (the
+    common case ends there); otherwise all remaining tries run as one batch WITHOUT abort, and the abort
+    / take-over logic is replayed on the host from their per-level residuals -- a level's LM result does
+    not depend on minResForAbort, so the replay is exact.
+    Returns (haveOneGood, lastF_2_fh, aff_g2l, flowVecs, achievedRes, tries_used)."""
+    tries = np.ascontiguousarray(tries, np.float64).reshape(-1, 7)
+    n = len(tries)
+    achieved = np.full(MAX_LEVELS, np.nan)
+    have_good = False
+    flow = np.array([100.0, 100.0, 100.0])
+    best_pose, best_aff = IDENTITY_POSE7.copy(), np.zeros(2)
+
+    def consume(good, pose, aff, cur_res, fl):
+        nonlocal have_good, flow, best_pose, best_aff
+        if good and np.isfinite(np.float32(cur_res[0])) and not (cur_res[0] >= achieved[0]):  # :225-233
+            flow, best_aff, best_pose, have_good = fl.copy(), aff.copy(), pose.copy(), True
+        if have_good:  # :236-243
+            for l in range(5):
+                if not np.isfinite(np.float32(achieved[l])) or achieved[l] > cur_res[l]:
+                    achieved[l] = cur_res[l]
+        return have_good and achieved[0] < last_coarse_rmse0 * reTrackThreshold  # :245-247
+
+    # try 0 alone
+    good, pose, aff, last = trk.trackNewestCoarse(tries[0], aff_last_2_l, coarsestLvl, achieved)
+    used = 1
+    if consume(good, pose, aff, last, trk.lastFlowIndicators) or n == 1:
+        return have_good, (best_pose if have_good else tries[0]), (best_aff if have_good else np.asarray(aff_last_2_l, float)), \
+            (flow if have_good else np.zeros(3)), achieved, used
+    # the rest as one batch, no abort
+    m = n - 1
+    goods, poses, affs, lasts, flows = ctx.track_batch([trk] * m, tries[1:], np.tile(np.asarray(aff_last_2_l, np.float64), (m, 1)),
+                                                       coarsestLvl, None)
+    for i in range(m):
+        used += 1
+        cur = lasts[i].copy()
+        good_i = bool(goods[i])
+        # replay the abort test of TrackerAndScaler.cpp:598 level by level (coarse to fine)
+        for l in range(coarsestLvl, -1, -1):
+            if cur[l] > 1.5 * achieved[l]:
+                cur[:l] = np.nan
+                good_i = False
+                break
+        pose_i = poses[i] if good_i else tries[1 + i]  # an aborted try leaves lastToNew_out untouched
+        if consume(good_i, pose_i, affs[i], cur, flows[i]):
+            break
+    if not have_good:  # :249-256
+        return False, tries[0], np.asarray(aff_last_2_l, float), np.zeros(3), achieved, used
+    return True, best_pose, best_aff, flow, achieved, used
+
+
+IDENTITY_POSE7 = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
