@@ -126,4 +126,114 @@ private:
   long long uploaded_[2] = {-1, -1};
 };
 
+// ---- "next" row N4: the hypothesis loop of FrontEnd::trackNewCoarse (FrontEnd.cpp:194-256) -----------
+// Same results as the reference's sequential loop; try 0 runs alone, the remaining tries as ONE batched
+// launch sequence without abort, and the abort / take-over logic (TrackerAndScaler.cpp:598,
+// FrontEnd.cpp:225-247) is replayed on the host from their per-level residuals.
+struct HypothesesResult {
+  bool haveOneGood = false;
+  SE3 lastF_2_fh;
+  AffLight aff_g2l;
+  double flowVecs[3] = {0, 0, 0};
+  double achievedRes[5];
+  int triesUsed = 0;
+};
+
+inline HypothesesResult trackHypotheses(dsm_context *ctx, TrackerAndScaler &tracker, const FrameView &fh,
+                                        const std::vector<SE3> &lastF_2_fh_tries, const AffLight &aff_last_2_l,
+                                        int coarsestLvl, double last_coarse_rmse0, double reTrackThreshold = 1.5) {
+  HypothesesResult R;
+  for (double &a : R.achievedRes) a = NAN;
+  double flow[3] = {100, 100, 100};
+  auto consume = [&](bool good, const SE3 &pose, const AffLight &aff, const double *cur, const double *fl) {
+    if (good && std::isfinite((float)cur[0]) && !(cur[0] >= R.achievedRes[0])) { // FrontEnd.cpp:225-233
+      for (int k = 0; k < 3; k++) flow[k] = fl[k];
+      R.aff_g2l = aff;
+      R.lastF_2_fh = pose;
+      R.haveOneGood = true;
+    }
+    if (R.haveOneGood) // :236-243
+      for (int l = 0; l < 5; l++)
+        if (!std::isfinite((float)R.achievedRes[l]) || R.achievedRes[l] > cur[l]) R.achievedRes[l] = cur[l];
+    return R.haveOneGood && R.achievedRes[0] < last_coarse_rmse0 * reTrackThreshold; // :245-247
+  };
+  const size_t n = lastF_2_fh_tries.size();
+  bool done = false;
+  {
+    SE3 pose = lastF_2_fh_tries[0];
+    AffLight aff = aff_last_2_l;
+    double cur[5];
+    const bool good = tracker.trackNewestCoarse(fh, pose, aff, coarsestLvl, R.achievedRes, cur);
+    R.triesUsed = 1;
+    done = consume(good, pose, aff, cur, tracker.lastFlowIndicators);
+  }
+  if (!done && n > 1) {
+    const int m = (int)n - 1;
+    std::vector<dsm_tracker *> ts(m, tracker.handle());
+    std::vector<double> poses(7 * m), affs(2 * m), last(DSM_MAX_LEVELS * m), fl(3 * m);
+    std::vector<int> good(m);
+    for (int i = 0; i < m; i++) {
+      const SE3 &T = lastF_2_fh_tries[i + 1];
+      for (int k = 0; k < 4; k++) poses[7 * i + k] = T.q[k];
+      for (int k = 0; k < 3; k++) poses[7 * i + 4 + k] = T.t[k];
+      affs[2 * i] = aff_last_2_l.a, affs[2 * i + 1] = aff_last_2_l.b;
+    }
+    check(dsm_track_batch(ctx, m, ts.data(), poses.data(), affs.data(), coarsestLvl, nullptr, last.data(), fl.data(),
+                          good.data()),
+          "dsm_track_batch");
+    for (int i = 0; i < m && !done; i++) {
+      R.triesUsed++;
+      double cur[5];
+      for (int l = 0; l < 5; l++) cur[l] = last[DSM_MAX_LEVELS * i + l];
+      bool g = good[i] != 0;
+      for (int l = coarsestLvl; l >= 0; l--)
+        if (cur[l] > 1.5 * R.achievedRes[l]) { // the abort the sequential run would have taken (:598)
+          for (int k = 0; k < l; k++) cur[k] = NAN;
+          g = false;
+          break;
+        }
+      SE3 pose = lastF_2_fh_tries[i + 1];
+      if (g) {
+        for (int k = 0; k < 4; k++) pose.q[k] = poses[7 * i + k];
+        for (int k = 0; k < 3; k++) pose.t[k] = poses[7 * i + 4 + k];
+      }
+      done = consume(g, pose, AffLight(affs[2 * i], affs[2 * i + 1]), cur, &fl[3 * i]);
+    }
+  }
+  if (!R.haveOneGood) { // :249-256
+    R.lastF_2_fh = lastF_2_fh_tries[0];
+    R.aff_g2l = aff_last_2_l;
+    flow[0] = flow[1] = flow[2] = 0;
+  }
+  for (int k = 0; k < 3; k++) R.flowVecs[k] = flow[k];
+  return R;
+}
+
+// ---- "next" row N2: dso::PoseEstimator (PoseEstimator.h:34-83) on the C ABI ---------------------------
+class PoseEstimator {
+public:
+  PoseEstimator(dsm_context *ctx, int w, int h, int pyrLevelsUsed, const dsm_params *params = nullptr) {
+    check(dsm_pose_estimator_create(ctx, w, h, pyrLevelsUsed, params, &pe_), "dsm_pose_estimator_create");
+  }
+  ~PoseEstimator() { dsm_pose_estimator_destroy(pe_); }
+  PoseEstimator(const PoseEstimator &) = delete;
+  PoseEstimator &operator=(const PoseEstimator &) = delete;
+
+  // reference: bool estimate(const std::vector<std::pair<Eigen::Vector3d, float*>>& pts, float ref_ab_exposure,
+  //                          FrameHessian* new_fh, const std::vector<float>& new_cam, int coarsest_lvl,
+  //                          Eigen::Matrix4d& ref_to_new, float& pose_error)
+  // pts: xyz as n x 3 doubles, ref_colors[lvl][i] = pts[i].second[lvl]; ref_to_new: row-major 4x4
+  bool estimate(int n, const double *xyz, const float *const *ref_colors, float ref_ab_exposure, const FrameView &new_fh,
+                const float new_cam[4], int coarsest_lvl, double ref_to_new[16], float &pose_error) {
+    int ok = 0;
+    check(dsm_pose_estimator_estimate(pe_, n, xyz, ref_colors, ref_ab_exposure, new_fh.dIp, new_fh.ab_exposure, new_cam,
+                                      coarsest_lvl, ref_to_new, &pose_error, &ok),
+          "PoseEstimator::estimate");
+    return ok != 0;
+  }
+
+private:
+  dsm_pose_estimator *pe_ = nullptr;
+};
+
 } // namespace dsm_host
