@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--config", default="S1", choices=["S1", "S2"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--kf-every", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -201,6 +202,7 @@ def bench_tracking(args):
 
     rank, local, world = dist_setup(args)
     ctx = Context(local)
+    ctx.set_streams(args.streams)
     wl = build_workload(args, ctx, rank)
     B = args.batch
     kf_idx = list(range(0, B, args.kf_every))
@@ -268,7 +270,7 @@ def bench_tracking(args):
         "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
-                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
+                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,

@@ -60,6 +60,7 @@ SYMBOLS = {
     "dsm_context_destroy": (C.c_int, [_vp]),
     "dsm_context_sync": (C.c_int, [_vp]),
     "dsm_context_set_timing": (C.c_int, [_vp, C.c_int]),
+    "dsm_context_set_streams": (C.c_int, [_vp, C.c_int]),
     "dsm_context_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "dsm_context_stream": (_vp, [_vp]),
     "dsm_diag_read_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, c_double_p]),

@@ -190,6 +190,7 @@ int dsm_context_create(int device_ordinal, dsm_context **out) {
   DSM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   DSM_HIP(hipEventCreate(&ctx->ev_total[0]));
   DSM_HIP(hipEventCreate(&ctx->ev_total[1]));
+  DSM_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
   *out = ctx;
   return DSM_OK;
 }
@@ -211,6 +212,9 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipHostFree(ctx->h_status);
   hipFree(ctx->d_stage);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->join_events) hipEventDestroy(ev);
+  for (hipStream_t st : ctx->extra_streams) hipStreamDestroy(st);
+  hipEventDestroy(ctx->fork_event);
   hipEventDestroy(ctx->ev_total[0]);
   hipEventDestroy(ctx->ev_total[1]);
   hipStreamDestroy(ctx->stream);
@@ -226,6 +230,11 @@ int dsm_context_sync(dsm_context *ctx) {
 int dsm_context_set_timing(dsm_context *ctx, int enable) {
   if (!ctx) return invalid("null context");
   ctx->timing = enable != 0;
+  return DSM_OK;
+}
+int dsm_context_set_streams(dsm_context *ctx, int n_streams) {
+  if (!ctx || n_streams < 1 || n_streams > 16) return invalid("dsm_context_set_streams: 1..16");
+  ctx->n_streams = n_streams;
   return DSM_OK;
 }
 int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out) {
@@ -554,29 +563,56 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     worst[L] = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
   }
   int *sched = ctx->sched[mode];
+  int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
+  if (ng > n) ng = n;
+  while ((int)ctx->extra_streams.size() < ng - 1) {
+    hipStream_t st;
+    DSM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->extra_streams.push_back(st);
+    hipEvent_t ev;
+    DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->join_events.push_back(ev);
+  }
   int top = coarsest;
   for (int pass = 0;; pass++) {
+    if (ng > 1) { // fork: the extra streams start after everything enqueued on the main stream so far
+      DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+      for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
+    }
     for (int L = top; L >= 0; L--) {
       int steps = P.adaptive_schedule ? sched[L] << (pass > 3 ? 3 : pass) : worst[L];
       if (steps > worst[L]) steps = worst[L];
       if (steps < 1) steps = 1;
       for (int k = 0; k < steps; k++) {
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (ctx->timing) {
-          ea = get_event(ctx, ev_used++);
-          eb = get_event(ctx, ev_used++);
-          ev_lvl.push_back(L);
-          if (ea) DSM_HIP(hipEventRecord(ea, ctx->stream));
+        // Stream groups: the batch is split into `ng` contiguous groups, each with its own HIP stream.
+        // A group's lm_kernel (one small workgroup per problem) and its small-level eval kernels leave
+        // most of the chip idle; another group's kernels fill it.  Per-problem results are unchanged.
+        for (int g = 0; g < ng; g++) {
+          const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
+          if (g1 <= g0) continue;
+          hipStream_t st = g == 0 ? ctx->stream : ctx->extra_streams[g - 1];
+          hipEvent_t ea = nullptr, eb = nullptr;
+          if (ctx->timing) {
+            ea = get_event(ctx, ev_used++);
+            eb = get_event(ctx, ev_used++);
+            ev_lvl.push_back(L);
+            if (ea) DSM_HIP(hipEventRecord(ea, st));
+          }
+          launch_eval(st, mode, layout, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
+                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride);
+          if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
+          launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
+                    ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr,
+                    ctx->d_status + 2 * g0);
         }
-        launch_eval(ctx->stream, mode, layout, L, grid_x[L], n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
-                    ctx->partial_stride);
-        if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, ctx->stream));
-        launch_lm(ctx->stream, mode, LM_OP_STEP, L, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
-                  ctx->partial_stride, nullptr, nullptr, ctx->d_status);
       }
       ctx->stats.launches[L] += steps;
     }
     DSM_HIP(hipGetLastError()); // launch-configuration errors of the kernels enqueued above
+    for (int g = 1; g < ng; g++) { // join
+      DSM_HIP(hipEventRecord(ctx->join_events[g - 1], ctx->extra_streams[g - 1]));
+      DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->join_events[g - 1], 0));
+    }
     DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
     DSM_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stats.polls++;

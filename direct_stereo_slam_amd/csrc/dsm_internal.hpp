@@ -22,6 +22,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 struct dsm_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  // batched calls may split the batch over several streams so that one group's small kernels overlap
+  // another group's (dsm_context_set_streams); single calls always use `stream`
+  int n_streams = 1;
+  std::vector<hipStream_t> extra_streams;
+  std::vector<hipEvent_t> join_events;
+  hipEvent_t fork_event = nullptr;
   // batch workspaces (grown on demand)
   int cap_prob = 0;
   int partial_stride = 0; // floats per problem

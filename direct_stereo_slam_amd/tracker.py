@@ -59,6 +59,9 @@ class Context:
     def set_timing(self, on):
         check(self.L.dsm_context_set_timing(self.h, int(on)))
 
+    def set_streams(self, n):
+        check(self.L.dsm_context_set_streams(self.h, int(n)))
+
     def stats(self):
         s = Stats()
         check(self.L.dsm_context_get_stats(self.h, C.byref(s)))

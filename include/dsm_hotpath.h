@@ -90,6 +90,9 @@ int dsm_context_sync(dsm_context *ctx);
 /* enable per-level HIP-event timing of the eval kernels (off by default) */
 int dsm_context_set_timing(dsm_context *ctx, int enable);
 int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out);
+/* batched calls: split the batch into n_streams groups on separate HIP streams so that the small
+ * (latency-bound) kernels of one group overlap the kernels of another; results are unchanged.  Default 1. */
+int dsm_context_set_streams(dsm_context *ctx, int n_streams);
 /* raw hipStream_t of the context (for callers that order their own device work) */
 void *dsm_context_stream(dsm_context *ctx);
 

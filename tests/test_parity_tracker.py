@@ -336,3 +336,23 @@ def test_sparse_template_just_below_a_chunking_threshold(ctx):
     good_g, pose_g, _, _ = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     assert good_g == good_o
     np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
+
+
+def test_stream_groups_do_not_change_results(ctx):
+    scs = [make_scene("small", seed=90 + i) for i in range(7)]
+    trks = [hip_tracker(ctx, sc) for sc in scs]
+    poses0 = np.tile(S.IDENTITY_POSE, (7, 1))
+    ref = ctx.track_batch(trks, poses0, np.zeros((7, 2)), 2)
+    try:
+        for ns in (2, 3, 16):
+            ctx.set_streams(ns)
+            got = ctx.track_batch(trks, poses0, np.zeros((7, 2)), 2)
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+            e1, s1 = ctx.optimize_scale_batch(trks, np.ones(7), 2)
+            ctx.set_streams(1)
+            e0, s0 = ctx.optimize_scale_batch(trks, np.ones(7), 2)
+            np.testing.assert_array_equal(e0, e1)
+            np.testing.assert_array_equal(s0, s1)
+    finally:
+        ctx.set_streams(1)
