@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--kf-every", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
+    ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--evals-only", action="store_true",
@@ -119,6 +120,8 @@ def build_workload(args, ctx, rank):
     T = S.KITTI_T_STEREO
     params = default_params()
     params.adaptive_schedule = 0 if args.no_adaptive else 1
+    if args.coarse is not None:
+        params.persistent_coarse = args.coarse
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0
@@ -272,7 +275,7 @@ def bench_tracking(args):
         "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
-                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
+                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,

@@ -33,6 +33,7 @@ class Params(C.Structure):
         ("lambda_extrapolation_limit", C.c_float),
         ("max_iterations", C.c_int * MAX_LEVELS),
         ("adaptive_schedule", C.c_int),
+        ("persistent_coarse", C.c_int),
     ]
 
 
@@ -44,6 +45,7 @@ class Stats(C.Structure):
         ("eval_kernel_ms", C.c_double * MAX_LEVELS),
         ("total_ms", C.c_double),
         ("polls", C.c_int64),
+        ("coarse_launches", C.c_int64),
     ]
 
 

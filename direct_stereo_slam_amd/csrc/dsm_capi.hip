@@ -172,6 +172,7 @@ void dsm_params_default(dsm_params *p) {
   const int it[DSM_MAX_LEVELS] = {10, 20, 50, 50, 50, 50};
   memcpy(p->max_iterations, it, sizeof it);
   p->adaptive_schedule = 1;
+  p->persistent_coarse = 0;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -574,6 +575,20 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     ctx->join_events.push_back(ev);
   }
   int top = coarsest;
+  if (P.persistent_coarse > 0) {
+    // Small levels: the whole LM loop in one launch per problem (coarse_kernel).  It hands a problem
+    // back (still RUNNING) at the first level with more than coarse_max_points() template points.
+    const int max_pts = P.persistent_coarse < coarse_max_points() ? P.persistent_coarse : coarse_max_points();
+    launch_coarse(ctx->stream, mode, layout, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_status, max_pts);
+    ctx->stats.coarse_launches = 1;
+    top = -1;
+    for (int L = coarsest; L >= 0 && top < 0; L--)
+      for (int i = 0; i < n; i++)
+        if (ts[i]->desc.lv[L].n > max_pts) {
+          top = L;
+          break;
+        }
+  }
   for (int pass = 0;; pass++) {
     if (ng > 1) { // fork: the extra streams start after everything enqueued on the main stream so far
       DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));

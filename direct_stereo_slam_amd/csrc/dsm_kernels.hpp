@@ -51,6 +51,11 @@ void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const Tracke
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
                SingleOut *single_out, int *status_out);
 
+// persistent LM loop of the small levels (levels with <= coarse_max_points() template points)
+void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const TrackerDev *const *trackers, LMState *states,
+                   int *status_out, int max_pts);
+int coarse_max_points();
+
 void launch_interleave_template(hipStream_t s, int n, const float *u, const float *v, const float *id,
                                 const float *c, float4 *out);
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,

@@ -118,280 +118,283 @@ struct Warped {
 // ------------------------------------------------------------------------------------------
 // eval kernel
 // ------------------------------------------------------------------------------------------
-// LVL0 = true is the level-0 instantiation (adds the flow indicators); it is also the dominant kernel
-// of the path and shows up under its own symbol in rocprofv3 kernel traces.
+// Wave-uniform inputs of one evaluation (kept in SGPRs): a copy of EvalIn.
+struct EvalConsts {
+  const float4 *pts;
+  const float *img;
+  int n, w, h;
+  float fx, fy, cx, cy;
+  float Ki[9];
+  float huber;
+  float M[9];
+  float t[3];
+  float aff0, aff1, b0, scale, cutoff, max_energy;
+};
+
+// One chunk of one evaluation by 256 threads (tid = 0..255 inside the chunk's thread group):
+// the per-point loop, the flow-indicator pass and the fixed-order reduction into the chunk's 52-slot
+// partial `out` (global memory in eval_kernel, LDS in coarse_kernel).  `red` is this thread group's
+// [16][kNumSlots] LDS scratch.  Contains two workgroup barriers: every thread of the workgroup must
+// call it; thread groups without a chunk pass active = false.
 template <int MODE, int LAYOUT, bool LVL0>
-__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
-                                                        const LMState *__restrict__ states,
-                                                        float *__restrict__ partials,
-                                                        int partial_stride, int lvl) {
-  const int prob = blockIdx.y;
-  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
-  const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
-  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
-  const DSM_GLOBAL EvalIn &in = S.in;
-  const int n = in.n;
+__device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
+                                           float *out) {
+  const int n = c.n;
   const int P = pts_per_thread(n);
-  const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
-  // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
-  // contiguous band of the template (and therefore of the target rows it gathers from).
-  const int per_xcd = gridDim.x >> 3;
-  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (chunk >= nchunks) return;
-
-  const float M0 = in.M[0], M1 = in.M[1], M2 = in.M[2], M3 = in.M[3], M4 = in.M[4], M5 = in.M[5],
-              M6 = in.M[6], M7 = in.M[7], M8 = in.M[8];
-  const float t0 = in.t[0], t1 = in.t[1], t2 = in.t[2];
-  const float cutoff = in.cutoff, max_energy = in.max_energy;
-  const float huber = in.huber;
-  const float fxl = in.fx, fyl = in.fy, cxl = in.cx, cyl = in.cy;
-  const int wl = in.w, hl = in.h;
-  const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
-  const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)in.img;
-  const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)in.pts;
-  // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
-  const float sc = in.scale;
-  const float S0 = sc * M0, S1 = sc * M1, S2 = sc * M2, S3 = sc * M3, S4 = sc * M4, S5 = sc * M5,
-              S6 = sc * M6, S7 = sc * M7, S8 = sc * M8;
-  const float aff0 = in.aff0, aff1 = in.aff1, b0 = in.b0;
-
   constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
   float acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; a++) acc[a] = 0.f;
   float E = 0.f;
   int n_terms = 0, n_sat = 0, n_warped = 0;
-
-  const int tid = threadIdx.x;
-  const int chunk_start = chunk * kThreads * P;
-
-  // Software-pipelined, branch-free loop.  Stage A warps template point k+1 and issues its four
-  // bilinear tap loads; stage B consumes the taps of point k (residual, Huber, Jacobian, 45 FMAs)
-  // while those loads are in flight.  Out-of-range lanes are clamped to a safe address and masked
-  // by selects, so the accumulators never cross a divergent join.
-  auto stage_a = [&](const fvec4 &p, bool in_list, Warped &W, Taps &T) {
-    const float x = p.x, y = p.y, id = p.z;
-    float pt0, pt1, pt2;
-    if (MODE == 0) { // :747
-      pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
-      pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
-      pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
-    } else if (MODE == 2) { // PoseEstimator.cpp:192: pt = R (x,y,z) + t ; the float4 is (x, y, z, refColor[lvl])
-      pt0 = ((M0 * x + M1 * y) + M2 * id) + t0;
-      pt1 = ((M3 * x + M4 * y) + M5 * id) + t1;
-      pt2 = ((M6 * x + M7 * y) + M8 * id) + t2;
-    } else { // :1061
-      pt0 = ((S0 * x + S1 * y) + S2) + t0 * id;
-      pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
-      pt2 = ((S6 * x + S7 * y) + S8) + t2 * id;
-    }
-    // u = pt0/pt2, v = pt1/pt2, new_idepth = id/pt2 (:748-752).  u and v position the bilinear
-    // taps and decide in/out, so they must equal the IEEE quotients bit for bit; new_idepth only
-    // enters the sign test and the Jacobian.  The three quotients share one refined reciprocal
-    // and use the hardware's own correction sequence (what `a / d` expands to) without the
-    // range scaling / fix-up instructions, which are identities for ordinary operands.  A wave
-    // that holds a lane outside that range takes the full IEEE divisions instead.
-    {
-      const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
-      const bool ordinary = (unsigned)(ex + 32) <= 64u && (MODE == 2 || __builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
-                            __builtin_fabsf(pt2) >= 0x1p-34f;
-      if (__builtin_expect(__ballot(!ordinary) != 0ull, 0)) {
-        W.u = pt0 / pt2;
-        W.v = pt1 / pt2;
-        W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2; // PoseEstimator.cpp:197: 1 / pt[2]
-      } else {
-        const float r0 = __builtin_amdgcn_rcpf(pt2);
-        const float r1 = __builtin_fmaf(__builtin_fmaf(-pt2, r0, 1.0f), r0, r0);
-        auto quot = [pt2, r1](float a) {
-          const float q0 = a * r1;
-          const float q1 = __builtin_fmaf(__builtin_fmaf(-pt2, q0, a), r1, q0);
-          return __builtin_fmaf(__builtin_fmaf(-pt2, q1, a), r1, q1);
-        };
-        W.u = quot(pt0);
-        W.v = quot(pt1);
-        W.new_idepth = MODE == 2 ? r1 : id * r1;
-      }
-    }
-    const float Ku = fxl * W.u + cxl;
-    const float Kv = fyl * W.v + cyl;
-    W.refColor = p.w;
-    W.x = x, W.y = y, W.id = id;
-    W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-    if (DSM_ABLATE & 2)
-      taps_load<LAYOUT>(img, W.inb ? 2.25f : 2.5f, W.inb ? 2.75f : 2.5f, wl, T);
-    else
-      taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
-  };
-  auto stage_b = [&](const Warped &W, const Taps &T) {
-    float h0, h1, h2;
-    taps_interp(T, h0, h1, h2);
-    const float refColor = W.refColor;
-    const bool fin = W.inb && __builtin_isfinite(h0); // :791
-    const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
-    const float ar = __builtin_fabsf(residual);
-    // Huber weight (:794-795).  It scales E and the normal equations only (no decision depends
-    // on it), so the hardware reciprocal (1 ulp) replaces the IEEE division.
-    const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
-    const bool sat = ar > cutoff;                    // :797
-    const bool use = fin && !sat;
-    const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
-    E += fin ? e_term : 0.0f;
-    // integer outputs are counted per wave on the scalar unit (s_bcnt1 of the lane masks)
-    n_terms += __builtin_popcountll(__ballot(fin));
-    n_sat += __builtin_popcountll(__ballot(fin && sat));
-    n_warped += __builtin_popcountll(__ballot(use));
-    const float wgt = use ? hw : 0.0f;
-    if (MODE != 1) {
-      // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
-      // lanes get all-zero inputs so that they add exact zeros
-      const unsigned m = use ? 0xFFFFFFFFu : 0u;
-      auto keep = [m](float f) { return __uint_as_float(__float_as_uint(f) & m); };
-      const float u = keep(W.u), v = keep(W.v), nid = keep(W.new_idepth);
-      const float dx = keep(h1 * fxl), dy = keep(h2 * fyl);
-      float J[9];
-      J[0] = nid * dx;
-      J[1] = nid * dy;
-      J[2] = -(nid * __builtin_fmaf(u, dx, v * dy));
-      J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
-      J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
-      J[5] = __builtin_fmaf(u, dy, -(v * dx));
-      J[6] = keep(aff0 * (b0 - refColor));
-      J[7] = -1.0f;
-      J[8] = keep(residual);
-      if (DSM_ABLATE & 1) {
-        float t = 0;
-#pragma unroll
-        for (int r = 0; r < 9; r++) t += J[r];
-        acc[0] = __builtin_fmaf(t, wgt, acc[0]);
-      }
-      int idx = 0;
-#pragma unroll
-      for (int r = 0; r < ((DSM_ABLATE & 1) ? 0 : 9); r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
-        const float Jw = J[r] * wgt;
-#pragma unroll
-        for (int c = r; c < 9; c++) {
-          acc[idx] = __builtin_fmaf(Jw, J[c], acc[idx]);
-          idx++;
-        }
-      }
-    } else {
-      // calcResScale :1068 and calcGSSSEScale :983-999
-      const float x = W.x, y = W.y, id = W.id;
-      const float rx1 = ((M0 * x + M1 * y) + M2) / id;
-      const float rx2 = ((M3 * x + M4 * y) + M5) / id;
-      const float rx3 = ((M6 * x + M7 * y) + M8) / id;
-      const float dxfx = h1 * fxl, dyfy = h2 * fyl;
-      const float deno_sqrt = sc * rx3 + t2;
-      const float deno = 1.0f / (deno_sqrt * deno_sqrt);
-      const float xno = rx1 * t2 - rx3 * t0;
-      const float yno = rx2 * t2 - rx3 * t1;
-      const float J0 = use ? dxfx * (deno * xno) + dyfy * (deno * yno) : 0.0f;
-      const float J1 = use ? residual : 0.0f;
-      const float J0w = J0 * wgt;
-      acc[0] = __builtin_fmaf(J0w, J0, acc[0]);
-      acc[1] = __builtin_fmaf(J0w, J1, acc[1]);
-      acc[2] = __builtin_fmaf(J1 * wgt, J1, acc[2]);
-    }
-  };
-
-  {
-    const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
-    auto load_pt = [pb, n](int idx) {
-      if (DSM_ABLATE & 4) idx &= 255;
-      // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
-      return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)));
-    };
-    // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
-    // (Deeper register rings and bulk staging through LDS were measured and bought nothing -- the
-    // kernel is not bound by the latency of this stream)
-    const int i = chunk_start + tid;
-    const fvec4 p0 = load_pt(i);
-    int i2 = i + kThreads;
-    fvec4 p_next = load_pt(i2);
-    __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-#pragma unroll
-    for (int a = 0; a < NACC; a++) acc[a] = 0.f;
-    Warped Wc;
-    Taps Tc;
-    stage_a(p0, i < n, Wc, Tc);
-    for (int k = 0; k < P; k++) {
-      // stage A for point k+1 (its template entry was prefetched one iteration ago)
-      const fvec4 p = p_next;
-      const bool in_next = i2 < n && k + 1 < P;
-      const int i3 = i2 + kThreads;
-      p_next = load_pt(i3);
-      Warped Wn;
-      Taps Tn;
-      stage_a(p, in_next, Wn, Tn);
-      // stage B for point k
-      stage_b(Wc, Tc);
-      Wc = Wn;
-      Tc = Tn;
-      i2 = i3;
-    }
-  }
-
-  // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
-  // handles the 8*P such points of this chunk in a single pass.
   float fT = 0.f, fRT = 0.f, fNum = 0.f;
-  if (LVL0 && tid < 8 * P) {
-    const int i = chunk_start + 32 * tid;
-    if (i < n) {
-      const fvec4 p = pts[i];
+  if (active) {
+    const float M0 = c.M[0], M1 = c.M[1], M2 = c.M[2], M3 = c.M[3], M4 = c.M[4], M5 = c.M[5],
+                M6 = c.M[6], M7 = c.M[7], M8 = c.M[8];
+    const float t0 = c.t[0], t1 = c.t[1], t2 = c.t[2];
+    const float cutoff = c.cutoff, max_energy = c.max_energy;
+    const float huber = c.huber;
+    const float fxl = c.fx, fyl = c.fy, cxl = c.cx, cyl = c.cy;
+    const int wl = c.w, hl = c.h;
+    const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
+    const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)c.img;
+    const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)c.pts;
+    // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
+    const float sc = c.scale;
+    const float S0 = sc * M0, S1 = sc * M1, S2 = sc * M2, S3 = sc * M3, S4 = sc * M4, S5 = sc * M5,
+                S6 = sc * M6, S7 = sc * M7, S8 = sc * M8;
+    const float aff0 = c.aff0, aff1 = c.aff1, b0 = c.b0;
+
+    const int chunk_start = chunk * kThreads * P;
+
+    // Software-pipelined, branch-free loop.  Stage A warps template point k+1 and issues its four
+    // bilinear tap loads; stage B consumes the taps of point k (residual, Huber, Jacobian, 45 FMAs)
+    // while those loads are in flight.  Out-of-range lanes are clamped to a safe address and masked
+    // by selects, so the accumulators never cross a divergent join.
+    auto stage_a = [&](const fvec4 &p, bool in_list, Warped &W, Taps &T) {
       const float x = p.x, y = p.y, id = p.z;
-      const DSM_GLOBAL float *Ki = in.Ki;
-      if (MODE == 2) {
-        // PoseEstimator.cpp:185-229, as written: shifts are measured against the reference
-        // projection (Ku0,Kv0) and the "translation only" points use (x, y, 1)
-        const float z = id;
-        const float Ku0 = fxl * (x / z) + cxl, Kv0 = fyl * (y / z) + cyl;
-        const float ptz = ((M6 * x + M7 * y) + M8 * z) + t2;
-        const float Ku = fxl * ((((M0 * x + M1 * y) + M2 * z) + t0) / ptz) + cxl;
-        const float Kv = fyl * ((((M3 * x + M4 * y) + M5 * z) + t1) / ptz) + cyl;
-        const float KuT = fxl * ((x + t0) / (1.0f + t2)) + cxl, KvT = fyl * ((y + t1) / (1.0f + t2)) + cyl;
-        const float KuT2 = fxl * ((x - t0) / (1.0f - t2)) + cxl, KvT2 = fyl * ((y - t1) / (1.0f - t2)) + cyl;
-        const float p3z = ((M6 * x + M7 * y) + M8) - t2;
-        const float Ku3 = fxl * ((((M0 * x + M1 * y) + M2) - t0) / p3z) + cxl;
-        const float Kv3 = fyl * ((((M3 * x + M4 * y) + M5) - t1) / p3z) + cyl;
-        fT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
-        fT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
-        fRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
-        fRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
-      } else {
-        float kx0, kx1, kx2, rx0, rx1, rx2;
-        if (MODE == 0) {
-          kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
-          kx1 = (Ki[3] * x + Ki[4] * y) + Ki[5];
-          kx2 = (Ki[6] * x + Ki[7] * y) + Ki[8];
-          rx0 = (M0 * x + M1 * y) + M2;
-          rx1 = (M3 * x + M4 * y) + M5;
-          rx2 = (M6 * x + M7 * y) + M8;
-        } else {
-          kx0 = ((sc * Ki[0]) * x + (sc * Ki[1]) * y) + (sc * Ki[2]);
-          kx1 = ((sc * Ki[3]) * x + (sc * Ki[4]) * y) + (sc * Ki[5]);
-          kx2 = ((sc * Ki[6]) * x + (sc * Ki[7]) * y) + (sc * Ki[8]);
-          rx0 = (S0 * x + S1 * y) + S2;
-          rx1 = (S3 * x + S4 * y) + S5;
-          rx2 = (S6 * x + S7 * y) + S8;
-        }
-        const float a0 = t0 * id, a1 = t1 * id, a2 = t2 * id;
-        const float ptz = rx2 + a2;
-        const float Ku = fxl * ((rx0 + a0) / ptz) + cxl, Kv = fyl * ((rx1 + a1) / ptz) + cyl;
-        const float pTz = kx2 + a2;
-        const float KuT = fxl * ((kx0 + a0) / pTz) + cxl, KvT = fyl * ((kx1 + a1) / pTz) + cyl;
-        const float pT2z = kx2 - a2;
-        const float KuT2 = fxl * ((kx0 - a0) / pT2z) + cxl, KvT2 = fyl * ((kx1 - a1) / pT2z) + cyl;
-        const float p3z = rx2 - a2;
-        const float Ku3 = fxl * ((rx0 - a0) / p3z) + cxl, Kv3 = fyl * ((rx1 - a1) / p3z) + cyl;
-        fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-        fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-        fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-        fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+      float pt0, pt1, pt2;
+      if (MODE == 0) { // :747
+        pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
+        pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
+        pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
+      } else if (MODE == 2) { // PoseEstimator.cpp:192: pt = R (x,y,z) + t ; the float4 is (x, y, z, refColor[lvl])
+        pt0 = ((M0 * x + M1 * y) + M2 * id) + t0;
+        pt1 = ((M3 * x + M4 * y) + M5 * id) + t1;
+        pt2 = ((M6 * x + M7 * y) + M8 * id) + t2;
+      } else { // :1061
+        pt0 = ((S0 * x + S1 * y) + S2) + t0 * id;
+        pt1 = ((S3 * x + S4 * y) + S5) + t1 * id;
+        pt2 = ((S6 * x + S7 * y) + S8) + t2 * id;
       }
-      fNum += 2;
+      // u = pt0/pt2, v = pt1/pt2, new_idepth = id/pt2 (:748-752).  u and v position the bilinear
+      // taps and decide in/out, so they must equal the IEEE quotients bit for bit; new_idepth only
+      // enters the sign test and the Jacobian.  The three quotients share one refined reciprocal
+      // and use the hardware's own correction sequence (what `a / d` expands to) without the
+      // range scaling / fix-up instructions, which are identities for ordinary operands.  A wave
+      // that holds a lane outside that range takes the full IEEE divisions instead.
+      {
+        const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
+        const bool ordinary = (unsigned)(ex + 32) <= 64u && (MODE == 2 || __builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
+                              __builtin_fabsf(pt2) >= 0x1p-34f;
+        if (__builtin_expect(__ballot(!ordinary) != 0ull, 0)) {
+          W.u = pt0 / pt2;
+          W.v = pt1 / pt2;
+          W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2; // PoseEstimator.cpp:197: 1 / pt[2]
+        } else {
+          const float r0 = __builtin_amdgcn_rcpf(pt2);
+          const float r1 = __builtin_fmaf(__builtin_fmaf(-pt2, r0, 1.0f), r0, r0);
+          auto quot = [pt2, r1](float a) {
+            const float q0 = a * r1;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-pt2, q0, a), r1, q0);
+            return __builtin_fmaf(__builtin_fmaf(-pt2, q1, a), r1, q1);
+          };
+          W.u = quot(pt0);
+          W.v = quot(pt1);
+          W.new_idepth = MODE == 2 ? r1 : id * r1;
+        }
+      }
+      const float Ku = fxl * W.u + cxl;
+      const float Kv = fyl * W.v + cyl;
+      W.refColor = p.w;
+      W.x = x, W.y = y, W.id = id;
+      W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
+      if (DSM_ABLATE & 2)
+        taps_load<LAYOUT>(img, W.inb ? 2.25f : 2.5f, W.inb ? 2.75f : 2.5f, wl, T);
+      else
+        taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
+    };
+    auto stage_b = [&](const Warped &W, const Taps &T) {
+      float h0, h1, h2;
+      taps_interp(T, h0, h1, h2);
+      const float refColor = W.refColor;
+      const bool fin = W.inb && __builtin_isfinite(h0); // :791
+      const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
+      const float ar = __builtin_fabsf(residual);
+      // Huber weight (:794-795).  It scales E and the normal equations only (no decision depends
+      // on it), so the hardware reciprocal (1 ulp) replaces the IEEE division.
+      const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
+      const bool sat = ar > cutoff;                    // :797
+      const bool use = fin && !sat;
+      const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
+      E += fin ? e_term : 0.0f;
+      // integer outputs are counted per wave on the scalar unit (s_bcnt1 of the lane masks)
+      n_terms += __builtin_popcountll(__ballot(fin));
+      n_sat += __builtin_popcountll(__ballot(fin && sat));
+      n_warped += __builtin_popcountll(__ballot(use));
+      const float wgt = use ? hw : 0.0f;
+      if (MODE != 1) {
+        // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
+        // lanes get all-zero inputs so that they add exact zeros
+        const unsigned m = use ? 0xFFFFFFFFu : 0u;
+        auto keep = [m](float f) { return __uint_as_float(__float_as_uint(f) & m); };
+        const float u = keep(W.u), v = keep(W.v), nid = keep(W.new_idepth);
+        const float dx = keep(h1 * fxl), dy = keep(h2 * fyl);
+        float J[9];
+        J[0] = nid * dx;
+        J[1] = nid * dy;
+        J[2] = -(nid * __builtin_fmaf(u, dx, v * dy));
+        J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
+        J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
+        J[5] = __builtin_fmaf(u, dy, -(v * dx));
+        J[6] = keep(aff0 * (b0 - refColor));
+        J[7] = -1.0f;
+        J[8] = keep(residual);
+        if (DSM_ABLATE & 1) {
+          float t = 0;
+  #pragma unroll
+          for (int r = 0; r < 9; r++) t += J[r];
+          acc[0] = __builtin_fmaf(t, wgt, acc[0]);
+        }
+        int idx = 0;
+  #pragma unroll
+        for (int r = 0; r < ((DSM_ABLATE & 1) ? 0 : 9); r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
+          const float Jw = J[r] * wgt;
+  #pragma unroll
+          for (int c = r; c < 9; c++) {
+            acc[idx] = __builtin_fmaf(Jw, J[c], acc[idx]);
+            idx++;
+          }
+        }
+      } else {
+        // calcResScale :1068 and calcGSSSEScale :983-999
+        const float x = W.x, y = W.y, id = W.id;
+        const float rx1 = ((M0 * x + M1 * y) + M2) / id;
+        const float rx2 = ((M3 * x + M4 * y) + M5) / id;
+        const float rx3 = ((M6 * x + M7 * y) + M8) / id;
+        const float dxfx = h1 * fxl, dyfy = h2 * fyl;
+        const float deno_sqrt = sc * rx3 + t2;
+        const float deno = 1.0f / (deno_sqrt * deno_sqrt);
+        const float xno = rx1 * t2 - rx3 * t0;
+        const float yno = rx2 * t2 - rx3 * t1;
+        const float J0 = use ? dxfx * (deno * xno) + dyfy * (deno * yno) : 0.0f;
+        const float J1 = use ? residual : 0.0f;
+        const float J0w = J0 * wgt;
+        acc[0] = __builtin_fmaf(J0w, J0, acc[0]);
+        acc[1] = __builtin_fmaf(J0w, J1, acc[1]);
+        acc[2] = __builtin_fmaf(J1 * wgt, J1, acc[2]);
+      }
+    };
+
+    {
+      const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
+      auto load_pt = [pb, n](int idx) {
+        if (DSM_ABLATE & 4) idx &= 255;
+        // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
+        return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)));
+      };
+      // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
+      // (Deeper register rings and bulk staging through LDS were measured and bought nothing -- the
+      // kernel is not bound by the latency of this stream)
+      const int i = chunk_start + tid;
+      const fvec4 p0 = load_pt(i);
+      int i2 = i + kThreads;
+      fvec4 p_next = load_pt(i2);
+      __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+      Warped Wc;
+      Taps Tc;
+      stage_a(p0, i < n, Wc, Tc);
+      for (int k = 0; k < P; k++) {
+        // stage A for point k+1 (its template entry was prefetched one iteration ago)
+        const fvec4 p = p_next;
+        const bool in_next = i2 < n && k + 1 < P;
+        const int i3 = i2 + kThreads;
+        p_next = load_pt(i3);
+        Warped Wn;
+        Taps Tn;
+        stage_a(p, in_next, Wn, Tn);
+        // stage B for point k
+        stage_b(Wc, Tc);
+        Wc = Wn;
+        Tc = Tn;
+        i2 = i3;
+      }
     }
-  }
+
+    // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
+    // handles the 8*P such points of this chunk in a single pass.
+    if (LVL0 && tid < 8 * P) {
+      const int i = chunk_start + 32 * tid;
+      if (i < n) {
+        const fvec4 p = pts[i];
+        const float x = p.x, y = p.y, id = p.z;
+        const float *Ki = c.Ki;
+        if (MODE == 2) {
+          // PoseEstimator.cpp:185-229, as written: shifts are measured against the reference
+          // projection (Ku0,Kv0) and the "translation only" points use (x, y, 1)
+          const float z = id;
+          const float Ku0 = fxl * (x / z) + cxl, Kv0 = fyl * (y / z) + cyl;
+          const float ptz = ((M6 * x + M7 * y) + M8 * z) + t2;
+          const float Ku = fxl * ((((M0 * x + M1 * y) + M2 * z) + t0) / ptz) + cxl;
+          const float Kv = fyl * ((((M3 * x + M4 * y) + M5 * z) + t1) / ptz) + cyl;
+          const float KuT = fxl * ((x + t0) / (1.0f + t2)) + cxl, KvT = fyl * ((y + t1) / (1.0f + t2)) + cyl;
+          const float KuT2 = fxl * ((x - t0) / (1.0f - t2)) + cxl, KvT2 = fyl * ((y - t1) / (1.0f - t2)) + cyl;
+          const float p3z = ((M6 * x + M7 * y) + M8) - t2;
+          const float Ku3 = fxl * ((((M0 * x + M1 * y) + M2) - t0) / p3z) + cxl;
+          const float Kv3 = fyl * ((((M3 * x + M4 * y) + M5) - t1) / p3z) + cyl;
+          fT += (KuT - Ku0) * (KuT - Ku0) + (KvT - Kv0) * (KvT - Kv0);
+          fT += (KuT2 - Ku0) * (KuT2 - Ku0) + (KvT2 - Kv0) * (KvT2 - Kv0);
+          fRT += (Ku - Ku0) * (Ku - Ku0) + (Kv - Kv0) * (Kv - Kv0);
+          fRT += (Ku3 - Ku0) * (Ku3 - Ku0) + (Kv3 - Kv0) * (Kv3 - Kv0);
+        } else {
+          float kx0, kx1, kx2, rx0, rx1, rx2;
+          if (MODE == 0) {
+            kx0 = (Ki[0] * x + Ki[1] * y) + Ki[2];
+            kx1 = (Ki[3] * x + Ki[4] * y) + Ki[5];
+            kx2 = (Ki[6] * x + Ki[7] * y) + Ki[8];
+            rx0 = (M0 * x + M1 * y) + M2;
+            rx1 = (M3 * x + M4 * y) + M5;
+            rx2 = (M6 * x + M7 * y) + M8;
+          } else {
+            kx0 = ((sc * Ki[0]) * x + (sc * Ki[1]) * y) + (sc * Ki[2]);
+            kx1 = ((sc * Ki[3]) * x + (sc * Ki[4]) * y) + (sc * Ki[5]);
+            kx2 = ((sc * Ki[6]) * x + (sc * Ki[7]) * y) + (sc * Ki[8]);
+            rx0 = (S0 * x + S1 * y) + S2;
+            rx1 = (S3 * x + S4 * y) + S5;
+            rx2 = (S6 * x + S7 * y) + S8;
+          }
+          const float a0 = t0 * id, a1 = t1 * id, a2 = t2 * id;
+          const float ptz = rx2 + a2;
+          const float Ku = fxl * ((rx0 + a0) / ptz) + cxl, Kv = fyl * ((rx1 + a1) / ptz) + cyl;
+          const float pTz = kx2 + a2;
+          const float KuT = fxl * ((kx0 + a0) / pTz) + cxl, KvT = fyl * ((kx1 + a1) / pTz) + cyl;
+          const float pT2z = kx2 - a2;
+          const float KuT2 = fxl * ((kx0 - a0) / pT2z) + cxl, KvT2 = fyl * ((kx1 - a1) / pT2z) + cyl;
+          const float p3z = rx2 - a2;
+          const float Ku3 = fxl * ((rx0 - a0) / p3z) + cxl, Kv3 = fyl * ((rx1 - a1) / p3z) + cyl;
+          fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+          fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+          fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+          fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+        }
+        fNum += 2;
+      }
+    }
+
+
+  } // active
 
   // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
-  __shared__ float red[16][kNumSlots];
   const int lane = tid & 63, wave = tid >> 6;
   const int row = wave * 4 + (lane >> 4);
   const bool writer = (lane & 15) == 0;
@@ -416,9 +419,9 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     }
   }
   __syncthreads();
-  float *out = partials + (size_t)prob * partial_stride + (size_t)chunk * kPartialStride;
   const bool is_float_slot = tid < NACC || (tid >= kSlotE && tid < kSlotNTerms);
-  if (is_float_slot) {
+  if (!active) {
+  } else if (is_float_slot) {
     float s = red[0][tid];
 #pragma unroll
     for (int r = 1; r < 16; r++) s += red[r][tid];
@@ -429,6 +432,38 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     for (int r = 0; r < 16; r++) s += __float_as_int(red[r][tid]);
     out[tid] = __int_as_float(s);
   }
+}
+
+// LVL0 = true is the level-0 instantiation (adds the flow indicators); it is also the dominant kernel
+// of the path and shows up under its own symbol in rocprofv3 kernel traces.
+template <int MODE, int LAYOUT, bool LVL0>
+__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
+                                                        const LMState *__restrict__ states,
+                                                        float *__restrict__ partials,
+                                                        int partial_stride, int lvl) {
+  const int prob = blockIdx.y;
+  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
+  const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
+  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
+  const DSM_GLOBAL EvalIn &in = S.in;
+  const int n = in.n;
+  const int P = pts_per_thread(n);
+  const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
+  // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
+  // contiguous band of the template (and therefore of the target rows it gathers from).
+  const int per_xcd = gridDim.x >> 3;
+  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (chunk >= nchunks) return;
+  EvalConsts c;
+  c.pts = in.pts, c.img = in.img, c.n = n, c.w = in.w, c.h = in.h;
+  c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
+  c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
+  c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
+  __shared__ float red[16][kNumSlots];
+  eval_chunk<MODE, LAYOUT, LVL0>(c, chunk, threadIdx.x, true, red,
+                                 partials + (size_t)prob * partial_stride + (size_t)chunk * kPartialStride);
 }
 
 template <int MODE, int LAYOUT>
@@ -472,7 +507,7 @@ void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int n
 // ------------------------------------------------------------------------------------------
 constexpr int kLmThreads = 256;
 
-__device__ void make_eval_pose(const TrackerDev &T, LMState &S, int lvl, const double pose[7],
+__device__ void make_eval_pose(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7],
                                const double aff[2], float cutoff) {
   double Rd[9];
   quat_to_rot(pose, Rd);
@@ -485,37 +520,37 @@ __device__ void make_eval_pose(const TrackerDev &T, LMState &S, int lvl, const d
   float M[9];
   mat3f_mul(Rf, Ki, M); // :715
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+  for (int i = 0; i < 9; i++) e.M[i] = M[i];
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.Ki[i] = Ki[i];
+  for (int i = 0; i < 9; i++) e.Ki[i] = Ki[i];
   {
     const LevelDev &L = T.lv[lvl];
-    S.in.pts = L.pts;
-    S.in.img = L.img[0]; // new left frame (:709)
-    S.in.n = L.n;
-    S.in.w = L.w;
-    S.in.h = L.h;
-    S.in.fx = L.fx;
-    S.in.fy = L.fy;
-    S.in.cx = L.cx;
-    S.in.cy = L.cy;
-    S.in.huber = T.p.huber_th;
+    e.pts = L.pts;
+    e.img = L.img[0]; // new left frame (:709)
+    e.n = L.n;
+    e.w = L.w;
+    e.h = L.h;
+    e.fx = L.fx;
+    e.fy = L.fy;
+    e.cx = L.cx;
+    e.cy = L.cy;
+    e.huber = T.p.huber_th;
   }
-  S.in.t[0] = (float)pose[4]; // :716
-  S.in.t[1] = (float)pose[5];
-  S.in.t[2] = (float)pose[6];
+  e.t[0] = (float)pose[4]; // :716
+  e.t[1] = (float)pose[5];
+  e.t[2] = (float)pose[6];
   double affd[2];
   aff_from_to(T.ref_exposure, T.exposure[0], T.ref_a, T.ref_b, aff[0], aff[1], affd); // :717-720
-  S.in.aff0 = (float)affd[0];
-  S.in.aff1 = (float)affd[1];
-  S.in.b0 = (float)T.ref_b; // :646
-  S.in.scale = 1.0f;
-  S.in.cutoff = cutoff;
+  e.aff0 = (float)affd[0];
+  e.aff1 = (float)affd[1];
+  e.b0 = (float)T.ref_b; // :646
+  e.scale = 1.0f;
+  e.cutoff = cutoff;
   const float h = T.p.huber_th;
-  S.in.max_energy = 2 * h * cutoff - h * h; // :726-728
+  e.max_energy = 2 * h * cutoff - h * h; // :726-728
 }
 
-__device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float scale, float cutoff) {
+__device__ void make_eval_scale(const TrackerDev &T, EvalIn &e, int lvl, float scale, float cutoff) {
   double Rd[9];
   quat_to_rot(T.T10, Rd);
   float Rf[9];
@@ -527,87 +562,92 @@ __device__ void make_eval_scale(const TrackerDev &T, LMState &S, int lvl, float 
   float M[9];
   mat3f_mul(Rf, Ki, M); // :1022-1023
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.M[i] = M[i];
+  for (int i = 0; i < 9; i++) e.M[i] = M[i];
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.Ki[i] = Ki[i];
+  for (int i = 0; i < 9; i++) e.Ki[i] = Ki[i];
   {
     const LevelDev &L = T.lv[lvl];
-    S.in.pts = L.pts;
-    S.in.img = L.img[1]; // right frame fh1_ (:1016)
-    S.in.n = L.n;
-    S.in.w = L.w;
-    S.in.h = L.h;
-    S.in.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
-    S.in.fy = L.fy1;
-    S.in.cx = L.cx1;
-    S.in.cy = L.cy1;
-    S.in.huber = T.p.huber_th;
+    e.pts = L.pts;
+    e.img = L.img[1]; // right frame fh1_ (:1016)
+    e.n = L.n;
+    e.w = L.w;
+    e.h = L.h;
+    e.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
+    e.fy = L.fy1;
+    e.cx = L.cx1;
+    e.cy = L.cy1;
+    e.huber = T.p.huber_th;
   }
-  S.in.t[0] = (float)T.T10[4]; // :1024
-  S.in.t[1] = (float)T.T10[5];
-  S.in.t[2] = (float)T.T10[6];
-  S.in.aff0 = 1.0f;
-  S.in.aff1 = 0.0f;
-  S.in.b0 = 0.0f;
-  S.in.scale = scale;
-  S.in.cutoff = cutoff;
+  e.t[0] = (float)T.T10[4]; // :1024
+  e.t[1] = (float)T.T10[5];
+  e.t[2] = (float)T.T10[6];
+  e.aff0 = 1.0f;
+  e.aff1 = 0.0f;
+  e.b0 = 0.0f;
+  e.scale = scale;
+  e.cutoff = cutoff;
   const float h = T.p.huber_th;
-  S.in.max_energy = 2 * h * cutoff - h * h; // :1030-1032
+  e.max_energy = 2 * h * cutoff - h * h; // :1030-1032
 }
 
 // loop-closure pose (PoseEstimator::calcRes, PoseEstimator.cpp:155-163): M = R (no K^-1), reference
 // affine parameters (0,0) (:317), exposure handed over by the caller
-__device__ void make_eval_points3d(const TrackerDev &T, LMState &S, int lvl, const double pose[7], const double aff[2],
+__device__ void make_eval_points3d(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7], const double aff[2],
                                    float cutoff) {
   double Rd[9];
   quat_to_rot(pose, Rd);
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.M[i] = (float)Rd[i];
-  S.in.t[0] = (float)pose[4];
-  S.in.t[1] = (float)pose[5];
-  S.in.t[2] = (float)pose[6];
+  for (int i = 0; i < 9; i++) e.M[i] = (float)Rd[i];
+  e.t[0] = (float)pose[4];
+  e.t[1] = (float)pose[5];
+  e.t[2] = (float)pose[6];
   double affd[2];
   aff_from_to(T.ref_exposure, T.exposure[0], 0.0, 0.0, aff[0], aff[1], affd);
-  S.in.aff0 = (float)affd[0];
-  S.in.aff1 = (float)affd[1];
-  S.in.b0 = 0.0f; // ref_aff_g2l_.b (:90)
-  S.in.scale = 1.0f;
-  S.in.cutoff = cutoff;
+  e.aff0 = (float)affd[0];
+  e.aff1 = (float)affd[1];
+  e.b0 = 0.0f; // ref_aff_g2l_.b (:90)
+  e.scale = 1.0f;
+  e.cutoff = cutoff;
   const float h = T.p.huber_th;
-  S.in.max_energy = 2 * h * cutoff - h * h;
+  e.max_energy = 2 * h * cutoff - h * h;
   const LevelDev &L = T.lv[lvl];
 #pragma unroll
-  for (int i = 0; i < 9; i++) S.in.Ki[i] = L.Ki[i];
-  S.in.pts = L.pts;
-  S.in.img = L.img[0];
-  S.in.n = L.n;
-  S.in.w = L.w;
-  S.in.h = L.h;
-  S.in.fx = L.fx;
-  S.in.fy = L.fy;
-  S.in.cx = L.cx;
-  S.in.cy = L.cy;
-  S.in.huber = T.p.huber_th;
+  for (int i = 0; i < 9; i++) e.Ki[i] = L.Ki[i];
+  e.pts = L.pts;
+  e.img = L.img[0];
+  e.n = L.n;
+  e.w = L.w;
+  e.h = L.h;
+  e.fx = L.fx;
+  e.fy = L.fy;
+  e.cx = L.cx;
+  e.cy = L.cy;
+  e.huber = T.p.huber_th;
 }
 
+// lane 0 only.  Builds the inputs of the next evaluation, stores them in the problem state and -- inside the
+// persistent coarse kernel -- in the workgroup's LDS mirror, from which all waves read them.
 __device__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
-                              float scale, float cutoff) {
+                              float scale, float cutoff, EvalIn *mirror) {
+  EvalIn e;
   if (mode == 1)
-    make_eval_scale(T, S, lvl, scale, cutoff);
+    make_eval_scale(T, e, lvl, scale, cutoff);
   else if (mode == 2)
-    make_eval_points3d(T, S, lvl, pose, aff, cutoff);
+    make_eval_points3d(T, e, lvl, pose, aff, cutoff);
   else
-    make_eval_pose(T, S, lvl, pose, aff, cutoff);
+    make_eval_pose(T, e, lvl, pose, aff, cutoff);
+  S.in = e;
+  if (mirror) *mirror = e;
 }
 
 // lane 0 only
-__device__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
+__device__ void begin_level(const TrackerDev &T, LMState &S, int lvl, EvalIn *mirror) {
   S.lvl = lvl;
   S.phase = PH_INIT;
   S.iteration = 0;
   S.level_cutoff_repeat = 1.0f;
   const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-  make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
+  make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff, mirror);
 }
 
 // Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
@@ -739,7 +779,7 @@ __device__ void finish_track(const TrackerDev &T, LMState &S) {
 
 // whole wave: solve + propose for the pose problem (:505-554).  h = H(r,c) of this lane,
 // bneg = -b(r) replicated along the row.
-__device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane) {
+__device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane, EvalIn *mirror) {
   const int r = lane >> 3, c = lane & 7;
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   double a = h;
@@ -798,11 +838,11 @@ __device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double b
   for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
   S.inc_norm = sqrt(nrm);
   S.phase = PH_ITER;
-  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, mirror);
 }
 
 // lane 0 only: :897-913
-__device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
+__device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda, EvalIn *mirror) {
   float Hl = S.Hs;
   Hl *= (1 + lambda);
   float inc = -S.bs / Hl;
@@ -814,11 +854,11 @@ __device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
   S.inc_f = inc;
   S.scale_cand = S.scale_cur + inc;
   S.phase = PH_ITER;
-  make_eval_scale(T, S, S.lvl, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, mirror);
 }
 
 // lane 0 only
-__device__ void end_level(const TrackerDev &T, LMState &S) {
+__device__ void end_level(const TrackerDev &T, LMState &S, EvalIn *mirror) {
   const int lvl = S.lvl;
   S.last_residuals[lvl] = sqrtf((float)(S.res_old[0] / S.res_old[1])); // :596 / :945
   S.last_inners[lvl] = S.res_old[1];                                     // PoseEstimator.cpp:463
@@ -843,154 +883,81 @@ __device__ void end_level(const TrackerDev &T, LMState &S) {
       finish_track(T, S); // the same affine plausibility checks end PoseEstimator::estimate (:470-482)
     return;
   }
-  begin_level(T, S, next);
+  begin_level(T, S, next, mirror);
 }
 
-__global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
-                                                        const TrackerDev *const *__restrict__ trackers,
-                                                        LMState *__restrict__ states,
-                                                        const float *__restrict__ partials, int partial_stride,
-                                                        const StartInfo *__restrict__ start,
-                                                        SingleOut *__restrict__ single_out,
-                                                        int *__restrict__ status_out) {
-  const int prob = blockIdx.x;
-  const bool pose_like = mode != 1; // 0: frame tracking, 2: loop-closure pose -- same 8-DoF LM; 1: stereo scale
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const TrackerDev &T = *trackers[prob];
-  LMState &S = states[prob];
-  __shared__ double psum[19][kNumSlots];
-  __shared__ long long pisum[19][4];
-  __shared__ double sums[kNumSlots];
-  __shared__ long long isums[4];
+// LDS workspace of the partial reduction / LM step (lm_kernel and coarse_kernel)
+struct LmShared {
+  double psum[19][kNumSlots];
+  long long pisum[19][4];
+  double sums[kNumSlots];
+  long long isums[4];
+};
 
-  if (op == LM_OP_START) {
-    if (tid == 0) {
-      const StartInfo &I = start[prob];
-      S.is_scale = mode;
-      S.coarsest = I.coarsest;
-      S.have_repeated = 0;
-      S.lambda = 0.01f;
-      S.inc_norm = 0;
-      S.inc_f = 0;
-      for (int i = 0; i < 7; i++) S.cur[i] = I.pose[i];
-      S.aff_cur[0] = I.aff[0];
-      S.aff_cur[1] = I.aff[1];
-      S.scale_cur = I.scale;
-      for (int i = 0; i < DSM_MAX_LEVELS; i++) {
-        S.last_residuals[i] = __builtin_nan(""); // :459 / :860
-        S.min_res[i] = I.min_res[i];
-        S.evals[i] = 0;
+// ---- fixed-order reduction over the chunk partials (double / int64), first 247 threads of the
+// workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
+// g, g+19, g+38, ...: every load is a 16-byte read and up to kRedBatch of them are in flight per
+// thread.  `P` may point to global memory (lm_kernel) or LDS (coarse_kernel): same order, same sums.
+__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, LmShared &sh) {
+  constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
+  const fvec4 *P4 = (const fvec4 *)P;
+  const int q = tid % kQuads, g = tid / kQuads;
+  if (g < kGroups) {
+    double sd[4] = {0, 0, 0, 0};
+    long long si[4] = {0, 0, 0, 0};
+    for (int c0 = g; c0 < nch; c0 += kGroups * kRedBatch) {
+      fvec4 v[kRedBatch];
+#pragma unroll
+      for (int j = 0; j < kRedBatch; j++) {
+        const int cc = c0 + j * kGroups;
+        v[j] = cc < nch ? P4[(size_t)cc * (kPartialStride / 4) + q] : fvec4{0.f, 0.f, 0.f, 0.f};
       }
-      S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
-      S.status = ST_RUNNING;
-      begin_level(T, S, I.coarsest);
-      if (status_out) {
-        status_out[2 * prob] = S.status;
-        status_out[2 * prob + 1] = S.lvl;
+#pragma unroll
+      for (int j = 0; j < kRedBatch; j++) {
+        sd[0] += (double)v[j].x, sd[1] += (double)v[j].y, sd[2] += (double)v[j].z, sd[3] += (double)v[j].w;
+        si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
+            si[3] += __float_as_int(v[j].w);
       }
     }
-    return;
-  }
-  if (op == LM_OP_SINGLE_PREP) {
-    if (tid == 0) {
-      const StartInfo &I = start[prob];
-      S.is_scale = mode;
-      S.status = ST_RUNNING;
-      S.lvl = I.lvl;
-      make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int slot = 4 * q + e;
+      if (slot < kSlotNTerms)
+        sh.psum[g][slot] = sd[e];
+      else
+        sh.pisum[g][slot - kSlotNTerms] = si[e];
     }
-    return;
   }
+}
 
-  const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
-  if (!active) { // block-uniform
-    if (tid == 0 && status_out) {
-      status_out[2 * prob] = S.status;
-      status_out[2 * prob + 1] = S.lvl;
-    }
-    return;
-  }
-  // ---- fixed-order reduction over the chunk partials (double / int64).  Thread (g, q) sums the
-  // slot quad q (one float4 = 4 of the 52 slots) over chunks g, g+19, g+38, ...: every load is a
-  // coalesced 16-byte read and up to kRedBatch of them are in flight per thread, so a level-0
-  // reduction (219 chunks) costs two memory round trips.  The 19 group sums are then added in
-  // group order by the slot's lane. ----
-  {
-    constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
-    const int nch = num_chunks(T.lv[lvl].n);
-    const DSM_GLOBAL fvec4 *P4 = (const DSM_GLOBAL fvec4 *)(partials + (size_t)prob * partial_stride);
-    const int q = tid % kQuads, g = tid / kQuads;
-    if (g < kGroups) {
-      double sd[4] = {0, 0, 0, 0};
-      long long si[4] = {0, 0, 0, 0};
-      for (int c0 = g; c0 < nch; c0 += kGroups * kRedBatch) {
-        fvec4 v[kRedBatch];
-#pragma unroll
-        for (int j = 0; j < kRedBatch; j++) {
-          const int cc = c0 + j * kGroups;
-          v[j] = cc < nch ? P4[(size_t)cc * (kPartialStride / 4) + q] : fvec4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int j = 0; j < kRedBatch; j++) {
-          sd[0] += (double)v[j].x, sd[1] += (double)v[j].y, sd[2] += (double)v[j].z, sd[3] += (double)v[j].w;
-          si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
-              si[3] += __float_as_int(v[j].w);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int slot = 4 * q + e;
-        if (slot < kSlotNTerms)
-          psum[g][slot] = sd[e];
-        else
-          pisum[g][slot - kSlotNTerms] = si[e];
-      }
-    }
-  }
-  __syncthreads();
-  if (tid >= 64) return; // wave 0 carries on
+// wave 0, after a workgroup barrier: the 19 group sums are added in group order by the slot's lane
+__device__ __forceinline__ void reduce_partials_final(int lane, LmShared &sh) {
   if (lane < kSlotNTerms) {
-    double s = psum[0][lane];
+    double s = sh.psum[0][lane];
 #pragma unroll
-    for (int g = 1; g < 19; g++) s += psum[g][lane];
-    sums[lane] = s;
+    for (int g = 1; g < 19; g++) s += sh.psum[g][lane];
+    sh.sums[lane] = s;
   } else if (lane < kNumSlots) {
     long long s = 0;
 #pragma unroll
-    for (int g = 0; g < 19; g++) s += pisum[g][lane - kSlotNTerms];
-    isums[lane - kSlotNTerms] = s;
+    for (int g = 0; g < 19; g++) s += sh.pisum[g][lane - kSlotNTerms];
+    sh.isums[lane - kSlotNTerms] = s;
   }
-  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // LDS writes above are read by other lanes below
   __builtin_amdgcn_wave_barrier();
-  __syncthreads(); // only wave 0 is left; keeps the LDS writes ordered before the reads below
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
+// One step of the LM state machine by wave 0 (all 64 lanes; lane 0 writes the state).
+__device__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane, EvalIn *mirror) {
+  const bool pose_like = mode != 1;
+  const double *sums = sh.sums;
+  const long long *isums = sh.isums;
   double rs[6];
   build_rs(sums, isums, rs);
   const int n_warped = (int)isums[2];
   const int n4 = (n_warped + 3) & ~3; // :824-835 padding counts in n (quirk Q3)
   const int r = lane >> 3, c = lane & 7;
-
-  if (op == LM_OP_SINGLE_FINISH) {
-    SingleOut &O = single_out[prob];
-    if (pose_like) {
-      O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
-      if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
-    }
-    if (lane == 0) {
-      for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
-      O.n_warped = n4;
-      if (pose_like) {
-        O.Hs = O.bs = 0;
-      } else {
-        O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
-        O.bs = (float)sums[1] * (1.0f / n4);
-      }
-      S.status = ST_IDLE;
-    }
-    return;
-  }
-
   // ---- LM_OP_STEP: every lane of wave 0 evaluates the same (uniform) decisions; lane 0 writes ----
   const int max_it = T.p.max_iterations[lvl];
   const float lim = T.p.lambda_extrapolation_limit;
@@ -1004,7 +971,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
         S.evals[lvl]++;
         S.level_cutoff_repeat *= 2;
         const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
+        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff, mirror);
       }
     } else {
       if (pose_like) {
@@ -1077,18 +1044,223 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (do_propose) {
     if (pose_like)
-      propose_pose(T, S, h, bneg, lambda_next, lane);
+      propose_pose(T, S, h, bneg, lambda_next, lane, mirror);
     else if (lane == 0)
-      propose_scale(T, S, lambda_next);
+      propose_scale(T, S, lambda_next, mirror);
   }
-  if (lane == 0) {
-    if (level_done) end_level(T, S);
-    if (status_out) {
+  if (lane == 0 && level_done) end_level(T, S, mirror);
+}
+
+__global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
+                                                        const TrackerDev *const *__restrict__ trackers,
+                                                        LMState *__restrict__ states,
+                                                        const float *__restrict__ partials, int partial_stride,
+                                                        const StartInfo *__restrict__ start,
+                                                        SingleOut *__restrict__ single_out,
+                                                        int *__restrict__ status_out) {
+  const int prob = blockIdx.x;
+  const bool pose_like = mode != 1; // 0: frame tracking, 2: loop-closure pose -- same 8-DoF LM; 1: stereo scale
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const TrackerDev &T = *trackers[prob];
+  LMState &S = states[prob];
+  __shared__ LmShared sh;
+
+  if (op == LM_OP_START) {
+    if (tid == 0) {
+      const StartInfo &I = start[prob];
+      S.is_scale = mode;
+      S.coarsest = I.coarsest;
+      S.have_repeated = 0;
+      S.lambda = 0.01f;
+      S.inc_norm = 0;
+      S.inc_f = 0;
+      for (int i = 0; i < 7; i++) S.cur[i] = I.pose[i];
+      S.aff_cur[0] = I.aff[0];
+      S.aff_cur[1] = I.aff[1];
+      S.scale_cur = I.scale;
+      for (int i = 0; i < DSM_MAX_LEVELS; i++) {
+        S.last_residuals[i] = __builtin_nan(""); // :459 / :860
+        S.last_inners[i] = 0;
+        S.min_res[i] = I.min_res[i];
+        S.evals[i] = 0;
+      }
+      S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
+      S.status = ST_RUNNING;
+      begin_level(T, S, I.coarsest, nullptr);
+      if (status_out) {
+        status_out[2 * prob] = S.status;
+        status_out[2 * prob + 1] = S.lvl;
+      }
+    }
+    return;
+  }
+  if (op == LM_OP_SINGLE_PREP) {
+    if (tid == 0) {
+      const StartInfo &I = start[prob];
+      S.is_scale = mode;
+      S.status = ST_RUNNING;
+      S.lvl = I.lvl;
+      make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff, nullptr);
+    }
+    return;
+  }
+
+  const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
+  if (!active) { // block-uniform
+    if (tid == 0 && status_out) {
       status_out[2 * prob] = S.status;
       status_out[2 * prob + 1] = S.lvl;
     }
+    return;
+  }
+  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(T.lv[lvl].n), tid, sh);
+  __syncthreads();
+  if (tid >= 64) return; // wave 0 carries on
+  reduce_partials_final(lane, sh);
+
+  if (op == LM_OP_SINGLE_FINISH) {
+    const double *sums = sh.sums;
+    const long long *isums = sh.isums;
+    double rs[6];
+    build_rs(sums, isums, rs);
+    const int n_warped = (int)isums[2];
+    const int n4 = (n_warped + 3) & ~3;
+    const int r = lane >> 3, c = lane & 7;
+    SingleOut &O = single_out[prob];
+    if (pose_like) {
+      O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
+      if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
+    }
+    if (lane == 0) {
+      for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
+      O.n_warped = n4;
+      if (pose_like) {
+        O.Hs = O.bs = 0;
+      } else {
+        O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
+        O.bs = (float)sums[1] * (1.0f / n4);
+      }
+      S.status = ST_IDLE;
+    }
+    return;
+  }
+
+
+  lm_step_wave0(mode, lvl, T, S, sh, lane, nullptr);
+  if (lane == 0 && status_out) {
+    status_out[2 * prob] = S.status;
+    status_out[2 * prob + 1] = S.lvl;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// coarse_kernel: the whole LM loop of the small pyramid levels inside ONE launch.
+// One 1024-thread workgroup per problem keeps evaluating (4 chunks at a time, each by a 256-thread
+// group running exactly the code of eval_kernel), reducing (same fixed order, partials in LDS) and
+// stepping the state machine until the problem reaches a level with more than kCoarseMaxPts
+// template points (left to the launch-per-step path) or terminates.  Same arithmetic, same
+// summation order, hence bit-identical results to the launch-per-step path; what disappears is
+// ~80 % of the kernel launches of a track (the coarse levels need the most LM iterations and have
+// the least work per iteration).
+// ------------------------------------------------------------------------------------------
+constexpr int kCoarseThreads = 512;
+constexpr int kCoarseGroups = kCoarseThreads / 256;
+constexpr int kCoarseMaxPts = 32768;
+constexpr int kCoarseMaxChunks = 32; // 32768 points / (256 threads * 4 points)
+
+template <int MODE, int LAYOUT>
+__global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev *const *__restrict__ trackers,
+                                                                LMState *__restrict__ states, int *__restrict__ status_out,
+                                                                int max_pts) {
+  const int prob = blockIdx.x;
+  const int tid = threadIdx.x;
+  const TrackerDev &T = *trackers[prob];
+  LMState &S = states[prob];
+  __shared__ LmShared sh;
+  __shared__ float red[kCoarseGroups][16][kNumSlots];
+  __shared__ __attribute__((aligned(16))) float part[kCoarseMaxChunks][kPartialStride];
+  __shared__ EvalIn s_in;
+  __shared__ int s_ctrl[2];
+  if (tid == 0) {
+    s_ctrl[0] = (S.is_scale == MODE) ? S.status : ST_IDLE;
+    s_ctrl[1] = S.lvl;
+    s_in = S.in;
+  }
+  __syncthreads();
+  const int vb = tid >> 8, t256 = tid & 255;
+  for (;;) {
+    const int status = s_ctrl[0], lvl = s_ctrl[1];
+    const int n = s_in.n;
+    if (status != ST_RUNNING || n > max_pts) break; // workgroup-uniform
+    // wave-uniform evaluation inputs: LDS -> SGPRs
+    EvalConsts c;
+    {
+      auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      const unsigned long long pp = (unsigned long long)s_in.pts, ip = (unsigned long long)s_in.img;
+      c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
+      c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
+      c.n = __builtin_amdgcn_readfirstlane(n);
+      c.w = __builtin_amdgcn_readfirstlane(s_in.w);
+      c.h = __builtin_amdgcn_readfirstlane(s_in.h);
+      c.fx = rf(s_in.fx), c.fy = rf(s_in.fy), c.cx = rf(s_in.cx), c.cy = rf(s_in.cy), c.huber = rf(s_in.huber);
+#pragma unroll
+      for (int i = 0; i < 9; i++) c.Ki[i] = rf(s_in.Ki[i]), c.M[i] = rf(s_in.M[i]);
+      c.t[0] = rf(s_in.t[0]), c.t[1] = rf(s_in.t[1]), c.t[2] = rf(s_in.t[2]);
+      c.aff0 = rf(s_in.aff0), c.aff1 = rf(s_in.aff1), c.b0 = rf(s_in.b0), c.scale = rf(s_in.scale);
+      c.cutoff = rf(s_in.cutoff), c.max_energy = rf(s_in.max_energy);
+    }
+    const int nch = num_chunks(c.n);
+    for (int c0 = 0; c0 < nch; c0 += kCoarseGroups) {
+      const int chunk = c0 + vb;
+      const bool active = chunk < nch;
+      if (lvl == 0)
+        eval_chunk<MODE, LAYOUT, true>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
+      else
+        eval_chunk<MODE, LAYOUT, false>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
+      __syncthreads(); // red[] is reused by the next round
+    }
+    reduce_partials_groups(&part[0][0], nch, tid, sh);
+    __syncthreads();
+    if (tid < 64) {
+      reduce_partials_final(tid, sh);
+      lm_step_wave0(MODE, lvl, T, S, sh, tid, &s_in);
+      if (tid == 0) {
+        // lane 0 wrote status / lvl with plain stores: drain them, then read back past the L1
+        __builtin_amdgcn_s_waitcnt(0);
+        s_ctrl[0] = __hip_atomic_load(&S.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctrl[1] = __hip_atomic_load(&S.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && status_out) {
+    status_out[2 * prob] = S.status;
+    status_out[2 * prob + 1] = S.lvl;
+  }
+}
+
+void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const TrackerDev *const *trackers, LMState *states,
+                   int *status_out, int max_pts) {
+  if (max_pts > kCoarseMaxPts) max_pts = kCoarseMaxPts;
+  dim3 grid(nprob), block(kCoarseThreads);
+#define DSM_COARSE(M)                                                                                                 \
+  if (layout == IMG_AOS3)                                                                                             \
+    hipLaunchKernelGGL((coarse_kernel<M, IMG_AOS3>), grid, block, 0, s, trackers, states, status_out, max_pts);             \
+  else                                                                                                                \
+    hipLaunchKernelGGL((coarse_kernel<M, IMG_AOS4>), grid, block, 0, s, trackers, states, status_out, max_pts);
+  if (mode == 0) {
+    DSM_COARSE(0)
+  } else if (mode == 1) {
+    DSM_COARSE(1)
+  } else {
+    DSM_COARSE(2)
+  }
+#undef DSM_COARSE
+}
+int coarse_max_points() { return kCoarseMaxPts; }
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,

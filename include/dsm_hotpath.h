@@ -67,6 +67,10 @@ typedef struct dsm_params {
   int adaptive_schedule;              /* 1 (default): speculative per-level launch counts learnt from previous calls, one
                                          host read-back per pass; 0: enqueue the worst case (2*(7+max_iterations) launch
                                          pairs per level) and never poll.  Scheduling only -- results are identical. */
+  int persistent_coarse;              /* N > 0: pyramid levels with at most min(N, 32768) template points run their whole
+                                         LM loop inside one kernel launch per problem; 0 (default): one (evaluate, step)
+                                         launch pair per LM evaluation at every level.  Scheduling only -- results are
+                                         bit-identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
@@ -77,6 +81,7 @@ typedef struct dsm_stats {
   double eval_kernel_ms[DSM_MAX_LEVELS];/* HIP-event time of the eval kernels per level (only when timing enabled) */
   double total_ms;                      /* HIP-event time of the whole call */
   int64_t polls;                        /* host read-backs of the device LM state (passes) */
+  int64_t coarse_launches;              /* launches of the persistent small-level kernel */
 } dsm_stats;
 
 const char *dsm_last_error(void);
