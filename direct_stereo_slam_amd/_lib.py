@@ -66,6 +66,7 @@ SYMBOLS = {
     "dsm_context_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "dsm_context_stream": (_vp, [_vp]),
     "dsm_diag_read_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, c_double_p]),
+    "dsm_diag_read_bandwidth_chunked": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_int, c_double_p]),
     "dsm_tracker_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p, c_float_p, C.POINTER(Params), C.POINTER(_vp)]),
     "dsm_tracker_destroy": (C.c_int, [_vp]),
     "dsm_tracker_make_k": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -44,7 +44,7 @@ struct ParamsDev {
 };
 
 // Read-only (during track / optimize_scale) description of one TrackerAndScaler.
-struct TrackerDev {
+struct alignas(16) TrackerDev {
   LevelDev lv[DSM_MAX_LEVELS];
   ParamsDev p;
   int nlevels;
@@ -79,7 +79,7 @@ enum LMStatus { ST_IDLE = 0, ST_RUNNING = 1, ST_GOOD = 2, ST_ABORTED = 3, ST_BAD
 
 // Per-problem state of the Levenberg-Marquardt driver (trackNewestCoarse :451-638 /
 // optimizeScale :854-964), resident in device memory for the whole call.
-struct LMState {
+struct alignas(16) LMState {
   int status, lvl, phase, iteration;
   int have_repeated, coarsest, is_scale /* problem kind: 0 pose, 1 scale, 2 loop-closure pose (3-D points) */, pad0;
   float lambda, level_cutoff_repeat;

@@ -1,5 +1,6 @@
 // lm_math.hpp -- double precision device math of the LM drivers: Sophus SE3 exp / product,
-// Eigen quaternion->rotation, Eigen pivoted LDLT solve, DSO AffLight::fromToVecExposure.
+// Eigen quaternion->rotation, DSO AffLight::fromToVecExposure (the pivoted LDLT solve is wave-parallel
+// and lives in tracker_kernels.hip).
 // These are the un-vendored third-party pieces the reference calls at
 // TrackerAndScaler.cpp:509-534 (ldlt().solve), :551 (SE3::exp, operator*), :715/:1023
 // (rotationMatrix), :647-649/:717-720 (fromToVecExposure); restated from their published
@@ -72,21 +73,38 @@ __device__ inline void se3_mul(const double a[7], const double b[7], double out[
   out[6] = a[6] + r[2];
 }
 
-// Sophus SE3::exp, tangent = [upsilon ; omega]
-__device__ inline void se3_exp(const double xi[6], double pose[7]) {
+// value of `v` in lane `l` (wave-uniform l): v_readlane, no LDS round trip
+__device__ __forceinline__ double lane_value_d(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Sophus SE3::exp, tangent = [upsilon ; omega], executed by a whole wave on wave-uniform input: lanes 0
+// and 1 evaluate sincos(theta/2) and sincos(theta) side by side, everything else is computed redundantly
+// by all lanes.
+__device__ inline void se3_exp_wave(const double xi[6], double pose[7], int lane) {
   const double *ups = xi, *om = xi + 3;
   const double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
   const double theta = sqrt(theta_sq);
   const double half = 0.5 * theta;
   double imag, real;
   const double eps = 1e-10;
+  double s_half = 0, c_half = 1, s_th = 0, c_th = 1;
+  if (!(theta < eps)) {
+    double sv, cv;
+    sincos((lane & 1) ? theta : half, &sv, &cv);
+    s_half = lane_value_d(sv, 0), c_half = lane_value_d(cv, 0);
+    s_th = lane_value_d(sv, 1), c_th = lane_value_d(cv, 1);
+  }
   if (theta < eps) {
     const double t2 = theta * theta, t4 = t2 * t2;
     imag = 0.5 - (1.0 / 48.0) * t2 + (1.0 / 3840.0) * t4;
     real = 1.0 - 0.5 * t2 + (1.0 / 384.0) * t4;
   } else {
-    imag = sin(half) / theta;
-    real = cos(half);
+    imag = s_half / theta;
+    real = c_half;
   }
   double q[4] = {imag * om[0], imag * om[1], imag * om[2], real};
   quat_normalize(q);
@@ -101,8 +119,8 @@ __device__ inline void se3_exp(const double xi[6], double pose[7]) {
 #pragma unroll
       for (int j = 0; j < 3; j++)
         O2[i * 3 + j] = O[i * 3 + 0] * O[0 * 3 + j] + O[i * 3 + 1] * O[1 * 3 + j] + O[i * 3 + 2] * O[2 * 3 + j];
-    const double ca = (1.0 - cos(theta)) / theta_sq;
-    const double cb = (theta - sin(theta)) / (theta_sq * theta);
+    const double ca = (1.0 - c_th) / theta_sq;
+    const double cb = (theta - s_th) / (theta_sq * theta);
 #pragma unroll
     for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + ca * O[i] + cb * O2[i];
   }
@@ -130,97 +148,6 @@ __device__ inline void mat3f_mul(const float *a, const float *b, float *o) {
 #pragma unroll
     for (int j = 0; j < 3; j++)
       o[i * 3 + j] = (a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j]) + a[i * 3 + 2] * b[2 * 3 + j];
-}
-
-// Eigen LDLT<Lower> with diagonal pivoting + solve.  A (n x n, leading dimension 8) lives in
-// LDS or scratch; only the lower triangle is referenced.  x = solution of A x = rhs.
-__device__ inline void ldlt_solve(int n, double *A, const double *rhs, double *x) {
-  double temp[8];
-  int tr[8];
-#define A_(i, j) A[(i) * 8 + (j)]
-  bool all_zero = false;
-  for (int k = 0; k < n; k++) {
-    int big = k;
-    double bigv = fabs(A_(k, k));
-    for (int i = k + 1; i < n; i++) {
-      const double v = fabs(A_(i, i));
-      if (v > bigv) {
-        bigv = v;
-        big = i;
-      }
-    }
-    tr[k] = big;
-    if (k != big) {
-      for (int j = 0; j < k; j++) {
-        const double s = A_(k, j);
-        A_(k, j) = A_(big, j);
-        A_(big, j) = s;
-      }
-      for (int i = big + 1; i < n; i++) {
-        const double s = A_(i, k);
-        A_(i, k) = A_(i, big);
-        A_(i, big) = s;
-      }
-      {
-        const double s = A_(k, k);
-        A_(k, k) = A_(big, big);
-        A_(big, big) = s;
-      }
-      for (int i = k + 1; i < big; i++) {
-        const double s = A_(i, k);
-        A_(i, k) = A_(big, i);
-        A_(big, i) = s;
-      }
-    }
-    const int rs = n - k - 1;
-    if (k > 0) {
-      for (int j = 0; j < k; j++) temp[j] = A_(j, j) * A_(k, j);
-      double dot = 0;
-      for (int j = 0; j < k; j++) dot += A_(k, j) * temp[j];
-      A_(k, k) -= dot;
-      for (int i = 0; i < rs; i++) {
-        double s = 0;
-        for (int j = 0; j < k; j++) s += A_(k + 1 + i, j) * temp[j];
-        A_(k + 1 + i, k) -= s;
-      }
-    }
-    const double akk = A_(k, k);
-    const bool valid = fabs(akk) > 0.0;
-    if (k == 0 && !valid) {
-      all_zero = true;
-      break;
-    }
-    if (rs > 0 && valid)
-      for (int i = 0; i < rs; i++) A_(k + 1 + i, k) /= akk;
-  }
-  if (all_zero) {
-    for (int i = 0; i < n; i++) x[i] = 0;
-    return;
-  }
-  for (int i = 0; i < n; i++) x[i] = rhs[i];
-  for (int k = 0; k < n; k++) {
-    const double s = x[k];
-    x[k] = x[tr[k]];
-    x[tr[k]] = s;
-  }
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < i; j++) x[i] -= A_(i, j) * x[j];
-  const double tol = 1.0 / 1.7976931348623157e308;
-  for (int i = 0; i < n; i++) {
-    const double d = A_(i, i);
-    if (fabs(d) > tol)
-      x[i] /= d;
-    else
-      x[i] = 0;
-  }
-  for (int i = n - 1; i >= 0; i--)
-    for (int j = i + 1; j < n; j++) x[i] -= A_(j, i) * x[j];
-  for (int k = n - 1; k >= 0; k--) {
-    const double s = x[k];
-    x[k] = x[tr[k]];
-    x[tr[k]] = s;
-  }
-#undef A_
 }
 
 } // namespace dsm

@@ -21,6 +21,15 @@
 // DSM_ABLATE: developer-only ablation switches for roofline diagnosis (never set in the shipped
 // build): 1 = drop the 45-entry accumulation, 2 = gather all taps from one texel, 4 = read all
 // template points from one address.
+#ifdef DSM_LM_PROFILE // developer-only: 100 MHz clock stamps of an LM step, printed by problem 0
+__shared__ unsigned long long lm_prof[16];
+#define LM_STAMP(i)                                                                                                    \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0) lm_prof[i] = wall_clock64();                                                                 \
+  } while (0)
+#else
+#define LM_STAMP(i)
+#endif
 #ifndef DSM_ABLATE
 #define DSM_ABLATE 0
 #endif
@@ -507,7 +516,7 @@ void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int n
 // ------------------------------------------------------------------------------------------
 constexpr int kLmThreads = 256;
 
-__device__ void make_eval_pose(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7],
+__device__ __forceinline__ void make_eval_pose(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7],
                                const double aff[2], float cutoff) {
   double Rd[9];
   quat_to_rot(pose, Rd);
@@ -550,7 +559,7 @@ __device__ void make_eval_pose(const TrackerDev &T, EvalIn &e, int lvl, const do
   e.max_energy = 2 * h * cutoff - h * h; // :726-728
 }
 
-__device__ void make_eval_scale(const TrackerDev &T, EvalIn &e, int lvl, float scale, float cutoff) {
+__device__ __forceinline__ void make_eval_scale(const TrackerDev &T, EvalIn &e, int lvl, float scale, float cutoff) {
   double Rd[9];
   quat_to_rot(T.T10, Rd);
   float Rf[9];
@@ -592,7 +601,7 @@ __device__ void make_eval_scale(const TrackerDev &T, EvalIn &e, int lvl, float s
 
 // loop-closure pose (PoseEstimator::calcRes, PoseEstimator.cpp:155-163): M = R (no K^-1), reference
 // affine parameters (0,0) (:317), exposure handed over by the caller
-__device__ void make_eval_points3d(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7], const double aff[2],
+__device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7], const double aff[2],
                                    float cutoff) {
   double Rd[9];
   quat_to_rot(pose, Rd);
@@ -625,10 +634,10 @@ __device__ void make_eval_points3d(const TrackerDev &T, EvalIn &e, int lvl, cons
   e.huber = T.p.huber_th;
 }
 
-// lane 0 only.  Builds the inputs of the next evaluation, stores them in the problem state and -- inside the
-// persistent coarse kernel -- in the workgroup's LDS mirror, from which all waves read them.
-__device__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
-                              float scale, float cutoff, EvalIn *mirror) {
+// Builds the inputs of the next evaluation and (store) writes them to the problem state: called by lane 0
+// alone, or by a whole wave with wave-uniform arguments and store = (lane == 0).
+__device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
+                              float scale, float cutoff, bool store = true) {
   EvalIn e;
   if (mode == 1)
     make_eval_scale(T, e, lvl, scale, cutoff);
@@ -636,22 +645,21 @@ __device__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl
     make_eval_points3d(T, e, lvl, pose, aff, cutoff);
   else
     make_eval_pose(T, e, lvl, pose, aff, cutoff);
-  S.in = e;
-  if (mirror) *mirror = e;
+  if (store) S.in = e;
 }
 
 // lane 0 only
-__device__ void begin_level(const TrackerDev &T, LMState &S, int lvl, EvalIn *mirror) {
+__device__ __forceinline__ void begin_level(const TrackerDev &T, LMState &S, int lvl) {
   S.lvl = lvl;
   S.phase = PH_INIT;
   S.iteration = 0;
   S.level_cutoff_repeat = 1.0f;
   const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-  make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff, mirror);
+  make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
 }
 
 // Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
-__device__ void build_rs(const double *sums, const long long *isums, double rs[6]) {
+__device__ __forceinline__ void build_rs(const double *sums, const long long *isums, double rs[6]) {
   const float E = (float)sums[kSlotE];
   const float sT = (float)sums[kSlotFlowT], sRT = (float)sums[kSlotFlowRT], sN = (float)sums[kSlotFlowNum];
   const int n_terms = (int)isums[0], n_sat = (int)isums[1];
@@ -688,31 +696,39 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
 // Returns x_r (replicated along the row).  Same pivot order and the same operations as the
 // textbook (left-looking) form the oracle restates; only the order of the subtractions inside one
 // Schur-complement entry differs (round-off in the last bits of a double).
-__device__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
+// value of `v` in lane `idx` (any per-lane index): ds_bpermute
+__device__ __forceinline__ double permute_d(double v, int idx) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(idx << 2, (int)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(idx << 2, (int)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
   const int r = lane >> 3, c = lane & 7;
-  unsigned done = ~active & 0xFFu;
+  unsigned done = ~active & 0xFFu; // wave-uniform
   int order[8];
   bool all_zero = false;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    double best = -1.0;
-    int p = -1;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const double d = fabs(__shfl(a, 9 * i, 64));
-      const bool cand = !((done >> i) & 1u) && d > best; // strict >: first maximum wins (Eigen maxCoeff)
-      best = cand ? d : best;
-      p = cand ? i : p;
-    }
+    // pivot = first maximum of |diagonal| over the rows not yet eliminated (Eigen: maxCoeff of the
+    // remaining diagonal).  Lane (r,c) tests "candidate c beats r"; a row nobody beats wins.
+    const double dR = fabs(permute_d(a, 9 * r)), dC = fabs(permute_d(a, 9 * c));
+    const bool live_r = !((done >> r) & 1u), live_c = !((done >> c) & 1u);
+    const bool beats = live_c && (dC > dR || (dC == dR && c < r));
+    const unsigned long long m = __ballot(beats);
+    const bool row_beaten = ((m >> (8 * r)) & 0xFFull) != 0;
+    const unsigned long long w = __ballot(live_r && dR == dR && !row_beaten && c == 0);
+    const int p = w ? (__builtin_ctzll(w) >> 3) : -1; // wave-uniform
     order[k] = p;
-    if (p >= 0) { // wave-uniform
-      const double dp = __shfl(a, 9 * p, 64);
-      const double arow = __shfl(a, 8 * p + c, 64);
-      const double acol = __shfl(a, 8 * r + p, 64);
+    if (p >= 0) {
+      const double dp = lane_value_d(a, 9 * p);
+      const double arow = permute_d(a, 8 * p + c);
+      const double acol = permute_d(a, 8 * r + p);
       const bool valid = fabs(dp) > 0.0;
       if (k == 0 && !valid) all_zero = true;
-      const bool r_live = !((done >> r) & 1u) && r != p;
-      const bool c_live = !((done >> c) & 1u) && c != p;
+      const bool r_live = live_r && r != p;
+      const bool c_live = live_c && c != p;
       const double l = valid ? acol / dp : acol;
       if (r_live && c_live) a = a - l * arow;
       if (r_live && c == p) a = l; // keep L in the pivot column
@@ -725,15 +741,15 @@ __device__ double wave_ldlt_solve(double a, double y, unsigned active, int lane)
   for (int k = 0; k < 8; k++) {
     const int p = order[k];
     if (p >= 0) {
-      const double yp = __shfl(y, 8 * p, 64);
-      const double l = __shfl(a, 8 * r + p, 64);
+      const double yp = lane_value_d(y, 8 * p);
+      const double l = permute_d(a, 8 * r + p);
       fdone |= 1u << p;
       if (!((fdone >> r) & 1u)) y = y - l * yp;
     }
   }
   // D^-1 with Eigen's tolerance 1/highest
   {
-    const double d = __shfl(a, 9 * r, 64);
+    const double d = permute_d(a, 9 * r);
     const double tol = 1.0 / 1.7976931348623157e308;
     y = fabs(d) > tol ? y / d : 0.0;
   }
@@ -747,8 +763,8 @@ __device__ double wave_ldlt_solve(double a, double y, unsigned active, int lane)
     const int p = order[k];
     if (p >= 0) {
       before &= ~(1u << p);
-      const double xp = __shfl(y, 8 * p, 64);
-      const double l = __shfl(a, 8 * p + r, 64); // L[p][r], r eliminated before p
+      const double xp = lane_value_d(y, 8 * p);
+      const double l = permute_d(a, 8 * p + r); // L[p][r], r eliminated before p
       if ((before >> r) & 1u) y = y - l * xp;
     }
   }
@@ -757,7 +773,7 @@ __device__ double wave_ldlt_solve(double a, double y, unsigned active, int lane)
 }
 
 // lane 0 only: :612-637
-__device__ void finish_track(const TrackerDev &T, LMState &S) {
+__device__ __forceinline__ void finish_track(const TrackerDev &T, LMState &S) {
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   int status = ST_GOOD;
   if ((modeA != 0 && (__builtin_fabsf((float)S.aff_cur[0]) > 1.2)) ||
@@ -779,7 +795,7 @@ __device__ void finish_track(const TrackerDev &T, LMState &S) {
 
 // whole wave: solve + propose for the pose problem (:505-554).  h = H(r,c) of this lane,
 // bneg = -b(r) replicated along the row.
-__device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane, EvalIn *mirror) {
+__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane) {
   const int r = lane >> 3, c = lane & 7;
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   double a = h;
@@ -798,16 +814,19 @@ __device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double b
     a = __shfl(a, 8 * mr + mc, 64);
     y = __shfl(y, 8 * mr, 64);
   }
+  LM_STAMP(4);
   const double x = wave_ldlt_solve(a, y, active, lane);
+  LM_STAMP(5);
   // gather the 8 increments into every lane (row r's value sits in lanes 8r..8r+7)
   double inc[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) inc[i] = __shfl(x, 8 * i, 64);
+  for (int i = 0; i < 8; i++) inc[i] = lane_value_d(x, 8 * i);
   if (stitch) {
     inc[7] = inc[6];
     inc[6] = 0;
   }
-  if (lane != 0) return;
+  // From here on every lane computes the same (wave-uniform) values; lane 0 stores them.  The two
+  // sincos evaluations of SE3::exp run side by side in lanes 0 and 1.
   float extrapFac = 1; // :536-539
   const float lim = T.p.lambda_extrapolation_limit;
   if (lambda < lim) extrapFac = sqrtf(sqrtf(lim / lambda));
@@ -826,23 +845,27 @@ __device__ void propose_pose(const TrackerDev &T, LMState &S, double h, double b
   double ex[7], cur[7], cand[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) cur[i] = S.cur[i];
-  se3_exp(incScaled, ex);
+  se3_exp_wave(incScaled, ex, lane);
   se3_mul(ex, cur, cand); // :550-551
-#pragma unroll
-  for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
   double aff_cand[2] = {S.aff_cur[0] + incScaled[6], S.aff_cur[1] + incScaled[7]};
-  S.aff_cand[0] = aff_cand[0];
-  S.aff_cand[1] = aff_cand[1];
   double nrm = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
-  S.inc_norm = sqrt(nrm);
-  S.phase = PH_ITER;
-  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, mirror);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
+    S.aff_cand[0] = aff_cand[0];
+    S.aff_cand[1] = aff_cand[1];
+    S.inc_norm = sqrt(nrm);
+    S.phase = PH_ITER;
+  }
+  LM_STAMP(6);
+  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0);
+  LM_STAMP(7);
 }
 
 // lane 0 only: :897-913
-__device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda, EvalIn *mirror) {
+__device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
   float Hl = S.Hs;
   Hl *= (1 + lambda);
   float inc = -S.bs / Hl;
@@ -854,11 +877,11 @@ __device__ void propose_scale(const TrackerDev &T, LMState &S, float lambda, Eva
   S.inc_f = inc;
   S.scale_cand = S.scale_cur + inc;
   S.phase = PH_ITER;
-  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, mirror);
+  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
 }
 
 // lane 0 only
-__device__ void end_level(const TrackerDev &T, LMState &S, EvalIn *mirror) {
+__device__ __forceinline__ void end_level(const TrackerDev &T, LMState &S) {
   const int lvl = S.lvl;
   S.last_residuals[lvl] = sqrtf((float)(S.res_old[0] / S.res_old[1])); // :596 / :945
   S.last_inners[lvl] = S.res_old[1];                                     // PoseEstimator.cpp:463
@@ -883,7 +906,7 @@ __device__ void end_level(const TrackerDev &T, LMState &S, EvalIn *mirror) {
       finish_track(T, S); // the same affine plausibility checks end PoseEstimator::estimate (:470-482)
     return;
   }
-  begin_level(T, S, next, mirror);
+  begin_level(T, S, next);
 }
 
 // LDS workspace of the partial reduction / LM step (lm_kernel and coarse_kernel)
@@ -892,7 +915,29 @@ struct LmShared {
   long long pisum[19][4];
   double sums[kNumSlots];
   long long isums[4];
+  // The problem's LMState and its tracker descriptor are staged here for the duration of a step
+  // (lm_kernel) or of the whole small-level loop (coarse_kernel): the state machine then runs on LDS
+  // latencies instead of a chain of dependent global-memory round trips.
+  __attribute__((aligned(16))) LMState st;
+  __attribute__((aligned(16))) TrackerDev trk;
 };
+static_assert(sizeof(LMState) % 16 == 0 && sizeof(TrackerDev) % 16 == 0, "staged with 16-byte copies");
+
+// 16-byte block copies between global memory and LDS by `nthreads` threads
+template <class T>
+__device__ __forceinline__ void stage_in(T &dst_lds, const T *src_global, int tid, int nthreads) {
+  constexpr int n16 = sizeof(T) / 16;
+  const uint4 *src = (const uint4 *)src_global;
+  uint4 *dst = (uint4 *)&dst_lds;
+  for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+}
+template <class T>
+__device__ __forceinline__ void stage_out(T *dst_global, const T &src_lds, int tid, int nthreads) {
+  constexpr int n16 = sizeof(T) / 16;
+  const uint4 *src = (const uint4 *)&src_lds;
+  uint4 *dst = (uint4 *)dst_global;
+  for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+}
 
 // ---- fixed-order reduction over the chunk partials (double / int64), first 247 threads of the
 // workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
@@ -949,7 +994,7 @@ __device__ __forceinline__ void reduce_partials_final(int lane, LmShared &sh) {
 }
 
 // One step of the LM state machine by wave 0 (all 64 lanes; lane 0 writes the state).
-__device__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane, EvalIn *mirror) {
+__device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane) {
   const bool pose_like = mode != 1;
   const double *sums = sh.sums;
   const long long *isums = sh.isums;
@@ -971,7 +1016,7 @@ __device__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S
         S.evals[lvl]++;
         S.level_cutoff_repeat *= 2;
         const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff, mirror);
+        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
       }
     } else {
       if (pose_like) {
@@ -1042,13 +1087,17 @@ __device__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  LM_STAMP(4);
+  LM_STAMP(5);
+  LM_STAMP(6);
+  LM_STAMP(7);
   if (do_propose) {
     if (pose_like)
-      propose_pose(T, S, h, bneg, lambda_next, lane, mirror);
+      propose_pose(T, S, h, bneg, lambda_next, lane);
     else if (lane == 0)
-      propose_scale(T, S, lambda_next, mirror);
+      propose_scale(T, S, lambda_next);
   }
-  if (lane == 0 && level_done) end_level(T, S, mirror);
+  if (lane == 0 && level_done) end_level(T, S);
 }
 
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
@@ -1087,7 +1136,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       }
       S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
       S.status = ST_RUNNING;
-      begin_level(T, S, I.coarsest, nullptr);
+      begin_level(T, S, I.coarsest);
       if (status_out) {
         status_out[2 * prob] = S.status;
         status_out[2 * prob + 1] = S.lvl;
@@ -1101,11 +1150,20 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       S.is_scale = mode;
       S.status = ST_RUNNING;
       S.lvl = I.lvl;
-      make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff, nullptr);
+      make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff);
     }
     return;
   }
 
+  // ---- LM_OP_STEP / LM_OP_SINGLE_FINISH ----
+  LM_STAMP(0);
+  // first round trip: the state block (into registers), the activity test and the chunk count
+  constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
+  static_assert(kS16 <= kLmThreads && kT16 <= kLmThreads, "one 16-byte block per thread");
+  uint4 sv = {0, 0, 0, 0};
+  if (tid < kS16) sv = ((const uint4 *)&S)[tid];
+  const TrackerDev *Tg = trackers[prob];
+  const int n_lvl = S.in.n; // the pending evaluation was built for this level
   const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
   if (!active) { // block-uniform
     if (tid == 0 && status_out) {
@@ -1114,10 +1172,20 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     }
     return;
   }
-  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(T.lv[lvl].n), tid, sh);
+  if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
+  LM_STAMP(1);
+  // second round trip: tracker descriptor and the chunk partials, together
+  uint4 tv = {0, 0, 0, 0};
+  if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
+  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(n_lvl), tid, sh);
+  if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
   __syncthreads();
+  LM_STAMP(2);
   if (tid >= 64) return; // wave 0 carries on
   reduce_partials_final(lane, sh);
+  LM_STAMP(3);
+  const TrackerDev &Ts = sh.trk;
+  LMState &Ss = sh.st;
 
   if (op == LM_OP_SINGLE_FINISH) {
     const double *sums = sh.sums;
@@ -1129,8 +1197,8 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     const int r = lane >> 3, c = lane & 7;
     SingleOut &O = single_out[prob];
     if (pose_like) {
-      O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
-      if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
+      O.H[lane] = build_H_elem(Ts.p, sums, n4, r, c);
+      if (lane < 8) O.b[lane] = build_b_elem(Ts.p, sums, n4, lane);
     }
     if (lane == 0) {
       for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
@@ -1146,20 +1214,34 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     return;
   }
 
-
-  lm_step_wave0(mode, lvl, T, S, sh, lane, nullptr);
+  lm_step_wave0(mode, lvl, Ts, Ss, sh, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  LM_STAMP(8);
+  stage_out(&S, Ss, lane, 64);
   if (lane == 0 && status_out) {
-    status_out[2 * prob] = S.status;
-    status_out[2 * prob + 1] = S.lvl;
+    status_out[2 * prob] = Ss.status;
+    status_out[2 * prob + 1] = Ss.lvl;
   }
+#ifdef DSM_LM_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  LM_STAMP(9);
+  if (lane == 0 && prob == 0)
+    printf("LMPROF lvl %d: load %llu reduce %llu final %llu decide %llu ldlt %llu se3 %llu mkeval %llu end %llu out %llu (x10ns)\n", lvl,
+           lm_prof[1] - lm_prof[0], lm_prof[2] - lm_prof[1], lm_prof[3] - lm_prof[2], lm_prof[4] - lm_prof[3],
+           lm_prof[5] - lm_prof[4], lm_prof[6] - lm_prof[5], lm_prof[7] - lm_prof[6], lm_prof[8] - lm_prof[7],
+           lm_prof[9] - lm_prof[8]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
 // coarse_kernel: the whole LM loop of the small pyramid levels inside ONE launch.
 // One 1024-thread workgroup per problem keeps evaluating (4 chunks at a time, each by a 256-thread
 // group running exactly the code of eval_kernel), reducing (same fixed order, partials in LDS) and
-// stepping the state machine until the problem reaches a level with more than kCoarseMaxPts
-// template points (left to the launch-per-step path) or terminates.  Same arithmetic, same
+// stepping the state machine -- state and tracker descriptor staged in LDS for the whole loop --
+// until the problem reaches a level with more than max_pts template points (left to the
+// launch-per-step path) or terminates.  Same arithmetic, same
 // summation order, hence bit-identical results to the launch-per-step path; what disappears is
 // ~80 % of the kernel launches of a track (the coarse levels need the most LM iterations and have
 // the least work per iteration).
@@ -1175,42 +1257,40 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
                                                                 int max_pts) {
   const int prob = blockIdx.x;
   const int tid = threadIdx.x;
-  const TrackerDev &T = *trackers[prob];
   LMState &S = states[prob];
   __shared__ LmShared sh;
   __shared__ float red[kCoarseGroups][16][kNumSlots];
   __shared__ __attribute__((aligned(16))) float part[kCoarseMaxChunks][kPartialStride];
-  __shared__ EvalIn s_in;
-  __shared__ int s_ctrl[2];
-  if (tid == 0) {
-    s_ctrl[0] = (S.is_scale == MODE) ? S.status : ST_IDLE;
-    s_ctrl[1] = S.lvl;
-    s_in = S.in;
-  }
+  if (!(S.status == ST_RUNNING && S.is_scale == MODE)) return; // workgroup-uniform
+  stage_in(sh.st, &S, tid, kCoarseThreads);
+  stage_in(sh.trk, trackers[prob], tid, kCoarseThreads);
   __syncthreads();
+  const EvalIn &in = sh.st.in;
   const int vb = tid >> 8, t256 = tid & 255;
+  bool stepped = false;
   for (;;) {
-    const int status = s_ctrl[0], lvl = s_ctrl[1];
-    const int n = s_in.n;
+    const int status = sh.st.status, lvl = __builtin_amdgcn_readfirstlane(sh.st.lvl);
+    const int n = in.n;
     if (status != ST_RUNNING || n > max_pts) break; // workgroup-uniform
+    stepped = true;
     // wave-uniform evaluation inputs: LDS -> SGPRs
     EvalConsts c;
     {
       auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-      const unsigned long long pp = (unsigned long long)s_in.pts, ip = (unsigned long long)s_in.img;
+      const unsigned long long pp = (unsigned long long)in.pts, ip = (unsigned long long)in.img;
       c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
                                (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
       c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
                               (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
       c.n = __builtin_amdgcn_readfirstlane(n);
-      c.w = __builtin_amdgcn_readfirstlane(s_in.w);
-      c.h = __builtin_amdgcn_readfirstlane(s_in.h);
-      c.fx = rf(s_in.fx), c.fy = rf(s_in.fy), c.cx = rf(s_in.cx), c.cy = rf(s_in.cy), c.huber = rf(s_in.huber);
+      c.w = __builtin_amdgcn_readfirstlane(in.w);
+      c.h = __builtin_amdgcn_readfirstlane(in.h);
+      c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
 #pragma unroll
-      for (int i = 0; i < 9; i++) c.Ki[i] = rf(s_in.Ki[i]), c.M[i] = rf(s_in.M[i]);
-      c.t[0] = rf(s_in.t[0]), c.t[1] = rf(s_in.t[1]), c.t[2] = rf(s_in.t[2]);
-      c.aff0 = rf(s_in.aff0), c.aff1 = rf(s_in.aff1), c.b0 = rf(s_in.b0), c.scale = rf(s_in.scale);
-      c.cutoff = rf(s_in.cutoff), c.max_energy = rf(s_in.max_energy);
+      for (int i = 0; i < 9; i++) c.Ki[i] = rf(in.Ki[i]), c.M[i] = rf(in.M[i]);
+      c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
+      c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
+      c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
     }
     const int nch = num_chunks(c.n);
     for (int c0 = 0; c0 < nch; c0 += kCoarseGroups) {
@@ -1226,19 +1306,14 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
     __syncthreads();
     if (tid < 64) {
       reduce_partials_final(tid, sh);
-      lm_step_wave0(MODE, lvl, T, S, sh, tid, &s_in);
-      if (tid == 0) {
-        // lane 0 wrote status / lvl with plain stores: drain them, then read back past the L1
-        __builtin_amdgcn_s_waitcnt(0);
-        s_ctrl[0] = __hip_atomic_load(&S.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ctrl[1] = __hip_atomic_load(&S.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      lm_step_wave0(MODE, lvl, sh.trk, sh.st, sh, tid);
     }
-    __syncthreads();
+    __syncthreads(); // the state (status, level, next evaluation inputs) is read by all waves
   }
+  if (stepped) stage_out(&S, sh.st, tid, kCoarseThreads);
   if (tid == 0 && status_out) {
-    status_out[2 * prob] = S.status;
-    status_out[2 * prob + 1] = S.lvl;
+    status_out[2 * prob] = sh.st.status;
+    status_out[2 * prob + 1] = sh.st.lvl;
   }
 }
 

@@ -73,6 +73,12 @@ class Context:
         check(self.L.dsm_diag_read_bandwidth(self.h, nbytes, iters, C.byref(g)))
         return g.value
 
+    def read_bandwidth_chunked(self, nbytes=1 << 30, chunk_bytes=112 * 1024, iters=10):
+        """measurement aid: same, one contiguous chunk per workgroup (the eval kernels' access pattern)"""
+        g = C.c_double()
+        check(self.L.dsm_diag_read_bandwidth_chunked(self.h, nbytes, chunk_bytes, iters, C.byref(g)))
+        return g.value
+
     # ---- batched forms -----------------------------------------------------------------
     def track_batch(self, trackers, poses, affs, coarsest, min_res=None):
         n = len(trackers)

@@ -104,6 +104,9 @@ void *dsm_context_stream(dsm_context *ctx);
 /* measurement aid (no reference counterpart): read-only streaming bandwidth of the device in GB/s,
  * `bytes` per pass (choose > 256 MiB to defeat the Infinity Cache), `iters` timed passes */
 int dsm_diag_read_bandwidth(dsm_context *ctx, size_t bytes, int iters, double *gbps_out);
+/* same, but each workgroup streams its own contiguous chunk of `chunk_bytes` (the access pattern of the
+ * evaluation kernels) instead of all workgroups advancing through memory side by side */
+int dsm_diag_read_bandwidth_chunked(dsm_context *ctx, size_t bytes, size_t chunk_bytes, int iters, double *gbps_out);
 
 /* ---- TrackerAndScaler ---------------------------------------------------------------- */
 /* replaces TrackerAndScaler::TrackerAndScaler(w,h,tfm_vec,K1)  (TrackerAndScaler.cpp:47-109).
