@@ -34,6 +34,7 @@ class Params(C.Structure):
         ("max_iterations", C.c_int * MAX_LEVELS),
         ("adaptive_schedule", C.c_int),
         ("persistent_coarse", C.c_int),
+        ("fuse_lm", C.c_int),
     ]
 
 

@@ -67,6 +67,8 @@ int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride) {
   if ((rc = realloc_pinned(&ctx->h_single, cap))) return rc;
   if ((rc = realloc_dev(&ctx->d_status, 2 * (size_t)cap))) return rc;
   if ((rc = realloc_pinned(&ctx->h_status, 2 * (size_t)cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_tickets, cap))) return rc;
+  DSM_HIP(hipMemsetAsync(ctx->d_tickets, 0, sizeof(int) * cap, ctx->stream));
   DSM_HIP(hipMemsetAsync(ctx->d_states, 0, sizeof(LMState) * cap, ctx->stream));
   ctx->cap_prob = cap;
   ctx->partial_stride = ps;
@@ -173,6 +175,7 @@ void dsm_params_default(dsm_params *p) {
   memcpy(p->max_iterations, it, sizeof it);
   p->adaptive_schedule = 1;
   p->persistent_coarse = 0;
+  p->fuse_lm = 1;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -210,6 +213,7 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipFree(ctx->d_single);
   hipHostFree(ctx->h_single);
   hipFree(ctx->d_status);
+  hipFree(ctx->d_tickets);
   hipHostFree(ctx->h_status);
   hipFree(ctx->d_stage);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
@@ -613,12 +617,17 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
             ev_lvl.push_back(L);
             if (ea) DSM_HIP(hipEventRecord(ea, st));
           }
+          // levels >= 1: the eval kernel's last-arriving workgroup per problem performs the LM step itself
+          // (measured: -6 % latency for one frame in flight, -11 % throughput at 256 -- hence the batch rule)
+          const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n <= 8));
           launch_eval(st, mode, layout, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
-                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride);
+                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride,
+                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0);
           if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
-          launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
-                    ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr,
-                    ctx->d_status + 2 * g0);
+          if (!fused)
+            launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
+                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr,
+                      ctx->d_status + 2 * g0);
         }
       }
       ctx->stats.launches[L] += steps;
@@ -864,7 +873,7 @@ static int single_eval(dsm_tracker *t, int mode, int lvl, const double *pose, co
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_PREP, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, nullptr);
   launch_eval(ctx->stream, mode, t->desc.layout, lvl, round8(num_chunks(t->desc.lv[lvl].n) > 0 ? num_chunks(t->desc.lv[lvl].n) : 1), 1, ctx->d_tracker_ptrs,
-              ctx->d_states, ctx->d_partials, ctx->partial_stride);
+              ctx->d_states, ctx->d_partials, ctx->partial_stride, nullptr, nullptr);
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_FINISH, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, nullptr, ctx->d_single, nullptr);
   DSM_HIP(hipGetLastError());

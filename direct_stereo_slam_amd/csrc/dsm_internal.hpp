@@ -42,6 +42,7 @@ struct dsm_context {
   dsm::SingleOut *h_single = nullptr; // pinned
   int *d_status = nullptr;
   int *h_status = nullptr; // pinned
+  int *d_tickets = nullptr; // per-problem arrival counters of the fused eval+LM kernels (zero between launches)
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;

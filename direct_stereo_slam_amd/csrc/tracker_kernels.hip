@@ -140,6 +140,22 @@ struct EvalConsts {
   float aff0, aff1, b0, scale, cutoff, max_energy;
 };
 
+// Chunk partials are produced by one workgroup and consumed by another (the LM step), possibly on a
+// different XCD and -- in the fused eval+LM kernel -- inside the same launch: written and read with
+// device-scope accesses (write-through / L2-coherent), so no cache-wide write-back or invalidate is
+// ever needed for them.
+__device__ __forceinline__ void store_partial(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ fvec4 load_partial4(const float *p) {
+  const unsigned long long a = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  fvec4 v;
+  v.x = __uint_as_float((unsigned)a), v.y = __uint_as_float((unsigned)(a >> 32));
+  v.z = __uint_as_float((unsigned)b), v.w = __uint_as_float((unsigned)(b >> 32));
+  return v;
+}
+
 // One chunk of one evaluation by 256 threads (tid = 0..255 inside the chunk's thread group):
 // the per-point loop, the flow-indicator pass and the fixed-order reduction into the chunk's 52-slot
 // partial `out` (global memory in eval_kernel, LDS in coarse_kernel).  `red` is this thread group's
@@ -434,77 +450,12 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
     float s = red[0][tid];
 #pragma unroll
     for (int r = 1; r < 16; r++) s += red[r][tid];
-    out[tid] = s;
+    store_partial(out + tid, s);
   } else if (tid >= kSlotNTerms && tid < kNumSlots) {
     int s = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) s += __float_as_int(red[r][tid]);
-    out[tid] = __int_as_float(s);
-  }
-}
-
-// LVL0 = true is the level-0 instantiation (adds the flow indicators); it is also the dominant kernel
-// of the path and shows up under its own symbol in rocprofv3 kernel traces.
-template <int MODE, int LAYOUT, bool LVL0>
-__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
-                                                        const LMState *__restrict__ states,
-                                                        float *__restrict__ partials,
-                                                        int partial_stride, int lvl) {
-  const int prob = blockIdx.y;
-  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
-  const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
-  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
-  const DSM_GLOBAL EvalIn &in = S.in;
-  const int n = in.n;
-  const int P = pts_per_thread(n);
-  const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
-  // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
-  // contiguous band of the template (and therefore of the target rows it gathers from).
-  const int per_xcd = gridDim.x >> 3;
-  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (chunk >= nchunks) return;
-  EvalConsts c;
-  c.pts = in.pts, c.img = in.img, c.n = n, c.w = in.w, c.h = in.h;
-  c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
-#pragma unroll
-  for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
-  c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
-  c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
-  __shared__ float red[16][kNumSlots];
-  eval_chunk<MODE, LAYOUT, LVL0>(c, chunk, threadIdx.x, true, red,
-                                 partials + (size_t)prob * partial_stride + (size_t)chunk * kPartialStride);
-}
-
-template <int MODE, int LAYOUT>
-static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
-                           float *partials, int partial_stride) {
-  if (lvl == 0)
-    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl);
-  else
-    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl);
-}
-
-void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
-                 const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride) {
-  dim3 grid(grid_x, nprob);
-  if (mode == 0) {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<0, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
-    else
-      launch_eval_ml<0, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
-  } else if (mode == 2) {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<2, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
-    else
-      launch_eval_ml<2, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
-  } else {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<1, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride);
-    else
-      launch_eval_ml<1, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride);
+    store_partial(out + tid, __int_as_float(s));
   }
 }
 
@@ -707,7 +658,7 @@ __device__ __forceinline__ double permute_d(double v, int idx) {
 __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
   const int r = lane >> 3, c = lane & 7;
   unsigned done = ~active & 0xFFu; // wave-uniform
-  int order[8];
+  unsigned order = 0; // pivot of step k in bits 4k..4k+3, stored as p+1 (0 = no pivot): no indexed array
   bool all_zero = false;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -720,7 +671,7 @@ __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned a
     const bool row_beaten = ((m >> (8 * r)) & 0xFFull) != 0;
     const unsigned long long w = __ballot(live_r && dR == dR && !row_beaten && c == 0);
     const int p = w ? (__builtin_ctzll(w) >> 3) : -1; // wave-uniform
-    order[k] = p;
+    order |= (unsigned)(p + 1) << (4 * k);
     if (p >= 0) {
       const double dp = lane_value_d(a, 9 * p);
       const double arow = permute_d(a, 8 * p + c);
@@ -739,7 +690,7 @@ __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned a
   unsigned fdone = ~active & 0xFFu;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int p = order[k];
+    const int p = (int)((order >> (4 * k)) & 15u) - 1;
     if (p >= 0) {
       const double yp = lane_value_d(y, 8 * p);
       const double l = permute_d(a, 8 * r + p);
@@ -757,10 +708,10 @@ __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned a
   unsigned before = 0; // rows eliminated before the current pivot = all earlier pivots
 #pragma unroll
   for (int k = 0; k < 8; k++)
-    if (order[k] >= 0) before |= 1u << order[k];
+    if ((order >> (4 * k)) & 15u) before |= 1u << (((order >> (4 * k)) & 15u) - 1);
 #pragma unroll
   for (int k = 7; k >= 0; k--) {
-    const int p = order[k];
+    const int p = (int)((order >> (4 * k)) & 15u) - 1;
     if (p >= 0) {
       before &= ~(1u << p);
       const double xp = lane_value_d(y, 8 * p);
@@ -945,7 +896,6 @@ __device__ __forceinline__ void stage_out(T *dst_global, const T &src_lds, int t
 // thread.  `P` may point to global memory (lm_kernel) or LDS (coarse_kernel): same order, same sums.
 __device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, LmShared &sh) {
   constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
-  const fvec4 *P4 = (const fvec4 *)P;
   const int q = tid % kQuads, g = tid / kQuads;
   if (g < kGroups) {
     double sd[4] = {0, 0, 0, 0};
@@ -955,7 +905,7 @@ __device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, 
 #pragma unroll
       for (int j = 0; j < kRedBatch; j++) {
         const int cc = c0 + j * kGroups;
-        v[j] = cc < nch ? P4[(size_t)cc * (kPartialStride / 4) + q] : fvec4{0.f, 0.f, 0.f, 0.f};
+        v[j] = cc < nch ? load_partial4(P + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < kRedBatch; j++) {
@@ -1100,6 +1050,147 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   if (lane == 0 && level_done) end_level(T, S);
 }
 
+// One LM step by a workgroup of >= 256 threads on the problem's partials: state and tracker descriptor
+// staged through LDS, fixed-order reduction, wave 0 advances the state machine and writes the state
+// back.  Shared by lm_kernel (LM_OP_STEP) and by the last-arriving workgroup of a fused eval kernel.
+// All threads of the workgroup must call it; S must be at this level (status RUNNING, lvl, mode).
+__device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const TrackerDev *Tg, LMState &S,
+                                              const float *partials_prob, LmShared &sh, int tid, int *status_out) {
+  constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
+  static_assert(kS16 <= kThreads && kT16 <= kThreads, "one 16-byte block per thread");
+  LM_STAMP(0);
+  // one round trip: state block, tracker descriptor and the chunk partials together
+  uint4 sv = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
+  if (tid < kS16) sv = ((const uint4 *)&S)[tid];
+  if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
+  const int n_lvl = S.in.n; // the pending evaluation was built for this level
+  LM_STAMP(1);
+  reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh);
+  if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
+  if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
+  __syncthreads();
+  LM_STAMP(2);
+  if (tid >= 64) return; // wave 0 carries on
+  const int lane = tid;
+  reduce_partials_final(lane, sh);
+  LM_STAMP(3);
+  lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  LM_STAMP(8);
+  stage_out(&S, sh.st, lane, 64);
+  if (lane == 0 && status_out) {
+    status_out[2 * prob] = sh.st.status;
+    status_out[2 * prob + 1] = sh.st.lvl;
+  }
+#ifdef DSM_LM_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  LM_STAMP(9);
+  if (lane == 0 && prob == 0)
+    printf("LMPROF lvl %d: load %llu reduce %llu final %llu decide %llu ldlt %llu se3 %llu mkeval %llu end %llu out %llu (x10ns)\n", lvl,
+           lm_prof[1] - lm_prof[0], lm_prof[2] - lm_prof[1], lm_prof[3] - lm_prof[2], lm_prof[4] - lm_prof[3],
+           lm_prof[5] - lm_prof[4], lm_prof[6] - lm_prof[5], lm_prof[7] - lm_prof[6], lm_prof[8] - lm_prof[7],
+           lm_prof[9] - lm_prof[8]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// eval kernel: grid (chunk slots, problems).
+// LVL0 = true is the level-0 instantiation (adds the flow indicators); it is also the dominant kernel
+// of the path and shows up under its own symbol in rocprofv3 kernel traces.
+// FUSED = true: the workgroup of a problem that finishes last (ticket counter over ALL gridDim.x
+// workgroups of the problem's row, so that every one of them has read the state before it is
+// rewritten) also runs the LM step -- no separate lm_kernel launch for this evaluation.  The step
+// reads the same partials in the same order: results are bit-identical to the two-kernel form.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int LAYOUT, bool LVL0, bool FUSED>
+__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
+                                                        const LMState *__restrict__ states,
+                                                        float *__restrict__ partials,
+                                                        int partial_stride, int lvl, int *__restrict__ tickets,
+                                                        int *__restrict__ status_out) {
+  const int prob = blockIdx.y;
+  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
+  const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
+  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
+  const DSM_GLOBAL EvalIn &in = S.in;
+  const int n = in.n;
+  const int P = pts_per_thread(n);
+  const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
+  // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
+  // contiguous band of the template (and therefore of the target rows it gathers from).
+  const int per_xcd = gridDim.x >> 3;
+  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  float *partials_prob = partials + (size_t)prob * partial_stride;
+  if (chunk < nchunks) {
+    EvalConsts c;
+    c.pts = in.pts, c.img = in.img, c.n = n, c.w = in.w, c.h = in.h;
+    c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
+    c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
+    c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
+    __shared__ float red[16][kNumSlots];
+    eval_chunk<MODE, LAYOUT, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (size_t)chunk * kPartialStride);
+    if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // partial stores performed before the ticket
+  } else if (!FUSED) {
+    return;
+  }
+  if (FUSED) {
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&tickets[prob], 1);
+      last = t == (int)gridDim.x - 1;
+      if (last) tickets[prob] = 0; // for the next launch
+    }
+    __syncthreads();
+    if (!last) return;
+    __shared__ LmShared sh;
+    lm_step_block(MODE, lvl, prob, trackers[prob], const_cast<LMState &>(states[prob]), partials_prob, sh, threadIdx.x,
+                  status_out);
+  }
+}
+
+template <int MODE, int LAYOUT>
+static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
+                           float *partials, int partial_stride, int *tickets, int *status_out) {
+  if (tickets) { // fused LM step (never level 0: its kernel stays a pure evaluation)
+    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out);
+  } else if (lvl == 0)
+    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out);
+  else
+    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out);
+}
+
+// tickets != nullptr (levels >= 1 only): the kernel also performs the LM step (no lm_kernel launch needed)
+void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
+                 const TrackerDev *const *trackers, const LMState *states, float *partials,
+                 int partial_stride, int *tickets, int *status_out) {
+  dim3 grid(grid_x, nprob);
+  if (lvl == 0) tickets = nullptr;
+  if (mode == 0) {
+    if (layout == IMG_AOS3)
+      launch_eval_ml<0, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    else
+      launch_eval_ml<0, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+  } else if (mode == 2) {
+    if (layout == IMG_AOS3)
+      launch_eval_ml<2, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    else
+      launch_eval_ml<2, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+  } else {
+    if (layout == IMG_AOS3)
+      launch_eval_ml<1, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    else
+      launch_eval_ml<1, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+  }
+}
+
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
                                                         const TrackerDev *const *__restrict__ trackers,
                                                         LMState *__restrict__ states,
@@ -1156,14 +1247,6 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   }
 
   // ---- LM_OP_STEP / LM_OP_SINGLE_FINISH ----
-  LM_STAMP(0);
-  // first round trip: the state block (into registers), the activity test and the chunk count
-  constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
-  static_assert(kS16 <= kLmThreads && kT16 <= kLmThreads, "one 16-byte block per thread");
-  uint4 sv = {0, 0, 0, 0};
-  if (tid < kS16) sv = ((const uint4 *)&S)[tid];
-  const TrackerDev *Tg = trackers[prob];
-  const int n_lvl = S.in.n; // the pending evaluation was built for this level
   const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
   if (!active) { // block-uniform
     if (tid == 0 && status_out) {
@@ -1172,67 +1255,39 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     }
     return;
   }
-  if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
-  LM_STAMP(1);
-  // second round trip: tracker descriptor and the chunk partials, together
-  uint4 tv = {0, 0, 0, 0};
-  if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
-  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(n_lvl), tid, sh);
-  if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
-  __syncthreads();
-  LM_STAMP(2);
-  if (tid >= 64) return; // wave 0 carries on
-  reduce_partials_final(lane, sh);
-  LM_STAMP(3);
-  const TrackerDev &Ts = sh.trk;
-  LMState &Ss = sh.st;
-
-  if (op == LM_OP_SINGLE_FINISH) {
-    const double *sums = sh.sums;
-    const long long *isums = sh.isums;
-    double rs[6];
-    build_rs(sums, isums, rs);
-    const int n_warped = (int)isums[2];
-    const int n4 = (n_warped + 3) & ~3;
-    const int r = lane >> 3, c = lane & 7;
-    SingleOut &O = single_out[prob];
-    if (pose_like) {
-      O.H[lane] = build_H_elem(Ts.p, sums, n4, r, c);
-      if (lane < 8) O.b[lane] = build_b_elem(Ts.p, sums, n4, lane);
-    }
-    if (lane == 0) {
-      for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
-      O.n_warped = n4;
-      if (pose_like) {
-        O.Hs = O.bs = 0;
-      } else {
-        O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
-        O.bs = (float)sums[1] * (1.0f / n4);
-      }
-      S.status = ST_IDLE;
-    }
+  if (op == LM_OP_STEP) {
+    lm_step_block(mode, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, status_out);
     return;
   }
 
-  lm_step_wave0(mode, lvl, Ts, Ss, sh, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  LM_STAMP(8);
-  stage_out(&S, Ss, lane, 64);
-  if (lane == 0 && status_out) {
-    status_out[2 * prob] = Ss.status;
-    status_out[2 * prob + 1] = Ss.lvl;
+  // LM_OP_SINGLE_FINISH: reduced sums -> rs, H, b of one evaluation (dsm_tracker_calc_res_*)
+  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(S.in.n), tid, sh);
+  __syncthreads();
+  if (tid >= 64) return;
+  reduce_partials_final(lane, sh);
+  const double *sums = sh.sums;
+  const long long *isums = sh.isums;
+  double rs[6];
+  build_rs(sums, isums, rs);
+  const int n_warped = (int)isums[2];
+  const int n4 = (n_warped + 3) & ~3;
+  const int r = lane >> 3, c = lane & 7;
+  SingleOut &O = single_out[prob];
+  if (pose_like) {
+    O.H[lane] = build_H_elem(T.p, sums, n4, r, c);
+    if (lane < 8) O.b[lane] = build_b_elem(T.p, sums, n4, lane);
   }
-#ifdef DSM_LM_PROFILE
-  __builtin_amdgcn_s_waitcnt(0);
-  LM_STAMP(9);
-  if (lane == 0 && prob == 0)
-    printf("LMPROF lvl %d: load %llu reduce %llu final %llu decide %llu ldlt %llu se3 %llu mkeval %llu end %llu out %llu (x10ns)\n", lvl,
-           lm_prof[1] - lm_prof[0], lm_prof[2] - lm_prof[1], lm_prof[3] - lm_prof[2], lm_prof[4] - lm_prof[3],
-           lm_prof[5] - lm_prof[4], lm_prof[6] - lm_prof[5], lm_prof[7] - lm_prof[6], lm_prof[8] - lm_prof[7],
-           lm_prof[9] - lm_prof[8]);
-#endif
+  if (lane == 0) {
+    for (int i = 0; i < 6; i++) O.rs[i] = rs[i];
+    O.n_warped = n4;
+    if (pose_like) {
+      O.Hs = O.bs = 0;
+    } else {
+      O.Hs = (float)sums[0] * (1.0f / n4); // :1003-1004
+      O.bs = (float)sums[1] * (1.0f / n4);
+    }
+    S.status = ST_IDLE;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -71,6 +71,10 @@ typedef struct dsm_params {
                                          LM loop inside one kernel launch per problem; 0 (default): one (evaluate, step)
                                          launch pair per LM evaluation at every level.  Scheduling only -- results are
                                          bit-identical. */
+  int fuse_lm;                        /* at pyramid levels >= 1 the evaluation kernel's last-arriving workgroup of a
+                                         problem can perform the LM step itself (one launch per evaluation instead of
+                                         two): 0 never, 1 (default) for batches of at most 8 problems (where it shortens
+                                         the latency chain), 2 always.  Scheduling only -- results are bit-identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */

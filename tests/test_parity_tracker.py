@@ -388,3 +388,53 @@ def test_persistent_coarse_kernel_is_bit_identical(ctx, size, template):
         for a, b in zip(r0[1:], r1[1:]):
             np.testing.assert_array_equal(a, b)
         assert s0 == s1
+
+
+@pytest.mark.parametrize("size,template", [("small", "dense"), ("medium", "sparse"), ("kitti", "dense")])
+def test_fused_lm_step_is_bit_identical(ctx, size, template):
+    """fuse_lm: at levels >= 1 the last-arriving workgroup of the eval kernel performs the LM step; it
+    reads the same partials in the same order as the separate LM kernel: bit-identical results."""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene(size, seed=61, template=template, n0=12000)
+    assert default_params().fuse_lm == 1
+    out = []
+    for fuse in (0, 2, 1):
+        p = default_params()
+        p.fuse_lm = fuse
+        trk = hip_tracker(ctx, sc, p)
+        r = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        ev = list(ctx.stats().evals)
+        s = trk.optimizeScale(1.3, sc.nl - 1)
+        out.append((r, ev, s, list(ctx.stats().evals)))
+    for o in out[1:]:
+        assert o[1] == out[0][1] and o[3] == out[0][3] and o[2] == out[0][2]
+        assert o[0][0] == out[0][0][0]
+        for a, b in zip(o[0][1:], out[0][0][1:]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_fused_lm_step_batched(ctx):
+    """the fused eval+LM kernels with many problems in one launch (fuse_lm = 2 forces them for any batch
+    size) and two stream groups: bit-identical to the two-kernel form"""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    scs = [make_scene("small", seed=70 + i, template="dense" if i % 3 else "sparse", n0=2500) for i in range(12)]
+    poses0 = np.tile(S.IDENTITY_POSE, (12, 1))
+    out = []
+    try:
+        for fuse, ns in ((0, 1), (2, 1), (2, 2)):
+            p = default_params()
+            p.fuse_lm = fuse
+            trks = [hip_tracker(ctx, sc, p) for sc in scs]
+            ctx.set_streams(ns)
+            r = ctx.track_batch(trks, poses0, np.zeros((12, 2)), 2)
+            e = ctx.optimize_scale_batch(trks, np.ones(12), 2)
+            out.append((r, e))
+    finally:
+        ctx.set_streams(1)
+    for r, e in out[1:]:
+        for a, b in zip(r, out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(e, out[0][1]):
+            np.testing.assert_array_equal(a, b)
