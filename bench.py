@@ -51,7 +51,7 @@ def parse():
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--device-override", type=int, default=-1, help="testing: put every rank on this device")
-    ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidth and exit")
+    ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidths (two access patterns) and exit")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search instead")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
@@ -242,7 +242,9 @@ def bench_tracking(args):
     # this run's bytes per launch.  None when the summary is absent.
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        import glob
+
+        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))  # latest round
         traffic = pm["hbm_bytes_per_algorithmic_byte_level0_pose_eval"] * l0_evals * bytes_eval0 / max(1, l0_launches)
     except Exception:
         pass
@@ -356,7 +358,11 @@ if __name__ == "__main__":
         from direct_stereo_slam_amd.tracker import Context
 
         c = Context(0)
-        print(json.dumps({"read_bandwidth_GBps": {f"{mb}MiB": round(c.read_bandwidth(mb << 20, 10), 1) for mb in (512, 1024, 4096)}}))
+        print(json.dumps({
+            "read_bandwidth_GBps_grid_stride": {f"{mb}MiB": round(c.read_bandwidth(mb << 20, 10), 1) for mb in (512, 1024, 4096)},
+            # one contiguous chunk per workgroup -- the access pattern of the eval kernels (112 KiB ~ one level-0 chunk:
+            # 4096 template points + the image rows they land on)
+            "read_bandwidth_GBps_chunk_per_workgroup": {f"{kb}KiB": round(c.read_bandwidth_chunked(3 << 30, kb << 10, 5), 1) for kb in (16, 112, 1024)}}))
         sys.exit(0)
     if a.ringkey:
         bench_ringkey(a)
