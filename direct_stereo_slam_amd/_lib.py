@@ -72,6 +72,7 @@ SYMBOLS = {
     "dsm_tracker_destroy": (C.c_int, [_vp]),
     "dsm_tracker_make_k": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "dsm_tracker_set_ref": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_float, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
+    "dsm_tracker_set_ref_from_points": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
     "dsm_tracker_scale_depth": (C.c_int, [_vp, C.c_float]),
     "dsm_tracker_get_template": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "dsm_tracker_upload_frame": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),

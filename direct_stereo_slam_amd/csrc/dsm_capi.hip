@@ -381,6 +381,57 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
   return DSM_OK;
 }
 
+int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, int slot, int ref_frame_id, double ref_aff_a,
+                                    double ref_aff_b, float ref_exposure, int npts, const float *pu, const float *pv,
+                                    const float *pidepth, const float *pweight, int *n_out) {
+  if (!t || !frame_owner || slot < 0 || slot > 1 || npts < 0 || (npts > 0 && (!pu || !pv || !pidepth || !pweight)))
+    return invalid("dsm_tracker_set_ref_from_points: bad argument");
+  dsm_context *ctx = t->ctx;
+  if (frame_owner->ctx != ctx || frame_owner->w != t->w || frame_owner->h != t->h || frame_owner->nlevels != t->nlevels ||
+      frame_owner->desc.layout != t->desc.layout)
+    return invalid("dsm_tracker_set_ref_from_points: the frame owner must share context, size, levels and layout");
+  if (!frame_owner->have_frame[slot]) {
+    set_error("dsm_tracker_set_ref_from_points: the keyframe's pyramid has not been uploaded to that slot");
+    return DSM_ERR_STATE;
+  }
+  DSM_HIP(hipSetDevice(ctx->device));
+  for (int l = 0; l < t->nlevels; l++)
+    if ((long long)((t->w >> l) - 4) * ((t->h >> l) - 4) > t->pts_cap[l]) return invalid("template capacity too small");
+  const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, npts);
+  int rc = ensure_stage(ctx, floats);
+  if (rc) return rc;
+  float *ws = ctx->d_stage;
+  if (npts > 0) {
+    DSM_HIP(hipMemcpyAsync(ws, pu, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
+    DSM_HIP(hipMemcpyAsync(ws + npts, pv, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
+    DSM_HIP(hipMemcpyAsync(ws + 2 * (size_t)npts, pidepth, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
+    DSM_HIP(hipMemcpyAsync(ws + 3 * (size_t)npts, pweight, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int *d_n = (int *)(ws + floats - 64);
+  const float *ref[DSM_MAX_LEVELS];
+  for (int l = 0; l < t->nlevels; l++) ref[l] = frame_owner->d_img[slot][l];
+  launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, npts, ws, ref, t->desc.layout == IMG_AOS3 ? 3 : 4, t->d_pts, d_n);
+  DSM_HIP(hipGetLastError());
+  int h_n[DSM_MAX_LEVELS + 1];
+  DSM_HIP(hipMemcpyAsync(h_n, d_n, sizeof(int) * (t->nlevels + 1), hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  if (h_n[t->nlevels]) { // a point projected outside the image: the reference would corrupt memory (:160)
+    t->have_ref = false;
+    return invalid("dsm_tracker_set_ref_from_points: point outside the level-0 image");
+  }
+  for (int l = 0; l < t->nlevels; l++) {
+    t->desc.lv[l].n = h_n[l];
+    if (n_out) n_out[l] = h_n[l];
+  }
+  t->desc.ref_a = ref_aff_a; // :323-324
+  t->desc.ref_b = ref_aff_b;
+  t->desc.ref_exposure = ref_exposure;
+  t->ref_frame_id = ref_frame_id;
+  t->have_ref = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
 int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {
   if (!t) return invalid("null tracker");
   if (!t->have_ref) {

@@ -56,6 +56,11 @@ void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const Tracker
                    int *status_out, int max_pts);
 int coarse_max_points();
 
+// row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip)
+size_t make_coarse_depth_workspace_floats(int w, int h, int nlevels, int npts);
+void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, int npts, float *ws, const float *const *ref,
+                              int texel_floats, float4 *const *pts, int *d_n);
+
 void launch_interleave_template(hipStream_t s, int n, const float *u, const float *v, const float *id,
                                 const float *c, float4 *out);
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,

@@ -76,6 +76,21 @@ public:
     firstCoarseRMSE = -1;          // :326
   }
 
+  // The same, with makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) on the device: the caller flattens the window's
+  // active points (centerProjectedTo and the weight of :155-158, what the loops at :149-164 read from the
+  // PointHessian graph).  `frameOwner` is the tracker whose NEW_LEFT slot still holds the keyframe's pyramid (the
+  // one that tracked it; the reference swaps its two trackers, FrontEnd.cpp:627-632).
+  void setCoarseTrackingRef(const FrameView &ref, TrackerAndScaler &frameOwner, int npts, const float *pu, const float *pv,
+                            const float *pidepth, const float *pweight, int *pc_n_out = nullptr) {
+    check(dsm_tracker_set_ref_from_points(t_, frameOwner.t_, DSM_SLOT_NEW_LEFT, ref.shell_id, ref.aff_g2l.a, ref.aff_g2l.b,
+                                          ref.ab_exposure, npts, pu, pv, pidepth, pweight, pc_n_out),
+          "setCoarseTrackingRef (device template)");
+    lastRef = &ref;
+    refFrameID = ref.shell_id;
+    lastRef_aff_g2l = ref.aff_g2l;
+    firstCoarseRMSE = -1;
+  }
+
   void scaleCoarseDepthL0(float scale) { check(dsm_tracker_scale_depth(t_, scale), "scaleCoarseDepthL0"); }
 
   // reference: bool trackNewestCoarse(FrameHessian*, SE3&, AffLight&, int, Vec5, Vec5&, Output3DWrapper*)

@@ -142,6 +142,21 @@ class TrackerAndScaler:
                                          *[_ptr_array(a) for a in arrs]))
         self.firstCoarseRMSE = -1.0
 
+    def setCoarseTrackingRefFromPoints(self, ref_frame_id, ref_aff, ref_exposure, pu, pv, pidepth, pweight,
+                                       frame_owner=None, slot=0):
+        """makeCoarseDepthL0 + setCoarseTrackingRef (TrackerAndScaler.cpp:143-327) on the device (row N3): the
+        window's active points as flat arrays; the keyframe's pyramid is the one resident in `frame_owner`'s
+        `slot` (default: this tracker's new-left slot).  Returns pc_n per level."""
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (pu, pv, pidepth, pweight)]
+        npts = len(arrs[0])
+        assert all(len(a) == npts for a in arrs)
+        n = (C.c_int * self.nlevels)()
+        owner = self if frame_owner is None else frame_owner
+        check(self.L.dsm_tracker_set_ref_from_points(self.h, owner.h, slot, ref_frame_id, float(ref_aff[0]), float(ref_aff[1]),
+                                                     ref_exposure, npts, *[_fp(a) for a in arrs], n))
+        self.firstCoarseRMSE = -1.0
+        return list(n)
+
     def scaleCoarseDepthL0(self, scale):
         check(self.L.dsm_tracker_scale_depth(self.h, scale))
 

@@ -129,6 +129,17 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
                         float ref_exposure, const int *n, const float *const *pc_u,
                         const float *const *pc_v, const float *const *pc_idepth,
                         const float *const *pc_color);
+/* "next" row N3: makeCoarseDepthL0 + setCoarseTrackingRef (TrackerAndScaler.cpp:143-327) on the device.
+ * The window's active points as flat arrays -- (pu,pv) = centerProjectedTo[0..1], pidepth =
+ * centerProjectedTo[2], pweight = sqrtf(1e-3/(HdiF+1e-12)) (:155-158) -- are splatted, pyramided, dilated
+ * and emitted (row-major, the reference's order) straight into this tracker's template; the keyframe's
+ * (I,dx,dy) pyramid is the one already resident in `frame_owner`'s `slot` (the tracker that tracked the frame
+ * which became the keyframe; may be `t` itself).  Result identical to dsm_make_coarse_depth_l0 +
+ * dsm_tracker_set_ref, without the host loops and the template upload.  n_out (may be NULL): pc_n per level. */
+int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, int slot, int ref_frame_id,
+                                    double ref_aff_a, double ref_aff_b, float ref_exposure, int npts,
+                                    const float *pu, const float *pv, const float *pidepth, const float *pweight,
+                                    int *n_out);
 /* replaces TrackerAndScaler::scaleCoarseDepthL0(scale) (TrackerAndScaler.cpp:329-336) */
 int dsm_tracker_scale_depth(dsm_tracker *t, float scale);
 /* read back the device template of one level (tests; debugPlotIDepthMap replacement) */
