@@ -169,7 +169,7 @@ def one_step(ctx, wl, kf_idx):
     return good, poses, err, sc, st_track, st_scale
 
 
-def cpu_baseline(args, wl):
+def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
     """the oracle (kind 'port') timed on this box's host cores: 1 thread, as the reference runs this
     path on the image-callback thread.  Built with -O3 -march=native like CMakeLists.txt:4-6."""
     from direct_stereo_slam_amd import synth as S
@@ -188,14 +188,36 @@ def cpu_baseline(args, wl):
         orc.set_frame(1, O.make_images(right, nl, native=True), 1.0)
         trks.append(orc)
     t0 = time.perf_counter()
+    cpu_poses, cpu_good = [], []
     for i, orc in enumerate(trks):
-        orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        r = orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        cpu_good.append(bool(r[0]))
+        cpu_poses.append(np.asarray(r[1]))
         if i % args.kf_every == 0:
             orc.optimize_scale(1.0, nl - 1)
     dt = time.perf_counter() - t0
-    return {"value": len(trks) / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-            "sample": f"{len(trks)} of the same {w}x{h}x{nl} dense frames (track + scale-opt every {args.kf_every}th), "
-                      f"oracle/dsm_oracle.c -O3 -march=native, {dt:.2f} s"}
+    out = {"value": len(trks) / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+           "sample": f"{len(trks)} of the same {w}x{h}x{nl} {args.template} frames (track + scale-opt every {args.kf_every}th), "
+                     f"oracle/dsm_oracle.c -O3 -march=native, {dt:.2f} s"}
+    if gpu_poses is not None:
+        # the "ATE vs CPU ref" half of the metric on the very frames that were timed: translation error of both
+        # paths against the synthetic ground truth, and the GPU path against the CPU path
+        n = len(trks)
+        cp, gp, gt = np.array(cpu_poses)[:, 4:], np.asarray(gpu_poses)[:n, 4:], wl["gts"][:n, 4:]
+        ate = lambda a, b: float(np.sqrt(np.mean(np.sum((a - b) ** 2, 1))))
+        # frames on which the reference algorithm itself converges (CPU path within 5 cm of the ground truth): on the
+        # others both paths sit in the same wrong minimum, where the end point is sensitive to last-bit rounding
+        conv = np.abs(cp - gt).max(1) < 0.05
+        out["ate_vs_cpu_ref"] = {"frames": n, "ate_gpu_m": ate(gp, gt), "ate_cpu_m": ate(cp, gt),
+                                 "ate_ratio_gpu_over_cpu": ate(gp, gt) / max(ate(cp, gt), 1e-30),
+                                 "converged_frames": int(conv.sum()),
+                                 "ate_gpu_converged_m": ate(gp[conv], gt[conv]) if conv.any() else None,
+                                 "ate_cpu_converged_m": ate(cp[conv], gt[conv]) if conv.any() else None,
+                                 "ate_ratio_converged": ate(gp[conv], gt[conv]) / max(ate(cp[conv], gt[conv]), 1e-30) if conv.any() else None,
+                                 "max_abs_translation_diff_converged_m": float(np.abs(gp[conv] - cp[conv]).max()) if conv.any() else None,
+                                 "max_abs_translation_diff_gpu_vs_cpu_m": float(np.abs(gp - cp).max()),
+                                 "good_flags_equal": bool(np.array_equal(np.asarray(gpu_good)[:n].astype(bool), np.array(cpu_good)))}
+    return out
 
 
 def bench_tracking(args):
@@ -285,7 +307,7 @@ def bench_tracking(args):
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(args, wl)
+        res["cpu_baseline"] = cpu_baseline(args, wl, poses, good)
     else:
         res["cpu_baseline"] = None
     if rank == 0:
