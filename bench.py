@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--kf-every", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
+    ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -135,7 +136,7 @@ def build_workload(args, ctx, rank):
         new = scene.render(K, w, h, R, t, a=0.02, b=3.0, noise=2.0, rng=rng)
         right = scene.render(K, w, h, T[:3, :3], T[:3, 3], noise=2.0, rng=rng)
         scenes.append((scene, ref, new, right, S.pose_from_Rt(R, t)))
-    trackers, gts, host = [], [], []
+    trackers, gts, host, images = [], [], [], []
     for b in range(args.batch):
         scene, ref, new, right, gt = scenes[b % args.scenes]
         trk = TrackerAndScaler(ctx, w, h, nl, T, K, params)
@@ -151,15 +152,22 @@ def build_workload(args, ctx, rank):
         trk.upload_image(1, right, 1.0)
         trackers.append(trk)
         gts.append(gt)
+        images.append((np.ascontiguousarray(new, np.float32), np.ascontiguousarray(right, np.float32)))
         if b < args.cpu_frames:
             host.append((tpl, new, right))
-    return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params)
+    return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params, images=images)
 
 
-def one_step(ctx, wl, kf_idx):
+def one_step(ctx, wl, kf_idx, with_upload=False):
     from direct_stereo_slam_amd import synth as S
 
     B = len(wl["trackers"])
+    if with_upload:  # host float images in, pyramids built on the device (dsm_tracker_upload_image, row N1)
+        kfs = set(kf_idx)
+        for i, trk in enumerate(wl["trackers"]):
+            trk.upload_image(0, wl["images"][i][0], 1.0)
+            if i in kfs:
+                trk.upload_image(1, wl["images"][i][1], 1.0)
     poses0 = np.tile(S.IDENTITY_POSE, (B, 1))
     good, poses, affs, last, flow = ctx.track_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1)
     st_track = ctx.stats()
@@ -232,11 +240,11 @@ def bench_tracking(args):
     B = args.batch
     kf_idx = list(range(0, B, args.kf_every))
     for _ in range(args.warmup):
-        one_step(ctx, wl, kf_idx)
+        one_step(ctx, wl, kf_idx, args.with_upload)
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_step(ctx, wl, kf_idx)
+        out = one_step(ctx, wl, kf_idx, args.with_upload)
     ctx.sync()
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
@@ -299,7 +307,7 @@ def bench_tracking(args):
         "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
-                   "frames_in_flight_per_gpu": B, "replicas": world, "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
+                   "frames_in_flight_per_gpu": B, "replicas": world, "inputs": "host images uploaded and pyramids built inside the timed region (secondary figure)" if args.with_upload else "resident in HBM", "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,
