@@ -644,9 +644,9 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
 // Eigen LDLT<Lower> with diagonal pivoting + solve (call sites :509,:513,:518,:529), one matrix
 // element per lane (lane = 8*r + c, full symmetric storage), right-hand side replicated along
 // rows.  Rows/cols whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves).
-// Returns x_r (replicated along the row).  Same pivot order and the same operations as the
-// textbook (left-looking) form the oracle restates; only the order of the subtractions inside one
-// Schur-complement entry differs (round-off in the last bits of a double).
+// Returns x_r (replicated along the row).  Same pivot order as the textbook (left-looking) form the
+// oracle restates, right-looking symmetric updates; results differ from it by round-off in the last
+// bits of a double.
 // value of `v` in lane `idx` (any per-lane index): ds_bpermute
 __device__ __forceinline__ double permute_d(double v, int idx) {
   const long long b = __double_as_longlong(v);
@@ -658,53 +658,71 @@ __device__ __forceinline__ double permute_d(double v, int idx) {
 __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
   const int r = lane >> 3, c = lane & 7;
   unsigned done = ~active & 0xFFu; // wave-uniform
-  unsigned order = 0; // pivot of step k in bits 4k..4k+3, stored as p+1 (0 = no pivot): no indexed array
+  unsigned order = 0;              // pivot of step k in bits 4k..4k+3, stored as p+1 (0 = no pivot): no indexed array
+  unsigned live_at = 0;            // bit k: row r was still to be eliminated after step k (takes part in its update)
   bool all_zero = false;
+  // Every lane tracks the diagonal entries of its row and of its column (dR = A[r][r], dC = A[c][c]) with
+  // exactly the operations the diagonal lanes apply, and the matrix is updated symmetrically
+  // (A[i][j] -= (A[i][p]/d) * A[j][p] with i >= j on both sides of the diagonal), so one cross-lane fetch
+  // stage per pivot step -- column p for this lane's row and column -- is all that is needed.
+  a = permute_d(a, r >= c ? lane : 8 * c + r); // LDLT<Lower> reads the lower triangle only: mirror it (bitwise symmetric input)
+  double dR = permute_d(a, 9 * r), dC = permute_d(a, 9 * c);
+  double Lk[8];      // L[r][p_k]: this row's multiplier of step k (forward substitution)
+  double Lrow = 0.0; // L[c][r], captured at the step in which row r is the pivot (back substitution)
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     // pivot = first maximum of |diagonal| over the rows not yet eliminated (Eigen: maxCoeff of the
     // remaining diagonal).  Lane (r,c) tests "candidate c beats r"; a row nobody beats wins.
-    const double dR = fabs(permute_d(a, 9 * r)), dC = fabs(permute_d(a, 9 * c));
+    const double aR = fabs(dR), aC = fabs(dC);
     const bool live_r = !((done >> r) & 1u), live_c = !((done >> c) & 1u);
-    const bool beats = live_c && (dC > dR || (dC == dR && c < r));
+    const bool beats = live_c && (aC > aR || (aC == aR && c < r));
     const unsigned long long m = __ballot(beats);
     const bool row_beaten = ((m >> (8 * r)) & 0xFFull) != 0;
-    const unsigned long long w = __ballot(live_r && dR == dR && !row_beaten && c == 0);
+    const unsigned long long w = __ballot(live_r && aR == aR && !row_beaten && c == 0);
     const int p = w ? (__builtin_ctzll(w) >> 3) : -1; // wave-uniform
     order |= (unsigned)(p + 1) << (4 * k);
+    Lk[k] = 0.0;
     if (p >= 0) {
-      const double dp = lane_value_d(a, 9 * p);
-      const double arow = permute_d(a, 8 * p + c);
-      const double acol = permute_d(a, 8 * r + p);
+      const double dp = lane_value_d(dR, 8 * p);
+      const double colR = permute_d(a, 8 * r + p); // A[r][p]
+      const double colC = permute_d(a, 8 * c + p); // A[c][p]
       const bool valid = fabs(dp) > 0.0;
       if (k == 0 && !valid) all_zero = true;
       const bool r_live = live_r && r != p;
       const bool c_live = live_c && c != p;
-      const double l = valid ? acol / dp : acol;
-      if (r_live && c_live) a = a - l * arow;
-      if (r_live && c == p) a = l; // keep L in the pivot column
+      const double lR = valid ? colR / dp : colR;
+      const double lC = valid ? colC / dp : colC;
+      if (r_live && c_live) a = a - (r >= c ? lR * colC : lC * colR);
+      if (r_live) dR = dR - lR * colR;
+      if (c_live) dC = dC - lC * colC;
+      Lk[k] = lR;
+      if (r_live) live_at |= 1u << k;
+      if (r == p) Lrow = lC;
       done |= 1u << p;
     }
   }
   // forward substitution (unit lower), in pivot order
-  unsigned fdone = ~active & 0xFFu;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int p = (int)((order >> (4 * k)) & 15u) - 1;
     if (p >= 0) {
       const double yp = lane_value_d(y, 8 * p);
-      const double l = permute_d(a, 8 * r + p);
-      fdone |= 1u << p;
-      if (!((fdone >> r) & 1u)) y = y - l * yp;
+      if ((live_at >> k) & 1u) y = y - Lk[k] * yp;
     }
   }
-  // D^-1 with Eigen's tolerance 1/highest
+  // D^-1 with Eigen's tolerance 1/highest; dR stopped changing when row r became the pivot
   {
-    const double d = permute_d(a, 9 * r);
     const double tol = 1.0 / 1.7976931348623157e308;
-    y = fabs(d) > tol ? y / d : 0.0;
+    y = fabs(dR) > tol ? y / dR : 0.0;
   }
-  // back substitution (L^T), reverse pivot order
+  // back substitution (L^T), reverse pivot order: L[p_k][r] sits in lane (r, p_k); all eight fetches are
+  // independent of y and issued together
+  double Lb[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int p = (int)((order >> (4 * k)) & 15u) - 1;
+    Lb[k] = permute_d(Lrow, 8 * r + (p < 0 ? 0 : p));
+  }
   unsigned before = 0; // rows eliminated before the current pivot = all earlier pivots
 #pragma unroll
   for (int k = 0; k < 8; k++)
@@ -715,8 +733,7 @@ __device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned a
     if (p >= 0) {
       before &= ~(1u << p);
       const double xp = lane_value_d(y, 8 * p);
-      const double l = permute_d(a, 8 * p + r); // L[p][r], r eliminated before p
-      if ((before >> r) & 1u) y = y - l * xp;
+      if ((before >> r) & 1u) y = y - Lb[k] * xp;
     }
   }
   if (all_zero || !((active >> r) & 1u)) y = 0.0;
