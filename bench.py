@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="independent stereo frames in flight per GPU")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes (cycled over the batch)")
-    ap.add_argument("--config", default="S1", choices=["S1", "S2"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension)")
+    ap.add_argument("--config", default="S1", choices=["S1", "S2", "S3"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension), S3 = 1920x1080x6 (floor-halved, BASELINE configs[3] shape)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--kf-every", type=int, default=5)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
@@ -114,10 +114,14 @@ def build_workload(args, ctx, rank):
     if args.config == "S1":
         w, h, nl = 1232, 368, 5
         K = S.kitti_K_work()
-    else:
+    elif args.config == "S2":
         w, h, nl = 1248, 384, 6
         fx, fy, cx, cy = S.KITTI_K_RAW
         K = (fx, fy, cx + (1248 - 1241) / 2.0, cy + (384 - 376) / 2.0)
+    else:  # S3: synthetic 1920x1080, six floor-halved levels (1920x1080 ... 60x33), same field of view as KITTI
+        w, h, nl = 1920, 1080, 6
+        fx = S.KITTI_K_RAW[0] * 1920.0 / 1241.0
+        K = (fx, fx, 959.5, 539.5)
     T = S.KITTI_T_STEREO
     params = default_params()
     params.adaptive_schedule = 0 if args.no_adaptive else 1
@@ -304,7 +308,7 @@ def bench_tracking(args):
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"KITTI-00 shape {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded'}), "
+        "config": {"workload": f"{'KITTI-00 shape' if args.config != 'S3' else 'synthetic'} {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded' if args.config == 'S2' else 'floor-halved levels'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
                    "frames_in_flight_per_gpu": B, "replicas": world, "inputs": "host images uploaded and pyramids built inside the timed region (secondary figure)" if args.with_upload else "resident in HBM", "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
