@@ -1,0 +1,41 @@
+"""Scheduling choices (fused LM step, persistent small-level kernel, stream groups) must never change a result:
+repeated runs of mixed batches under every combination, compared bit for bit with the plain two-kernel,
+single-stream form.  A race in the ticket / staging protocols would show up here as a sporadic mismatch."""
+import numpy as np
+import pytest
+
+from _scenes import S, hip_tracker, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, scs, fuse, ns, coarse):
+    from direct_stereo_slam_amd.tracker import default_params
+
+    p = default_params()
+    p.fuse_lm, p.persistent_coarse = fuse, coarse
+    ctx.set_streams(ns)
+    out = []
+    for parity in (0, 1):  # two batches of equal image size
+        idx = [i for i in range(len(scs)) if i % 2 == parity]
+        trks = [hip_tracker(ctx, scs[i], p) for i in idx]
+        n, nl = len(trks), scs[idx[0]].nl
+        r = ctx.track_batch(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+        e = ctx.optimize_scale_batch(trks, np.full(n, 1.2), nl - 1)
+        out.append(tuple(r) + tuple(e))
+    return out
+
+
+def test_every_schedule_gives_identical_results(ctx):
+    scs = [make_scene("small" if i % 2 else "medium", seed=200 + i, template="dense" if i % 3 else "sparse", n0=6000)
+           for i in range(8)]
+    try:
+        ref = _run(ctx, scs, 0, 1, 0)
+        for it in range(12):
+            for fuse, ns, coarse in ((2, 1, 0), (2, 2, 0), (1, 3, 0), (0, 2, 4096), (2, 2, 2048)):
+                got = _run(ctx, scs, fuse, ns, coarse)
+                for g, r in zip(got, ref):
+                    for a, b in zip(g, r):
+                        assert np.array_equal(a, b, equal_nan=True), (it, fuse, ns, coarse)
+    finally:
+        ctx.set_streams(1)
