@@ -44,6 +44,8 @@ class Stats(C.Structure):
         ("launches", C.c_int64 * MAX_LEVELS),
         ("algorithmic_bytes", C.c_int64),
         ("eval_kernel_ms", C.c_double * MAX_LEVELS),
+        ("eval_kernel_union_ms", C.c_double * MAX_LEVELS),
+        ("eval_dispatches", C.c_int64 * MAX_LEVELS),
         ("total_ms", C.c_double),
         ("polls", C.c_int64),
         ("coarse_launches", C.c_int64),

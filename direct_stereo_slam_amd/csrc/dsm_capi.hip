@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "dsm_internal.hpp"
+#include <algorithm>
+#include <utility>
 
 namespace dsm {
 
@@ -707,10 +709,32 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
   ctx->stats.total_ms = ms;
   if (ctx->timing) {
+    // per dispatch: duration, and [start, end] relative to the start of the call for the per-level union
+    // (the stream groups' dispatches overlap; the union is the time during which the level's kernel ran at all)
+    std::vector<std::pair<float, float>> iv[DSM_MAX_LEVELS];
     for (size_t i = 0; i < ev_lvl.size(); i++) {
-      float m = 0;
-      if (hipEventElapsedTime(&m, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess)
+      float m = 0, a = 0;
+      if (hipEventElapsedTime(&m, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess &&
+          hipEventElapsedTime(&a, ctx->ev_total[0], ctx->ev_pool[2 * i]) == hipSuccess) {
         ctx->stats.eval_kernel_ms[ev_lvl[i]] += m;
+        ctx->stats.eval_dispatches[ev_lvl[i]]++;
+        iv[ev_lvl[i]].push_back(std::make_pair(a, a + m));
+      }
+    }
+    for (int l = 0; l < nlevels; l++) {
+      std::sort(iv[l].begin(), iv[l].end());
+      double busy = 0, cs = 0, ce = -1;
+      for (auto &p : iv[l]) {
+        if (ce < 0) {
+          cs = p.first, ce = p.second;
+        } else if (p.first > ce) {
+          busy += ce - cs;
+          cs = p.first, ce = p.second;
+        } else if (p.second > ce)
+          ce = p.second;
+      }
+      if (ce >= 0) busy += ce - cs;
+      ctx->stats.eval_kernel_union_ms[l] = busy;
     }
   }
   int need[DSM_MAX_LEVELS] = {0};

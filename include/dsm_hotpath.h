@@ -82,7 +82,9 @@ typedef struct dsm_stats {
   int64_t evals[DSM_MAX_LEVELS];        /* fused residual+Jacobian evaluations executed, summed over the batch */
   int64_t launches[DSM_MAX_LEVELS];     /* eval kernel launches per level */
   int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + 12*w_l*h_l   */
-  double eval_kernel_ms[DSM_MAX_LEVELS];/* HIP-event time of the eval kernels per level (only when timing enabled) */
+  double eval_kernel_ms[DSM_MAX_LEVELS];/* summed HIP-event durations of the eval kernel dispatches per level (timing enabled) */
+  double eval_kernel_union_ms[DSM_MAX_LEVELS]; /* time during which at least one of them ran (stream groups overlap) */
+  int64_t eval_dispatches[DSM_MAX_LEVELS];     /* timed dispatches per level (launches x stream groups) */
   double total_ms;                      /* HIP-event time of the whole call */
   int64_t polls;                        /* host read-backs of the device LM state (passes) */
   int64_t coarse_launches;              /* launches of the persistent small-level kernel */

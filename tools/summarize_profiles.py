@@ -74,9 +74,12 @@ if trace:
         "achieved_GBps_from_trace": l0["evals"] * steps * bytes_eval / max(1, busy),
         "achieved_GBps_bench_hip_events": bench["roofline"]["achieved"],
         "frames_in_flight": B, "stream_groups": cfg["streams"],
-        "note": "the timed steps run 2 stream groups (each launch = 2 concurrent dispatches over half of the batch, "
-                "so per-dispatch durations overlap: the trace figure uses the union of the dispatch intervals); "
-                "bench.py's roofline leg times one extra step on a single stream with HIP events",
+        "avg_ns_all_dispatches": sum(d) / max(1, len(d)),
+        "bench_avg_dispatch_us": bench["roofline"]["avg_launch_us"],
+        "note": "2 stream groups: each launch = 2 concurrent dispatches over half of the batch, so per-dispatch durations "
+                "overlap and the rate uses the union of the dispatch intervals -- in the trace and in bench.py's HIP-event "
+                "leg alike; avg_ns_all_dispatches (= rocprofv3 --stats AverageNs) is to be compared with bench.py's "
+                "roofline.avg_launch_us (per-dispatch average of one steady-state step)",
     }
     json.dump(summary, open(os.path.join(dst, f"{tag}_level0_eval_trace_summary.json"), "w"), indent=1)
     print("trace:", summary["achieved_GBps_from_trace"], "bench:", bench["roofline"]["achieved"])
