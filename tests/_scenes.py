@@ -10,6 +10,7 @@ SIZES = {
     "small": (308, 92, 2, 3),
     "medium": (616, 184, 1, 4),
     "kitti": (1232, 368, 0, 5),  # S1: what the reference actually runs
+    "odd": (240, 135, 2, 3),     # S3's floor-halved tail: 240x135 -> 120x67 -> 60x33 (odd sizes drop the last row/column)
 }
 
 

@@ -127,16 +127,17 @@ def test_template_roundtrip_and_scale_depth(ctx):
             np.testing.assert_array_equal(a, b)  # IEEE division on both sides: bit exact
 
 
-def test_device_pyramid_matches_make_images(ctx):
-    """N1: makeImages on the device is bit-exact with the oracle restatement"""
-    sc = make_scene("small", seed=15)
+@pytest.mark.parametrize("size", ["small", "odd"])
+def test_device_pyramid_matches_make_images(ctx, size):
+    """N1: makeImages on the device is bit-exact with the oracle restatement (also for floor-halved odd sizes, S3)"""
+    sc = make_scene(size, seed=15)
     trk = hip_tracker(ctx, sc)
     trk.upload_image(0, sc.new_img, 1.0)
     for lvl in range(sc.nl):
         np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
 
 
-@pytest.mark.parametrize("size,template,seed", [("tiny", "dense", 1), ("small", "dense", 2), ("small", "sparse", 3), ("medium", "dense", 4)])
+@pytest.mark.parametrize("size,template,seed", [("tiny", "dense", 1), ("small", "dense", 2), ("small", "sparse", 3), ("medium", "dense", 4), ("odd", "dense", 5)])
 def test_track_parity(ctx, size, template, seed):
     sc = make_scene(size, seed=seed, template=template, n0=4000)
     orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
