@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
+    ap.add_argument("--queue", type=int, default=0,
+                    help="dsm_params.work_queue: 0 (default here) launch-per-step form -- its dominant kernel, the level-0 evaluation, is "
+                         "timed per launch for the roofline; 1 the library's automatic rule (batches >= 32); 2 the whole call as one "
+                         "launch of persistent workgroups (faster: DESIGN.md section 6; its roofline is the whole-call figure)")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -127,6 +131,7 @@ def build_workload(args, ctx, rank):
     params.adaptive_schedule = 0 if args.no_adaptive else 1
     if args.coarse is not None:
         params.persistent_coarse = args.coarse
+    params.work_queue = args.queue
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0
@@ -290,6 +295,14 @@ def bench_tracking(args):
                 "avg_launch_us": 1e3 * stt.eval_kernel_ms[0] / max(1, l0_dispatches), "launches": int(l0_launches),
                 "dispatches": int(l0_dispatches), "stream_groups": args.streams,
                 "kernel_busy_us_per_launch": 1e3 * l0_ms / max(1, l0_launches)}
+    if stt.queue_blocks > 0:
+        # work-queue form: the whole track call is ONE kernel; its algorithmic bytes are those of every evaluation at every level
+        qms = stt.queue_kernel_ms
+        q_ach = stt.algorithmic_bytes / (qms * 1e-3) / 1e9 if qms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": q_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": q_ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "queue_kernel<pose> (whole track call: all levels' evaluations + LM steps in one launch)",
+                    "bytes_per_launch": int(stt.algorithmic_bytes), "avg_launch_us": 1e3 * qms, "launches": 1,
+                    "persistent_workgroups": int(stt.queue_blocks), "queue_items": int(stt.queue_items)}
     per_level = []
     for l in range(wl["nl"]):
         nl_ = len(wl["trackers"][0].get_template(l)[0])
@@ -315,7 +328,7 @@ def bench_tracking(args):
         "config": {"workload": f"{'KITTI-00 shape' if args.config != 'S3' else 'synthetic'} {wl['w']}x{wl['h']} ({'1241x376 cropped' if args.config == 'S1' else '1241x376 padded' if args.config == 'S2' else 'floor-halved levels'}), "
                                f"{wl['nl']}-level pyramid, {args.template} template n0={n0}, LM as executed, "
                                f"track every frame + scale-opt every {args.kf_every}th",
-                   "frames_in_flight_per_gpu": B, "replicas": world, "inputs": "host images uploaded and pyramids built inside the timed region (secondary figure)" if args.with_upload else "resident in HBM", "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
+                   "frames_in_flight_per_gpu": B, "replicas": world, "inputs": "host images uploaded and pyramids built inside the timed region (secondary figure)" if args.with_upload else "resident in HBM", "work_queue_blocks": int(stt.queue_blocks), "adaptive_schedule": not args.no_adaptive, "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams, "launch_pairs_per_step": int(sum(stt.launches) + sum(out_t[5].launches)), "readbacks_per_step": int(stt.polls + out_t[5].polls),
                    "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
                    "algorithmic_MB_per_frame": all_bytes / B / 1e6,
                    "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + out_t[5].total_ms)) / 1e9,

@@ -35,6 +35,7 @@ class Params(C.Structure):
         ("adaptive_schedule", C.c_int),
         ("persistent_coarse", C.c_int),
         ("fuse_lm", C.c_int),
+        ("work_queue", C.c_int),
     ]
 
 
@@ -49,6 +50,9 @@ class Stats(C.Structure):
         ("total_ms", C.c_double),
         ("polls", C.c_int64),
         ("coarse_launches", C.c_int64),
+        ("queue_blocks", C.c_int64),
+        ("queue_items", C.c_int64),
+        ("queue_kernel_ms", C.c_double),
     ]
 
 

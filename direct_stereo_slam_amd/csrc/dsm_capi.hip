@@ -178,6 +178,7 @@ void dsm_params_default(dsm_params *p) {
   p->adaptive_schedule = 1;
   p->persistent_coarse = 0;
   p->fuse_lm = 1;
+  p->work_queue = 1;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -216,6 +217,9 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipHostFree(ctx->h_single);
   hipFree(ctx->d_status);
   hipFree(ctx->d_tickets);
+  hipFree(ctx->d_queue);
+  hipFree(ctx->d_qitems);
+  hipHostFree(ctx->h_queue);
   hipHostFree(ctx->h_status);
   hipFree(ctx->d_stage);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
@@ -600,6 +604,46 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo) * n, hipMemcpyHostToDevice, ctx->stream));
   launch_lm(ctx->stream, mode, LM_OP_START, coarsest, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, ctx->d_status);
+  // Work-queue form: one launch of persistent workgroups for the whole call (queue_kernel).  Scheduling only:
+  // results are bit-identical to the launch-per-step form below.
+  const bool use_queue = P.work_queue >= 2 || (P.work_queue == 1 && n >= 32);
+  if (use_queue) {
+    int max_items = 1;
+    for (int L = 0; L <= coarsest; L++)
+      for (int i = 0; i < n; i++) {
+        const int c = num_chunks(ts[i]->desc.lv[L].n);
+        if (c > max_items) max_items = c;
+      }
+    if (max_items >= (1 << kQueueChunkBits) || n >= (1 << (32 - kQueueChunkBits))) return invalid("work queue: batch or level too large");
+    size_t qcap = 1024; // outstanding items <= problems x chunks of one evaluation: a problem has one evaluation in flight
+    while (qcap < (size_t)n * max_items) qcap <<= 1;
+    if (qcap > ctx->qcap) {
+      if (ctx->d_qitems) DSM_HIP(hipFree(ctx->d_qitems));
+      ctx->d_qitems = nullptr;
+      ctx->qcap = 0;
+      DSM_HIP(hipMalloc(&ctx->d_qitems, qcap * sizeof(unsigned long long)));
+      ctx->qcap = qcap;
+    }
+    if (!ctx->d_queue) DSM_HIP(hipMalloc(&ctx->d_queue, sizeof(WorkQueue)));
+    if (!ctx->h_queue) DSM_HIP(hipHostMalloc(&ctx->h_queue, sizeof(WorkQueue), hipHostMallocDefault));
+    DSM_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(WorkQueue), ctx->stream));
+    DSM_HIP(hipMemsetAsync(ctx->d_qitems, 0, ctx->qcap * sizeof(unsigned long long), ctx->stream)); // stale publication tags
+    if (ctx->queue_blocks[mode] == 0) {
+      hipDeviceProp_t prop;
+      DSM_HIP(hipGetDeviceProperties(&prop, ctx->device));
+      const int per_cu = queue_kernel_blocks_per_cu(mode, layout);
+      if (per_cu < 1) return invalid("work queue: kernel does not fit the device");
+      ctx->queue_blocks[mode] = per_cu * prop.multiProcessorCount; // all workgroups must be co-resident
+    }
+    hipEvent_t qa = ctx->timing ? get_event(ctx, 0) : nullptr, qb = ctx->timing ? get_event(ctx, 1) : nullptr;
+    if (qa) DSM_HIP(hipEventRecord(qa, ctx->stream));
+    launch_queue(ctx->stream, mode, layout, ctx->queue_blocks[mode], n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+                 ctx->partial_stride, ctx->d_tickets, ctx->d_queue, ctx->d_qitems, (unsigned)(ctx->qcap - 1));
+    if (qb) DSM_HIP(hipEventRecord(qb, ctx->stream));
+    DSM_HIP(hipGetLastError());
+    DSM_HIP(hipMemcpyAsync(ctx->h_queue, ctx->d_queue, sizeof(WorkQueue), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->stats.queue_blocks = ctx->queue_blocks[mode];
+  }
   size_t ev_used = 0;
   std::vector<int> ev_lvl;
   // Launch schedule.  The LM loop is sequential per problem and its length is data dependent
@@ -632,7 +676,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     ctx->join_events.push_back(ev);
   }
   int top = coarsest;
-  if (P.persistent_coarse > 0) {
+  if (!use_queue && P.persistent_coarse > 0) {
     // Small levels: the whole LM loop in one launch per problem (coarse_kernel).  It hands a problem
     // back (still RUNNING) at the first level with more than coarse_max_points() template points.
     const int max_pts = P.persistent_coarse < coarse_max_points() ? P.persistent_coarse : coarse_max_points();
@@ -646,7 +690,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
           break;
         }
   }
-  for (int pass = 0;; pass++) {
+  for (int pass = 0; !use_queue; pass++) {
     if (ng > 1) { // fork: the extra streams start after everything enqueued on the main stream so far
       DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
       for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
@@ -705,6 +749,20 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   DSM_HIP(hipMemcpyAsync(ctx->h_states, ctx->d_states, sizeof(LMState) * n, hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
+  if (use_queue) {
+    if (ctx->h_queue->error) {
+      // leave the arrival counters clean for the next call
+      DSM_HIP(hipMemsetAsync(ctx->d_tickets, 0, sizeof(int) * ctx->cap_prob, ctx->stream));
+      DSM_HIP(hipStreamSynchronize(ctx->stream));
+      set_error("internal: work-queue kernel gave up waiting (bounded wait expired)");
+      return DSM_ERR_STATE;
+    }
+    ctx->stats.queue_items = ctx->h_queue->tail;
+    if (ctx->timing && ctx->ev_pool.size() >= 2) {
+      float qm = 0;
+      if (hipEventElapsedTime(&qm, ctx->ev_pool[0], ctx->ev_pool[1]) == hipSuccess) ctx->stats.queue_kernel_ms = qm;
+    }
+  }
   float ms = 0;
   DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
   ctx->stats.total_ms = ms;

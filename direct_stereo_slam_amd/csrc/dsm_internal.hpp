@@ -42,6 +42,10 @@ struct dsm_context {
   dsm::SingleOut *h_single = nullptr; // pinned
   int *d_status = nullptr;
   int *h_status = nullptr; // pinned
+  dsm::WorkQueue *d_queue = nullptr, *h_queue = nullptr; // work-queue kernel: header (device / pinned copy)
+  unsigned long long *d_qitems = nullptr;
+  size_t qcap = 0;
+  int queue_blocks[3] = {0, 0, 0}; // co-resident grid size per mode
   int *d_tickets = nullptr; // per-problem arrival counters of the fused eval+LM kernels (zero between launches)
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;

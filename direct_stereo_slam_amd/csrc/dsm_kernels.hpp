@@ -51,6 +51,19 @@ void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const Tracke
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
                SingleOut *single_out, int *status_out);
 
+// work-queue kernel (queue_kernel): header of the device-side queue, zeroed before every launch; counters on their
+// own 128-byte lines.  Items: (index + 1) << 32 | problem << kQueueChunkBits | chunk.
+struct WorkQueue {
+  unsigned head, pad0[31];
+  unsigned tail, pad1[31];
+  unsigned done, pad2[31]; // problems that have terminated
+  int error, pad3[31];     // a bounded wait expired
+};
+constexpr int kQueueChunkBits = 12;
+int queue_kernel_blocks_per_cu(int mode, int layout);
+void launch_queue(hipStream_t s, int mode, int layout, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
+                  float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask);
+
 // persistent LM loop of the small levels (levels with <= coarse_max_points() template points)
 void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_pts);

@@ -907,6 +907,21 @@ __device__ __forceinline__ void stage_out(T *dst_global, const T &src_lds, int t
   for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
 }
 
+// Device-coherent 16-byte accesses (two 8-byte device-scope atomics): for state that one workgroup writes and a
+// workgroup on another XCD reads inside the SAME launch (work-queue kernel); the XCD L2s are not coherent with
+// each other for ordinary accesses.
+__device__ __forceinline__ uint4 load16_coherent(const void *p) {
+  const unsigned long long a = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint4 v;
+  v.x = (unsigned)a, v.y = (unsigned)(a >> 32), v.z = (unsigned)b, v.w = (unsigned)(b >> 32);
+  return v;
+}
+__device__ __forceinline__ void store16_coherent(void *p, const uint4 &v) {
+  __hip_atomic_store((unsigned long long *)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long *)p + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- fixed-order reduction over the chunk partials (double / int64), first 247 threads of the
 // workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
 // g, g+19, g+38, ...: every load is a 16-byte read and up to kRedBatch of them are in flight per
@@ -1071,6 +1086,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
 // staged through LDS, fixed-order reduction, wave 0 advances the state machine and writes the state
 // back.  Shared by lm_kernel (LM_OP_STEP) and by the last-arriving workgroup of a fused eval kernel.
 // All threads of the workgroup must call it; S must be at this level (status RUNNING, lvl, mode).
+template <bool COH = false>
 __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const TrackerDev *Tg, LMState &S,
                                               const float *partials_prob, LmShared &sh, int tid, int *status_out) {
   constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
@@ -1078,9 +1094,10 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   LM_STAMP(0);
   // one round trip: state block, tracker descriptor and the chunk partials together
   uint4 sv = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
-  if (tid < kS16) sv = ((const uint4 *)&S)[tid];
+  if (tid < kS16) sv = COH ? load16_coherent((const uint4 *)&S + tid) : ((const uint4 *)&S)[tid];
   if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
-  const int n_lvl = S.in.n; // the pending evaluation was built for this level
+  // the pending evaluation was built for this level
+  const int n_lvl = COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
   LM_STAMP(1);
   reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh);
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
@@ -1096,7 +1113,11 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   LM_STAMP(8);
-  stage_out(&S, sh.st, lane, 64);
+  if (COH) {
+    for (int i = lane; i < kS16; i += 64) store16_coherent((uint4 *)&S + i, ((const uint4 *)&sh.st)[i]);
+  } else {
+    stage_out(&S, sh.st, lane, 64);
+  }
   if (lane == 0 && status_out) {
     status_out[2 * prob] = sh.st.status;
     status_out[2 * prob + 1] = sh.st.lvl;
@@ -1408,6 +1429,166 @@ void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const Tracker
 #undef DSM_COARSE
 }
 int coarse_max_points() { return kCoarseMaxPts; }
+
+// ------------------------------------------------------------------------------------------
+// queue_kernel: the whole call in ONE launch of persistent workgroups pulling (problem, chunk) items from a
+// device-side queue.  The workgroup that completes a problem's evaluation (arrival ticket) performs its LM step
+// and pushes the chunks of the problem's next evaluation, so every problem advances at its own pace: no
+// lock-step launches sized for the slowest problem, no idle workgroups, LM steps overlapped with other
+// problems' evaluations.  Same chunks, same partials, same reduction order as the launch-per-step path:
+// bit-identical results.  Everything one workgroup writes and another reads inside the launch (queue
+// items, partials, LMState, tickets) uses device-scope accesses; the XCD L2s are not mutually coherent.
+// All workgroups must be co-resident (the host sizes the grid from the occupancy query); waits are bounded
+// and raise q->error instead of hanging.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned q_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// whole wave: append `nitems` chunk items of problem `prob`.  The caller has made the problem's new state visible.
+__device__ __forceinline__ void queue_push(WorkQueue *q, unsigned long long *items, unsigned qmask, int prob, int nitems, int lane) {
+  unsigned base = 0;
+  if (lane == 0) base = atomicAdd(&q->tail, (unsigned)nitems);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  for (int i = lane; i < nitems; i += 64) {
+    const unsigned idx = base + (unsigned)i;
+    __hip_atomic_store(&items[idx & qmask], ((unsigned long long)(idx + 1u) << 32) | ((unsigned)prob << kQueueChunkBits) | (unsigned)i,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int MODE, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *const *__restrict__ trackers, LMState *__restrict__ states,
+                                                         float *__restrict__ partials, int partial_stride, int *__restrict__ tickets,
+                                                         WorkQueue *__restrict__ q, unsigned long long *__restrict__ items, unsigned qmask,
+                                                         int nprob) {
+  __shared__ LmShared sh;
+  __shared__ float red[16][kNumSlots];
+  __shared__ __attribute__((aligned(16))) EvalIn s_in;
+  __shared__ int s_ctl[4]; // problem (-1: leave), chunk, level, "last arrival" flag
+  const int tid = threadIdx.x;
+
+  // seed: the first evaluation of every problem (LM_OP_START ran as its own launch before this kernel)
+  if (tid < 64)
+    for (int p = blockIdx.x; p < nprob; p += gridDim.x) {
+      const LMState &S0 = states[p];
+      if (S0.status == ST_RUNNING && S0.is_scale == MODE) {
+        const int nch = num_chunks(S0.in.n);
+        queue_push(q, items, qmask, p, nch > 0 ? nch : 1, tid);
+      } else if (tid == 0) {
+        atomicAdd(&q->done, 1u);
+      }
+    }
+
+  for (;;) {
+    if (tid == 0) {
+      const unsigned t = atomicAdd(&q->head, 1u);
+      int prob = -1, chunk = 0;
+      for (unsigned spins = 0;; spins++) {
+        const unsigned long long v = __hip_atomic_load(&items[t & qmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == t + 1u) {
+          prob = (int)(((unsigned)v) >> kQueueChunkBits);
+          chunk = (int)(((unsigned)v) & ((1u << kQueueChunkBits) - 1u));
+          break;
+        }
+        if (q_load(&q->done) >= (unsigned)nprob || q_load((const unsigned *)&q->error)) break;
+        if (spins > (1u << 22)) { // ~ a second of polling: something is wrong -- never hang the GPU
+          __hip_atomic_store(&q->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_ctl[0] = prob;
+      s_ctl[1] = chunk;
+    }
+    __syncthreads();
+    const int prob = s_ctl[0], chunk = s_ctl[1];
+    if (prob < 0) break; // workgroup-uniform
+    LMState &S = states[prob];
+    constexpr int kIn16 = sizeof(EvalIn) / 16;
+    static_assert(sizeof(EvalIn) % 16 == 0, "EvalIn is staged with 16-byte copies");
+    if (tid < kIn16) ((uint4 *)&s_in)[tid] = load16_coherent((const uint4 *)&S.in + tid);
+    if (tid == 64) s_ctl[2] = __hip_atomic_load(&S.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int lvl = __builtin_amdgcn_readfirstlane(s_ctl[2]);
+    EvalConsts c;
+    {
+      const EvalIn &in = s_in;
+      auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      const unsigned long long pp = (unsigned long long)in.pts, ip = (unsigned long long)in.img;
+      c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
+      c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
+      c.n = __builtin_amdgcn_readfirstlane(in.n);
+      c.w = __builtin_amdgcn_readfirstlane(in.w);
+      c.h = __builtin_amdgcn_readfirstlane(in.h);
+      c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
+#pragma unroll
+      for (int i = 0; i < 9; i++) c.Ki[i] = rf(in.Ki[i]), c.M[i] = rf(in.M[i]);
+      c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
+      c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
+      c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
+    }
+    const int nch = num_chunks(c.n);
+    const int nitems = nch > 0 ? nch : 1; // an empty level still needs its LM step
+    float *partials_prob = partials + (size_t)prob * partial_stride;
+    if (chunk < nch) {
+      if (lvl == 0)
+        eval_chunk<MODE, LAYOUT, true>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
+      else
+        eval_chunk<MODE, LAYOUT, false>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this workgroup's partial is performed before its ticket
+    __syncthreads();
+    if (tid == 0) {
+      const int tk = atomicAdd(&tickets[prob], 1);
+      const int last = tk == nitems - 1;
+      if (last) __hip_atomic_store(&tickets[prob], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ctl[3] = last;
+    }
+    __syncthreads();
+    if (s_ctl[3]) { // workgroup-uniform: the problem's evaluation is complete -> its LM step, then its next evaluation
+      lm_step_block<true>(MODE, lvl, prob, trackers[prob], S, partials_prob, sh, tid, nullptr);
+      if (tid < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // new state (and the ticket reset) performed before the items appear
+        if (sh.st.status == ST_RUNNING) {
+          const int nn = num_chunks(sh.st.in.n);
+          queue_push(q, items, qmask, prob, nn > 0 ? nn : 1, tid);
+        } else if (tid == 0) {
+          atomicAdd(&q->done, 1u);
+        }
+      }
+    }
+    __syncthreads(); // LDS (s_ctl, s_in, red, sh) is reused by the next item
+  }
+}
+
+int queue_kernel_blocks_per_cu(int mode, int layout) {
+  int nb = 0;
+#define DSM_QOCC(M, L) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, queue_kernel<M, L>, kThreads, 0)
+  if (mode == 0)
+    layout == IMG_AOS3 ? DSM_QOCC(0, IMG_AOS3) : DSM_QOCC(0, IMG_AOS4);
+  else if (mode == 1)
+    layout == IMG_AOS3 ? DSM_QOCC(1, IMG_AOS3) : DSM_QOCC(1, IMG_AOS4);
+  else
+    layout == IMG_AOS3 ? DSM_QOCC(2, IMG_AOS3) : DSM_QOCC(2, IMG_AOS4);
+#undef DSM_QOCC
+  return nb;
+}
+
+void launch_queue(hipStream_t s, int mode, int layout, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
+                  float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask) {
+#define DSM_QL(M, L)                                                                                                  \
+  hipLaunchKernelGGL((queue_kernel<M, L>), dim3(nblocks), dim3(kThreads), 0, s, trackers, states, partials, partial_stride, tickets, \
+                     q, items, qmask, nprob)
+  if (mode == 0) {
+    if (layout == IMG_AOS3) DSM_QL(0, IMG_AOS3); else DSM_QL(0, IMG_AOS4);
+  } else if (mode == 1) {
+    if (layout == IMG_AOS3) DSM_QL(1, IMG_AOS3); else DSM_QL(1, IMG_AOS4);
+  } else {
+    if (layout == IMG_AOS3) DSM_QL(2, IMG_AOS3); else DSM_QL(2, IMG_AOS4);
+  }
+#undef DSM_QL
+}
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,

@@ -75,6 +75,11 @@ typedef struct dsm_params {
                                          problem can perform the LM step itself (one launch per evaluation instead of
                                          two): 0 never, 1 (default) for batches of at most 8 problems (where it shortens
                                          the latency chain), 2 always.  Scheduling only -- results are bit-identical. */
+  int work_queue;                     /* the whole call as ONE launch of persistent workgroups that pull (problem, chunk)
+                                         items from a device-side queue; the workgroup completing an evaluation performs
+                                         the LM step and enqueues the problem's next evaluation, so problems advance
+                                         independently instead of in lock-step launches: 0 never, 1 (default) for batches
+                                         of at least 32 problems, 2 always.  Scheduling only -- results are bit-identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
@@ -88,6 +93,9 @@ typedef struct dsm_stats {
   double total_ms;                      /* HIP-event time of the whole call */
   int64_t polls;                        /* host read-backs of the device LM state (passes) */
   int64_t coarse_launches;              /* launches of the persistent small-level kernel */
+  int64_t queue_blocks;                 /* work-queue kernel: persistent workgroups launched (0: launch-per-step form) */
+  int64_t queue_items;                  /* work-queue kernel: (problem, chunk) items processed */
+  double queue_kernel_ms;               /* work-queue kernel: HIP-event duration of the launch (timing enabled) */
 } dsm_stats;
 
 const char *dsm_last_error(void);

@@ -439,3 +439,54 @@ def test_fused_lm_step_batched(ctx):
             np.testing.assert_array_equal(a, b)
         for a, b in zip(e, out[0][1]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("size,template", [("tiny", "dense"), ("small", "dense"), ("medium", "sparse"), ("kitti", "dense")])
+def test_work_queue_kernel_is_bit_identical(ctx, size, template):
+    """work_queue: the whole call in one launch of persistent workgroups pulling (problem, chunk) items; same chunks,
+    same partials, same reduction order -> bit-identical results, evaluation counts included.  Also with an empty
+    pyramid level (no template points there: the level still needs its LM step)."""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene(size, seed=63, template=template, n0=12000)
+    assert default_params().work_queue == 1
+    out = []
+    for queue in (0, 2, 2):
+        p = default_params()
+        p.work_queue = queue
+        trk = hip_tracker(ctx, sc, p)
+        r = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        st = ctx.stats()
+        ev, qb = list(st.evals), st.queue_blocks
+        s = trk.optimizeScale(1.3, sc.nl - 1)
+        out.append((r, ev, s, list(ctx.stats().evals), qb))
+    assert out[0][4] == 0 and out[1][4] > 0
+    for o in out[1:]:
+        assert o[1] == out[0][1] and o[3] == out[0][3] and o[2] == out[0][2]
+        assert o[0][0] == out[0][0][0]
+        for a, b in zip(o[0][1:], out[0][0][1:]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_work_queue_kernel_batched_with_empty_level(ctx):
+    from direct_stereo_slam_amd.tracker import default_params
+
+    scs = [make_scene("small", seed=170 + i, template="dense" if i % 3 else "sparse", n0=2500) for i in range(40)]
+    for sc in scs[::7]:  # a few problems without any template point at the coarsest level
+        sc.tpl = [[a[l] if l < sc.nl - 1 else a[l][:0] for l in range(sc.nl)] for a in sc.tpl]
+    poses0 = np.tile(S.IDENTITY_POSE, (40, 1))
+    out = []
+    for queue in (0, 1, 2):  # 1 = automatic rule (batches >= 32)
+        p = default_params()
+        p.work_queue = queue
+        trks = [hip_tracker(ctx, sc, p) for sc in scs]
+        r = ctx.track_batch(trks, poses0, np.zeros((40, 2)), 2)
+        qb = ctx.stats().queue_blocks
+        e = ctx.optimize_scale_batch(trks, np.ones(40), 2)
+        out.append((r, e, qb))
+    assert out[0][2] == 0 and out[1][2] > 0 and out[2][2] > 0
+    for r, e, _ in out[1:]:
+        for a, b in zip(r, out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(e, out[0][1]):
+            np.testing.assert_array_equal(a, b)

@@ -1,4 +1,4 @@
-"""Scheduling choices (fused LM step, persistent small-level kernel, stream groups) must never change a result:
+"""Scheduling choices (work-queue kernel, fused LM step, persistent small-level kernel, stream groups) must never change a result:
 repeated runs of mixed batches under every combination, compared bit for bit with the plain two-kernel,
 single-stream form.  A race in the ticket / staging protocols would show up here as a sporadic mismatch."""
 import numpy as np
@@ -9,11 +9,11 @@ from _scenes import S, hip_tracker, make_scene
 pytestmark = pytest.mark.gpu
 
 
-def _run(ctx, scs, fuse, ns, coarse):
+def _run(ctx, scs, fuse, ns, coarse, queue=0):
     from direct_stereo_slam_amd.tracker import default_params
 
     p = default_params()
-    p.fuse_lm, p.persistent_coarse = fuse, coarse
+    p.fuse_lm, p.persistent_coarse, p.work_queue = fuse, coarse, queue
     ctx.set_streams(ns)
     out = []
     for parity in (0, 1):  # two batches of equal image size
@@ -32,10 +32,10 @@ def test_every_schedule_gives_identical_results(ctx):
     try:
         ref = _run(ctx, scs, 0, 1, 0)
         for it in range(12):
-            for fuse, ns, coarse in ((2, 1, 0), (2, 2, 0), (1, 3, 0), (0, 2, 4096), (2, 2, 2048)):
-                got = _run(ctx, scs, fuse, ns, coarse)
+            for fuse, ns, coarse, queue in ((2, 1, 0, 0), (2, 2, 0, 0), (1, 3, 0, 0), (0, 2, 4096, 0), (2, 2, 2048, 0), (0, 1, 0, 2), (1, 2, 0, 2)):
+                got = _run(ctx, scs, fuse, ns, coarse, queue)
                 for g, r in zip(got, ref):
                     for a, b in zip(g, r):
-                        assert np.array_equal(a, b, equal_nan=True), (it, fuse, ns, coarse)
+                        assert np.array_equal(a, b, equal_nan=True), (it, fuse, ns, coarse, queue)
     finally:
         ctx.set_streams(1)
