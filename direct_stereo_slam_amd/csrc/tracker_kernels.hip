@@ -1478,36 +1478,43 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
       }
     }
 
+  constexpr int kIn16 = sizeof(EvalIn) / 16;
+  static_assert(sizeof(EvalIn) % 16 == 0 && kIn16 < 63, "EvalIn is staged with 16-byte copies by wave 0");
   for (;;) {
-    if (tid == 0) {
-      const unsigned t = atomicAdd(&q->head, 1u);
-      int prob = -1, chunk = 0;
-      for (unsigned spins = 0;; spins++) {
-        const unsigned long long v = __hip_atomic_load(&items[t & qmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == t + 1u) {
-          prob = (int)(((unsigned)v) >> kQueueChunkBits);
-          chunk = (int)(((unsigned)v) & ((1u << kQueueChunkBits) - 1u));
-          break;
+    // wave 0 takes an item and stages the problem's evaluation inputs; three workgroup barriers per item in all
+    if (tid < 64) {
+      unsigned it = 0xFFFFFFFFu;
+      if (tid == 0) {
+        const unsigned t = atomicAdd(&q->head, 1u);
+        for (unsigned spins = 0;; spins++) {
+          const unsigned long long v = __hip_atomic_load(&items[t & qmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(v >> 32) == t + 1u) {
+            it = (unsigned)v;
+            break;
+          }
+          if (q_load(&q->done) >= (unsigned)nprob || q_load((const unsigned *)&q->error)) break;
+          if (spins > (1u << 22)) { // ~ a second of polling: something is wrong -- never hang the GPU
+            __hip_atomic_store(&q->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
         }
-        if (q_load(&q->done) >= (unsigned)nprob || q_load((const unsigned *)&q->error)) break;
-        if (spins > (1u << 22)) { // ~ a second of polling: something is wrong -- never hang the GPU
-          __hip_atomic_store(&q->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
       }
-      s_ctl[0] = prob;
-      s_ctl[1] = chunk;
+      it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+      if (it != 0xFFFFFFFFu) {
+        const LMState &Sp = states[it >> kQueueChunkBits];
+        if (tid < kIn16) ((uint4 *)&s_in)[tid] = load16_coherent((const uint4 *)&Sp.in + tid);
+        if (tid == kIn16) s_ctl[2] = __hip_atomic_load(&Sp.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) {
+        s_ctl[0] = it == 0xFFFFFFFFu ? -1 : (int)(it >> kQueueChunkBits);
+        s_ctl[1] = (int)(it & ((1u << kQueueChunkBits) - 1u));
+      }
     }
     __syncthreads();
     const int prob = s_ctl[0], chunk = s_ctl[1];
     if (prob < 0) break; // workgroup-uniform
     LMState &S = states[prob];
-    constexpr int kIn16 = sizeof(EvalIn) / 16;
-    static_assert(sizeof(EvalIn) % 16 == 0, "EvalIn is staged with 16-byte copies");
-    if (tid < kIn16) ((uint4 *)&s_in)[tid] = load16_coherent((const uint4 *)&S.in + tid);
-    if (tid == 64) s_ctl[2] = __hip_atomic_load(&S.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     const int lvl = __builtin_amdgcn_readfirstlane(s_ctl[2]);
     EvalConsts c;
     {
@@ -1537,13 +1544,14 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
       else
         eval_chunk<MODE, LAYOUT, false>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this workgroup's partial is performed before its ticket
-    __syncthreads();
-    if (tid == 0) {
-      const int tk = atomicAdd(&tickets[prob], 1);
-      const int last = tk == nitems - 1;
-      if (last) __hip_atomic_store(&tickets[prob], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_ctl[3] = last;
+    if (tid < 64) { // the chunk's partial was stored by threads of wave 0 only (eval_chunk's final sum)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // performed before the arrival ticket
+      if (tid == 0) {
+        const int tk = atomicAdd(&tickets[prob], 1);
+        const int last = tk == nitems - 1;
+        if (last) __hip_atomic_store(&tickets[prob], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctl[3] = last;
+      }
     }
     __syncthreads();
     if (s_ctl[3]) { // workgroup-uniform: the problem's evaluation is complete -> its LM step, then its next evaluation
@@ -1558,7 +1566,8 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
         }
       }
     }
-    __syncthreads(); // LDS (s_ctl, s_in, red, sh) is reused by the next item
+    // no barrier here: wave 0 rewrites s_ctl[0..2] / s_in only after every wave has passed the barrier above, and all
+    // waves read them before the evaluation; the next writes of red[] / sh / s_ctl[3] follow the next item's first barrier
   }
 }
 
