@@ -11,6 +11,14 @@ SIZES = {
     "medium": (616, 184, 1, 4),
     "kitti": (1232, 368, 0, 5),  # S1: what the reference actually runs
     "odd": (240, 135, 2, 3),     # S3's floor-halved tail: 240x135 -> 120x67 -> 60x33 (odd sizes drop the last row/column)
+    # the other BASELINE.json configs' working sizes (crop keeps fx, fy and shifts cx, cy by half the removed border):
+    "kitti04": (1216, 368, 0, 5),  # configs[0]: cams/kitti/4_12/camera0.txt:1-4 (1226x370 cropped)
+    "malaga": (1024, 768, 0, 5),   # configs[2]: cams/malaga/camera0.txt:1-4
+}
+# (fx, fy, cx, cy) at the working size and the stereo baseline for sizes that are not KITTI-00
+CAMERAS = {
+    "kitti04": ((707.0912, 707.0912, 601.8873 - (1226 - 1216) / 2.0, 183.1104 - (370 - 368) / 2.0), -0.5372),
+    "malaga": ((795.11588, 795.11588, 517.12973, 395.59665), -0.119471),  # cams/malaga/T_stereo.yaml:4-7
 }
 
 
@@ -22,10 +30,15 @@ def make_scene(size="small", seed=3, noise=1.0, template="dense", idepth_scale=1
                motion_scale=1.0, wavelength_px=(8.0, 128.0)):
     w, h, klvl, nl = SIZES[size]
     K = S.level_K(S.kitti_K_work(), klvl)
+    T = S.KITTI_T_STEREO
+    if size in CAMERAS:
+        K, baseline = CAMERAS[size]
+        T = S.KITTI_T_STEREO.copy()
+        T[0, 3] = baseline
     scene = S.PlaneScene(seed=seed, fx_ref=K[0], wavelength_px=wavelength_px)
     rng = np.random.default_rng(seed + 100)
     sc = Scene()
-    sc.w, sc.h, sc.nl, sc.K, sc.T = w, h, nl, K, S.KITTI_T_STEREO
+    sc.w, sc.h, sc.nl, sc.K, sc.T = w, h, nl, K, T
     ref = scene.render(K, w, h, noise=noise, rng=rng)
     R, t = S.random_motion(rng)
     if motion_scale != 1.0:

@@ -86,6 +86,26 @@ def test_eval_parity_kitti_full_size(ctx):
     assert_eval_pose_equal(orc, trk, 0, sc.gt_pose, sc.gt_aff, 20.0)
 
 
+@pytest.mark.parametrize("size", ["kitti04", "malaga"])
+def test_eval_and_track_parity_other_baseline_shapes(ctx, size):
+    """BASELINE.json configs[0] (KITTI 04, 1216x368) and configs[2] (Malaga, 1024x768) working sizes with their own
+    intrinsics and stereo baselines: fused evaluation vs oracle at the finest and coarsest level, then the full LM."""
+    sc = make_scene(size, seed=23)
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    for lvl in (0, sc.nl - 1):
+        assert_eval_pose_equal(orc, trk, lvl, sc.gt_pose, sc.gt_aff, 20.0)
+        assert_eval_scale_equal(orc, trk, lvl, 1.0, 20.0)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    good_g, pose_g, aff_g, last_g = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    assert good_g == good_o
+    np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
+    assert list(ctx.stats().evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
+    err_o, s_o = orc.optimize_scale(1.0, sc.nl - 1)
+    err_g, s_g = trk.optimizeScale(1.0, sc.nl - 1)
+    # err = sqrt(E / N) at level 0: the oracle's E is the reference's sequential float sum (quirk Q1), good to ~n * 2^-24
+    assert abs(s_g - s_o) < 1e-4 and abs(err_g - err_o) < 5e-4 * err_o
+
+
 def test_edge_cases(ctx):
     sc = make_scene("small", seed=13)
     # ragged sizes (not multiples of 4 / 64 / 256), an empty level, and a single point
