@@ -29,7 +29,12 @@ for name in ("bench_b1", "bench_ringkey", "membw"):
         json.dump(last_json(f), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
 
 # per-kernel statistics
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+def newest(pattern):
+    """raw outputs of several profiling rounds may sit side by side (rocprofv3 names files by pid): take the latest"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
@@ -39,7 +44,7 @@ if stats:
 
 # level-0 eval kernel from the kernel trace: dispatches with work (the speculative schedule also enqueues
 # launches in which every problem has already left level 0; they take a few microseconds)
-trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
+trace = newest(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
 cfg = bench["config"]
 l0 = [k for k in cfg["pose_eval_kernels_by_level"] if k["lvl"] == 0][0]
 if trace:
@@ -86,7 +91,7 @@ if trace:
 
 
 def pmc_sum(dirname, counter):
-    files = glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv"))
+    files = newest(os.path.join(src, dirname, "*", "*counter_collection.csv"))
     if not files:
         return None, 0
     tot, n = 0.0, 0
