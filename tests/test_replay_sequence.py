@@ -172,6 +172,80 @@ def test_replay_trajectory_matches_cpu_reference(ctx):
         np.testing.assert_allclose([float(x) for x in a.split()[1:]], [float(x) for x in b.split()[1:]], atol=5e-4)
 
 
+def _active_points(scene, K, w, h, R, t, n, rng):
+    """a window's worth of active points at a keyframe: random interior pixels with the scene's inverse depth there
+    (what centerProjectedTo holds, TrackerAndScaler.cpp:155-158) and random HdiF-style weights"""
+    pu = rng.integers(3, w - 3, n).astype(np.float32)
+    pv = rng.integers(3, h - 3, n).astype(np.float32)
+    idl = scene.idepth(K, w, h, R, t)
+    pid = idl[pv.astype(int), pu.astype(int)]
+    pw = np.sqrt(1e-3 / (rng.uniform(1e-3, 10, n) + 1e-12)).astype(np.float32)
+    return pu, pv, pid, pw
+
+
+def test_replay_device_resident_semidense(ctx):
+    """the whole per-frame / per-keyframe flow with nothing but raw images and the window's active points crossing the
+    boundary: pyramids are built on the device (row N1), the semi-dense template of every keyframe is built on the device
+    from the resident keyframe pyramid (row N3), tracking and scale optimisation run there -- against the CPU path doing
+    the same with makeImages / makeCoarseDepthL0 / set_ref on the host."""
+    from direct_stereo_slam_amd.tracker import TrackerAndScaler
+
+    w, h, klvl, nl = 308, 92, 2, 3
+    K = S.level_K(S.kitti_K_work(), klvl)
+    T = S.KITTI_T_STEREO
+    scene = S.PlaneScene(seed=78, fx_ref=K[0], dist=9.0)
+    path = camera_path(26, seed=4)
+    gt = np.array([-R.T @ t for R, t in path])
+    orc = O.OracleTracker(w, h, nl, T, K)
+    orc.make_k(*K)
+    trk = TrackerAndScaler(ctx, w, h, nl, T, K)
+    trk.makeK(*K)
+    rng = np.random.default_rng(5)
+    trajs = {"cpu": [], "gpu": []}
+    kf_pose = {"cpu": None, "gpu": None}
+    last_rel = {"cpu": S.IDENTITY_POSE.copy(), "gpu": S.IDENTITY_POSE.copy()}
+    n_tpl = []
+    for i, (R, t) in enumerate(path):
+        img = scene.render(K, w, h, R, t, noise=1.0, rng=rng)
+        pyr = O.make_images(img, nl)      # CPU path: host pyramid
+        trk.upload_image(0, img, 1.0)     # GPU path: raw image in, pyramid built on the device
+        est = {}
+        if i == 0:
+            est["cpu"] = est["gpu"] = S.pose_from_Rt(R, t)
+        else:
+            orc.set_frame(0, pyr, 1.0)
+            go, po, _, _, _ = orc.track(last_rel["cpu"], [0.0, 0.0], nl - 1)
+            gg, pg, _, _ = trk.trackNewestCoarse(last_rel["gpu"], [0.0, 0.0], nl - 1)
+            assert go and gg, f"tracking lost at frame {i}"
+            assert list(ctx.stats().evals)[:nl] == orc.eval_counts()[0][:nl]
+            last_rel["cpu"], last_rel["gpu"] = po, pg
+            est["cpu"], est["gpu"] = mul_pose(po, kf_pose["cpu"]), mul_pose(pg, kf_pose["gpu"])
+        for k in ("cpu", "gpu"):
+            trajs[k].append(-S.quat_to_rot(est[k][:4]).T @ est[k][4:])
+        if i % 5 == 0:
+            pu, pv, pid, pw = _active_points(scene, K, w, h, R, t, 2500, rng)
+            tpl = orc.make_coarse_depth_l0(pu, pv, pid, pw, pyr)
+            orc.set_ref(i, 0.0, 0.0, 1.0, *tpl)
+            n = trk.setCoarseTrackingRefFromPoints(i, (0.0, 0.0), 1.0, pu, pv, pid, pw)  # keyframe pyramid = slot 0
+            assert n == [len(a) for a in tpl[0]]
+            n_tpl.append(n[0])
+            Rr, tr = T[:3, :3] @ R, T[:3, :3] @ t + T[:3, 3]
+            right = scene.render(K, w, h, Rr, tr, noise=1.0, rng=rng)
+            orc.set_frame(1, O.make_images(right, nl), 1.0)
+            trk.upload_image(1, right, 1.0)
+            eo, so = orc.optimize_scale(1.0, nl - 1)
+            eg, sg = trk.optimizeScale(1.0, nl - 1)
+            assert abs(sg - so) < 1e-4 and abs(eg - eo) < 1e-3 * eo
+            for k in ("cpu", "gpu"):
+                kf_pose[k] = est[k]
+                last_rel[k] = S.IDENTITY_POSE.copy()
+    ate_o, ate_g = ate(trajs["cpu"], gt), ate(trajs["gpu"], gt)
+    assert ate_o < 0.03 and ate_g < 0.03, (ate_o, ate_g)
+    assert abs(ate_g - ate_o) <= 0.01 * ate_o + 1e-5, (ate_g, ate_o)
+    assert ate(trajs["gpu"], trajs["cpu"]) < 2e-4
+    assert min(n_tpl) > 5000  # dilation: several template points per active point
+
+
 def test_replay_loop_closure_candidates_bit_exact(ctx):
     """ring keys of a 260-keyframe loop (revisiting the start) through search_ringkey: the GPU database
     returns exactly the oracle's candidate lists, and the revisits are detected"""
