@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
+    ap.add_argument("--pinned", action="store_true", help="with --with-upload: the host images live in pinned memory (dsm_host_alloc)")
     ap.add_argument("--queue", type=int, default=0,
                     help="dsm_params.work_queue: 0 (default here) launch-per-step form -- its dominant kernel, the level-0 evaluation, is "
                          "timed per launch for the roofline; 1 the library's automatic rule (batches >= 32); 2 the whole call as one "
@@ -161,7 +162,14 @@ def build_workload(args, ctx, rank):
         trk.upload_image(1, right, 1.0)
         trackers.append(trk)
         gts.append(gt)
-        images.append((np.ascontiguousarray(new, np.float32), np.ascontiguousarray(right, np.float32)))
+        if args.with_upload and args.pinned:
+            from direct_stereo_slam_amd.tracker import pinned_array
+
+            pl, pr = pinned_array(new.shape), pinned_array(right.shape)
+            pl[...], pr[...] = new, right
+            images.append((pl, pr))
+        else:
+            images.append((np.ascontiguousarray(new, np.float32), np.ascontiguousarray(right, np.float32)))
         if b < args.cpu_frames:
             host.append((tpl, new, right))
     return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params, images=images)

@@ -83,6 +83,8 @@ SYMBOLS = {
     "dsm_tracker_get_template": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "dsm_tracker_upload_frame": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
     "dsm_tracker_upload_image": (C.c_int, [_vp, C.c_int, c_float_p, C.c_float]),
+    "dsm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "dsm_host_free": (C.c_int, [_vp]),
     "dsm_tracker_get_frame": (C.c_int, [_vp, C.c_int, C.c_int, c_float_p]),
     "dsm_tracker_calc_res_pose": (C.c_int, [_vp, C.c_int, c_double_p, c_double_p, C.c_float, c_double_p, c_double_p, c_double_p, c_int_p]),
     "dsm_tracker_calc_res_scale": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, c_double_p, c_float_p, c_float_p, c_int_p]),

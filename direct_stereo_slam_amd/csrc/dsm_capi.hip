@@ -198,6 +198,7 @@ int dsm_context_create(int device_ordinal, dsm_context **out) {
   DSM_HIP(hipEventCreate(&ctx->ev_total[0]));
   DSM_HIP(hipEventCreate(&ctx->ev_total[1]));
   DSM_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+  DSM_HIP(hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
   *out = ctx;
   return DSM_OK;
 }
@@ -226,6 +227,7 @@ int dsm_context_destroy(dsm_context *ctx) {
   for (hipEvent_t ev : ctx->join_events) hipEventDestroy(ev);
   for (hipStream_t st : ctx->extra_streams) hipStreamDestroy(st);
   hipEventDestroy(ctx->fork_event);
+  hipEventDestroy(ctx->copy_event);
   hipEventDestroy(ctx->ev_total[0]);
   hipEventDestroy(ctx->ev_total[1]);
   hipStreamDestroy(ctx->stream);
@@ -327,6 +329,8 @@ int dsm_tracker_destroy(dsm_tracker *t) {
     hipFree(t->d_img[0][l]);
     hipFree(t->d_img[1][l]);
   }
+  hipFree(t->d_raw[0]);
+  hipFree(t->d_raw[1]);
   hipFree(t->d_desc);
   delete t;
   return DSM_OK;
@@ -504,20 +508,35 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   DSM_HIP(hipSetDevice(ctx->device));
   const int layout = t->desc.layout;
   const size_t npx0 = (size_t)t->w * t->h;
-  int rc = ensure_stage(ctx, npx0);
-  if (rc) return rc;
-  DSM_HIP(hipMemcpyAsync(ctx->d_stage, image, npx0 * 4, hipMemcpyHostToDevice, ctx->stream));
-  launch_pyr_level0(ctx->stream, t->w, t->h, ctx->d_stage, t->d_img[slot][0], layout);
+  // the raw image is staged in a buffer of this tracker and slot, so that nothing but the host->device copy has to finish
+  // before the call returns (the caller's buffer is free again); the pyramid kernels run on behind it.  With a pinned
+  // caller buffer (dsm_host_alloc) the copy is a straight DMA.
+  if (!t->d_raw[slot]) DSM_HIP(hipMalloc(&t->d_raw[slot], npx0 * sizeof(float)));
+  DSM_HIP(hipMemcpyAsync(t->d_raw[slot], image, npx0 * 4, hipMemcpyHostToDevice, ctx->stream));
+  DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
+  launch_pyr_level0(ctx->stream, t->w, t->h, t->d_raw[slot], t->d_img[slot][0], layout);
   for (int l = 0; l < t->nlevels; l++) {
     const int wl = t->w >> l, hl = t->h >> l;
     if (l > 0) launch_pyr_down(ctx->stream, t->w >> (l - 1), wl, hl, t->d_img[slot][l - 1], t->d_img[slot][l], layout);
     launch_pyr_grad(ctx->stream, wl, hl, t->d_img[slot][l], layout);
   }
   DSM_HIP(hipGetLastError());
-  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  DSM_HIP(hipEventSynchronize(ctx->copy_event));
   t->desc.exposure[slot] = ab_exposure;
   t->have_frame[slot] = true;
   t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_host_alloc(size_t bytes, void **out) {
+  if (!out || bytes == 0) return invalid("dsm_host_alloc: bad argument");
+  *out = nullptr;
+  DSM_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return DSM_OK;
+}
+
+int dsm_host_free(void *p) {
+  if (p) DSM_HIP(hipHostFree(p));
   return DSM_OK;
 }
 

@@ -28,6 +28,7 @@ struct dsm_context {
   std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> join_events;
   hipEvent_t fork_event = nullptr;
+  hipEvent_t copy_event = nullptr; // end of a host->device hand-over (dsm_tracker_upload_image)
   // batch workspaces (grown on demand)
   int cap_prob = 0;
   int partial_stride = 0; // floats per problem
@@ -68,6 +69,7 @@ struct dsm_tracker {
   float4 *d_pts[DSM_MAX_LEVELS] = {};
   int pts_cap[DSM_MAX_LEVELS] = {}; // template capacity per level (w_l*h_l; w*h on every level for the pose estimator)
   float *d_img[2][DSM_MAX_LEVELS] = {};
+  float *d_raw[2] = {nullptr, nullptr}; // raw level-0 images of dsm_tracker_upload_image, per slot
   bool have_k = false, have_ref = false, have_frame[2] = {false, false};
   int ref_frame_id = -1;
   bool desc_dirty = true;

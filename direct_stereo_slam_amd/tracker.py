@@ -30,6 +30,38 @@ def _ptr_array(arrs):
     return arr
 
 
+def pinned_array(shape, dtype=np.float32):
+    """numpy array backed by pinned host memory (dsm_host_alloc): dsm_tracker_upload_image copies from it by DMA.
+    The memory is released when the array is garbage collected."""
+    L = _lib.load()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    check(L.dsm_host_alloc(n, C.byref(p)))
+    buf = (C.c_char * n).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                L.dsm_host_free(self.ptr)
+            except Exception:
+                pass
+
+    owner = _Owner(p)
+    out = arr.view()
+    _PINNED_OWNERS[id(out)] = (owner, buf)
+    import weakref
+
+    weakref.finalize(out, _PINNED_OWNERS.pop, id(out), None)
+    return out
+
+
+_PINNED_OWNERS = {}
+
+
 def default_params():
     p = Params()
     _lib.load().dsm_params_default(C.byref(p))

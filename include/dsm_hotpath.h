@@ -163,6 +163,10 @@ int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, 
 /* "next" row N1: build the (I,dx,dy) pyramid on the device from the level-0 float image
  * (upstream DSO FrameHessian::makeImages, call sites FrontEnd.cpp:605,680). */
 int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure);
+/* pinned host memory for images handed to dsm_tracker_upload_image (straight DMA instead of a staged copy); no reference
+ * counterpart -- the reference keeps its images in ordinary host memory */
+int dsm_host_alloc(size_t bytes, void **out);
+int dsm_host_free(void *p);
 /* read back one pyramid level (AoS float3) */
 int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out);
 
