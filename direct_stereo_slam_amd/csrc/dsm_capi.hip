@@ -514,12 +514,7 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   if (!t->d_raw[slot]) DSM_HIP(hipMalloc(&t->d_raw[slot], npx0 * sizeof(float)));
   DSM_HIP(hipMemcpyAsync(t->d_raw[slot], image, npx0 * 4, hipMemcpyHostToDevice, ctx->stream));
   DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
-  launch_pyr_level0(ctx->stream, t->w, t->h, t->d_raw[slot], t->d_img[slot][0], layout);
-  for (int l = 0; l < t->nlevels; l++) {
-    const int wl = t->w >> l, hl = t->h >> l;
-    if (l > 0) launch_pyr_down(ctx->stream, t->w >> (l - 1), wl, hl, t->d_img[slot][l - 1], t->d_img[slot][l], layout);
-    launch_pyr_grad(ctx->stream, wl, hl, t->d_img[slot][l], layout);
-  }
+  launch_pyramid(ctx->stream, t->w, t->h, t->nlevels, t->d_raw[slot], t->d_img[slot], layout);
   DSM_HIP(hipGetLastError());
   DSM_HIP(hipEventSynchronize(ctx->copy_event));
   t->desc.exposure[slot] = ab_exposure;

@@ -82,9 +82,7 @@ void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
 void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out);
 void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out);
 // makeImages (upstream DSO): level 0 from the float image, level l from level l-1; layout aware
-void launch_pyr_level0(hipStream_t s, int w, int h, const float *image, float *out, int layout);
-void launch_pyr_down(hipStream_t s, int w_prev, int wl, int hl, const float *prev, float *out, int layout);
-void launch_pyr_grad(hipStream_t s, int wl, int hl, float *img, int layout);
+void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout);
 
 // ring-key kernels
 void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim,

@@ -1669,48 +1669,44 @@ void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out) {
 // makeImages (upstream DSO FrameHessian::makeImages; call sites FrontEnd.cpp:605,680)
 // texel stride TS = 3 (AOS3) or 4 (AOS4)
 // ------------------------------------------------------------------------------------------
-__global__ void pyr_level0_kernel(int npx, const float *__restrict__ image, float *__restrict__ out, int TS) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    out[TS * i] = image[i];
-    out[TS * i + 1] = 0.f;
-    out[TS * i + 2] = 0.f;
-    if (TS == 4) out[TS * i + 3] = 0.f;
-  }
-}
-__global__ void pyr_down_kernel(int wlm1, int wl, int hl, const float *__restrict__ prev,
-                                float *__restrict__ out, int TS) {
-  const int npx = wl * hl;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const int x = i % wl, y = i / wl;
-    const int b = 2 * x + 2 * y * wlm1;
-    out[TS * i] = 0.25f * (prev[TS * b] + prev[TS * (b + 1)] + prev[TS * (b + wlm1)] + prev[TS * (b + 1 + wlm1)]);
-    out[TS * i + 1] = 0.f;
-    out[TS * i + 2] = 0.f;
-    if (TS == 4) out[TS * i + 3] = 0.f;
-  }
-}
-__global__ void pyr_grad_kernel(int wl, int hl, float *img, int TS) {
+// One launch per pyramid level: gradients of level l (central differences on the flat index, borders zero -- upstream
+// DSO FrameHessian::makeImages) and the intensities of level l+1 (2x2 mean, 0.25 * (a + b + c + d)) both read
+// only the intensities of level l.  src: those intensities with element stride `ss` (1: the raw level-0 image,
+// TS: the I channel of out_l itself for l >= 1).
+__global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, int ss, float *__restrict__ out_l,
+                                       float *__restrict__ out_next, int TS) {
+  const int npx = wl * hl, wn = wl >> 1, hn = hl >> 1;
   const int lo = wl, hi = wl * (hl - 1);
-  for (int idx = lo + blockIdx.x * blockDim.x + threadIdx.x; idx < hi; idx += gridDim.x * blockDim.x) {
-    float dx = 0.5f * (img[TS * (idx + 1)] - img[TS * (idx - 1)]);
-    float dy = 0.5f * (img[TS * (idx + wl)] - img[TS * (idx - wl)]);
-    if (!__builtin_isfinite(dx)) dx = 0;
-    if (!__builtin_isfinite(dy)) dy = 0;
-    img[TS * idx + 1] = dx;
-    img[TS * idx + 2] = dy;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npx; idx += gridDim.x * blockDim.x) {
+    float dx = 0.f, dy = 0.f;
+    if (idx >= lo && idx < hi) {
+      dx = 0.5f * (src[ss * (idx + 1)] - src[ss * (idx - 1)]);
+      dy = 0.5f * (src[ss * (idx + wl)] - src[ss * (idx - wl)]);
+      if (!__builtin_isfinite(dx)) dx = 0;
+      if (!__builtin_isfinite(dy)) dy = 0;
+    }
+    if (ss == 1) {
+      out_l[TS * idx] = src[idx];
+      if (TS == 4) out_l[TS * idx + 3] = 0.f;
+    }
+    out_l[TS * idx + 1] = dx;
+    out_l[TS * idx + 2] = dy;
+    if (out_next && idx < wn * hn) {
+      const int x = idx % wn, y = idx / wn;
+      const int b = 2 * x + 2 * y * wl;
+      out_next[TS * idx] = 0.25f * (src[ss * b] + src[ss * (b + 1)] + src[ss * (b + wl)] + src[ss * (b + 1 + wl)]);
+      if (TS == 4) out_next[TS * idx + 3] = 0.f;
+    }
   }
 }
-void launch_pyr_level0(hipStream_t s, int w, int h, const float *image, float *out, int layout) {
-  hipLaunchKernelGGL(pyr_level0_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w * h, image, out,
-                     layout == IMG_AOS3 ? 3 : 4);
-}
-void launch_pyr_down(hipStream_t s, int w_prev, int wl, int hl, const float *prev, float *out, int layout) {
-  hipLaunchKernelGGL(pyr_down_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, w_prev, wl, hl, prev, out,
-                     layout == IMG_AOS3 ? 3 : 4);
-}
-void launch_pyr_grad(hipStream_t s, int wl, int hl, float *img, int layout) {
-  hipLaunchKernelGGL(pyr_grad_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, img,
-                     layout == IMG_AOS3 ? 3 : 4);
+// raw: the level-0 float image; img[l]: the AoS pyramid levels
+void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout) {
+  const int TS = layout == IMG_AOS3 ? 3 : 4;
+  for (int l = 0; l < nlevels; l++) {
+    const int wl = w >> l, hl = h >> l;
+    hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, l == 0 ? raw : img[l], l == 0 ? 1 : TS, img[l],
+                       l + 1 < nlevels ? img[l + 1] : nullptr, TS);
+  }
 }
 
 } // namespace dsm
