@@ -387,7 +387,8 @@ def bench_ringkey(args):
     def step():
         db.knn_packed_device(dq.data_ptr(), args.rk_q, out.data_ptr())
         ctx.sync()
-        return merge_topk_allreduce_min(out, 3, allmin)
+        # one shard: the local sorted top-k is the global one; G shards: k rounds of all-reduce(min) with winner pop
+        return out if world == 1 else merge_topk_allreduce_min(out, 3, allmin)
 
     for _ in range(args.warmup):
         step()

@@ -89,7 +89,7 @@ void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t 
                         int k, float thres, int shard_rank, int shard_count, const float *d_queries,
                         int nq, unsigned long long *d_scratch, int n_slices,
                         unsigned long long *d_packed_out);
-int ringkey_num_slices(int64_t n_local, int nq);
+int ringkey_num_slices(int64_t n_local, int nq, int dim);
 void launch_ringkey_insert(hipStream_t s, float *keysT, int64_t cap, int64_t pos, int dim,
                            const float *d_key, int nkeys);
 

@@ -88,7 +88,7 @@ static int rdb_append(dsm_ringdb *db, const float *keys, int64_t n) {
 }
 
 static int rdb_knn_dev(dsm_ringdb *db, const float *d_queries, int nq, unsigned long long *d_out) {
-  const int n_slices = ringkey_num_slices(db->n_local, nq);
+  const int n_slices = ringkey_num_slices(db->n_local, nq, db->dim);
   const size_t need = (size_t)n_slices * nq * db->k;
   if (need > db->scratch_words) {
     if (db->d_scratch) DSM_HIP(hipFree(db->d_scratch));

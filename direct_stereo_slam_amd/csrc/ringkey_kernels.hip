@@ -101,6 +101,89 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__
   }
 }
 
+// Few queries (the SLAM case: one ring key per keyframe, a handful with several concurrent sequences): one thread =
+// one key, the queries of a group of kRkQG sit in LDS and are broadcast, every thread keeps a top-K per query over the
+// keys it visits, the workgroup merges them at the end.  One sweep of the key planes per query group, fully coalesced:
+// HBM-bound (80 bytes per key) instead of one busy lane per query.  Same per-pair distance expression, same packed
+// candidates, same scratch layout as ringkey_knn_kernel -- bit-identical results.
+constexpr int kRkQG = 8;
+
+template <int DIM, int K>
+__global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const float *__restrict__ keysT, long long cap, long long n_local,
+                                                                      float thres, int shard_rank, int shard_count,
+                                                                      const float *__restrict__ queries, int nq, int n_slices,
+                                                                      unsigned long long *__restrict__ scratch) {
+  static_assert(DIM % 4 == 0, "flann::L2 main loop only");
+  __shared__ __attribute__((aligned(16))) float qs[kRkQG][DIM];
+  __shared__ unsigned long long wtop[kRkThreads / 64][kRkQG][K];
+  const int slice = blockIdx.x, q0 = blockIdx.y * kRkQG;
+  const int nqg = nq - q0 < kRkQG ? nq - q0 : kRkQG;
+  const long long per = (n_local + n_slices - 1) / n_slices;
+  const long long k0 = (long long)slice * per;
+  const long long k1 = k0 + per < n_local ? k0 + per : n_local;
+  for (int e = threadIdx.x; e < kRkQG * DIM; e += kRkThreads) {
+    const int qq = e / DIM, j = e % DIM;
+    qs[qq][j] = qq < nqg ? queries[(size_t)(q0 + qq) * DIM + j] : 0.f;
+  }
+  __syncthreads();
+  unsigned long long best[kRkQG][K];
+#pragma unroll
+  for (int qq = 0; qq < kRkQG; qq++)
+#pragma unroll
+    for (int j = 0; j < K; j++) best[qq][j] = kNoCand;
+  for (long long i = k0 + threadIdx.x; i < k1; i += kRkThreads) {
+    float kv[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; j++) kv[j] = keysT[(size_t)j * cap + i];
+    const unsigned long long g = (unsigned long long)i * shard_count + shard_rank;
+#pragma unroll
+    for (int qq = 0; qq < kRkQG; qq++) {
+      float result = 0.f;
+#pragma unroll
+      for (int j = 0; j < DIM; j += 4) { // flann::L2 main loop
+        const float d0 = qs[qq][j] - kv[j], d1 = qs[qq][j + 1] - kv[j + 1], d2 = qs[qq][j + 2] - kv[j + 2],
+                    d3 = qs[qq][j + 3] - kv[j + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+      if (qq < nqg && result < thres) topk_insert<K>(best[qq], ((unsigned long long)__float_as_uint(result) << 32) | g);
+    }
+  }
+  // per wave and query: K rounds of wave-min extraction (the winner lane pops its head) -> LDS; then one thread per
+  // query merges the waves' lists
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int qq = 0; qq < kRkQG; qq++) {
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+      unsigned long long m = best[qq][0];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o < m ? o : m;
+      }
+      if (lane == 0) wtop[wave][qq][r] = m;
+      if (m != kNoCand && best[qq][0] == m) { // packed candidates are unique (global index in the low bits)
+#pragma unroll
+        for (int j = 0; j + 1 < K; j++) best[qq][j] = best[qq][j + 1];
+        best[qq][K - 1] = kNoCand;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nqg) {
+    const int qq = threadIdx.x;
+    unsigned long long t[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = kNoCand;
+    for (int w = 0; w < kRkThreads / 64; w++)
+#pragma unroll
+      for (int j = 0; j < K; j++)
+        if (wtop[w][qq][j] != kNoCand) topk_insert<K>(t, wtop[w][qq][j]);
+#pragma unroll
+    for (int j = 0; j < K; j++) scratch[((size_t)slice * nq + q0 + qq) * K + j] = t[j];
+  }
+}
+
 // one wave per query merges the per-slice candidates
 template <int K>
 __global__ __launch_bounds__(64) void ringkey_merge_kernel(const unsigned long long *__restrict__ scratch, int nq,
@@ -144,7 +227,16 @@ __global__ void ringkey_insert_kernel(float *keysT, long long cap, long long pos
   }
 }
 
-int ringkey_num_slices(int64_t n_local, int nq) {
+constexpr int kRkFewQueries = 32; // up to here the thread-per-key kernel is used (dim 20 only)
+static bool ringkey_use_fewq(int dim, int nq) { return dim == 20 && nq <= kRkFewQueries; }
+
+int ringkey_num_slices(int64_t n_local, int nq, int dim) {
+  if (ringkey_use_fewq(dim, nq)) {
+    // about eight workgroups per CU for one query group, at least 1024 keys (four per thread) per workgroup
+    int64_t s = (n_local + 1023) / 1024;
+    if (s > 2048) s = 2048;
+    return (int)(s < 1 ? 1 : s);
+  }
   // enough workgroups to fill 256 CUs, at least one key tile per slice
   const int qblocks = (nq + kRkThreads - 1) / kRkThreads;
   int64_t want = 2048 / (qblocks > 0 ? qblocks : 1);
@@ -161,7 +253,10 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
                          int shard_rank, int shard_count, const float *d_queries, int nq,
                          unsigned long long *d_scratch, int n_slices, unsigned long long *d_packed_out) {
   dim3 grid((nq + kRkThreads - 1) / kRkThreads, n_slices), block(kRkThreads);
-  if (dim == 20)
+  if (ringkey_use_fewq(dim, nq))
+    hipLaunchKernelGGL((ringkey_knn_fewq_kernel<20, K>), dim3(n_slices, (nq + kRkQG - 1) / kRkQG), block, 0, s, keysT, (long long)cap,
+                       (long long)n_local, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
+  else if (dim == 20)
     hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
                        thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
   else
