@@ -106,29 +106,29 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__
 // keys it visits, the workgroup merges them at the end.  One sweep of the key planes per query group, fully coalesced:
 // HBM-bound (80 bytes per key) instead of one busy lane per query.  Same per-pair distance expression, same packed
 // candidates, same scratch layout as ringkey_knn_kernel -- bit-identical results.
-constexpr int kRkQG = 8;
+constexpr int kRkQG = 8; // largest query group
 
-template <int DIM, int K>
+template <int DIM, int K, int QG>
 __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const float *__restrict__ keysT, long long cap, long long n_local,
                                                                       float thres, int shard_rank, int shard_count,
                                                                       const float *__restrict__ queries, int nq, int n_slices,
                                                                       unsigned long long *__restrict__ scratch) {
   static_assert(DIM % 4 == 0, "flann::L2 main loop only");
-  __shared__ __attribute__((aligned(16))) float qs[kRkQG][DIM];
-  __shared__ unsigned long long wtop[kRkThreads / 64][kRkQG][K];
-  const int slice = blockIdx.x, q0 = blockIdx.y * kRkQG;
-  const int nqg = nq - q0 < kRkQG ? nq - q0 : kRkQG;
+  __shared__ __attribute__((aligned(16))) float qs[QG][DIM];
+  __shared__ unsigned long long wtop[kRkThreads / 64][QG][K];
+  const int slice = blockIdx.x, q0 = blockIdx.y * QG;
+  const int nqg = nq - q0 < QG ? nq - q0 : QG;
   const long long per = (n_local + n_slices - 1) / n_slices;
   const long long k0 = (long long)slice * per;
   const long long k1 = k0 + per < n_local ? k0 + per : n_local;
-  for (int e = threadIdx.x; e < kRkQG * DIM; e += kRkThreads) {
+  for (int e = threadIdx.x; e < QG * DIM; e += kRkThreads) {
     const int qq = e / DIM, j = e % DIM;
     qs[qq][j] = qq < nqg ? queries[(size_t)(q0 + qq) * DIM + j] : 0.f;
   }
   __syncthreads();
-  unsigned long long best[kRkQG][K];
+  unsigned long long best[QG][K];
 #pragma unroll
-  for (int qq = 0; qq < kRkQG; qq++)
+  for (int qq = 0; qq < QG; qq++)
 #pragma unroll
     for (int j = 0; j < K; j++) best[qq][j] = kNoCand;
   for (long long i = k0 + threadIdx.x; i < k1; i += kRkThreads) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const floa
     for (int j = 0; j < DIM; j++) kv[j] = keysT[(size_t)j * cap + i];
     const unsigned long long g = (unsigned long long)i * shard_count + shard_rank;
 #pragma unroll
-    for (int qq = 0; qq < kRkQG; qq++) {
+    for (int qq = 0; qq < QG; qq++) {
       float result = 0.f;
 #pragma unroll
       for (int j = 0; j < DIM; j += 4) { // flann::L2 main loop
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const floa
   // query merges the waves' lists
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int qq = 0; qq < kRkQG; qq++) {
+  for (int qq = 0; qq < QG; qq++) {
 #pragma unroll
     for (int r = 0; r < K; r++) {
       unsigned long long m = best[qq][0];
@@ -253,10 +253,20 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
                          int shard_rank, int shard_count, const float *d_queries, int nq,
                          unsigned long long *d_scratch, int n_slices, unsigned long long *d_packed_out) {
   dim3 grid((nq + kRkThreads - 1) / kRkThreads, n_slices), block(kRkThreads);
-  if (ringkey_use_fewq(dim, nq))
-    hipLaunchKernelGGL((ringkey_knn_fewq_kernel<20, K>), dim3(n_slices, (nq + kRkQG - 1) / kRkQG), block, 0, s, keysT, (long long)cap,
-                       (long long)n_local, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
-  else if (dim == 20)
+  if (ringkey_use_fewq(dim, nq)) {
+#define DSM_FEWQ(QG)                                                                                                   \
+  hipLaunchKernelGGL((ringkey_knn_fewq_kernel<20, K, QG>), dim3(n_slices, (nq + QG - 1) / QG), block, 0, s, keysT, (long long)cap,       \
+                     (long long)n_local, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch)
+    if (nq == 1)
+      DSM_FEWQ(1);
+    else if (nq == 2)
+      DSM_FEWQ(2);
+    else if (nq <= 4)
+      DSM_FEWQ(4);
+    else
+      DSM_FEWQ(8);
+#undef DSM_FEWQ
+  } else if (dim == 20)
     hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
                        thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
   else
