@@ -399,13 +399,19 @@ def bench_ringkey(args):
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     if rank == 0:
-        sweep = 80 * args.rk_n + 104 * args.rk_q
+        groups = (args.rk_q + 7) // 8 if 8 < args.rk_q <= 32 else 1  # the few-query kernel sweeps the keys once per query group
+        sweep = 80 * args.rk_n * groups + 104 * args.rk_q
         print(json.dumps({"metric": "ring-key k=3 queries/s over a sharded DB", "value": args.rk_q * args.steps / dt,
                           "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"ring-key DB N={args.rk_n} x 20 float, Q={args.rk_q}, k=3, thres 0.1",
-                                     "db_sweep_GBps": sweep * args.steps / dt / 1e9}}))
+                                     "db_sweep_GBps": sweep * args.steps / dt / 1e9},
+                          # HBM roofline of the scan for few queries (one sweep of the 80-byte keys per group of <= 8 queries);
+                          # with many queries per key the scan is VALU-bound and this figure is only informative
+                          "roofline": {"bound": "hbm", "achieved": sweep * args.steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": sweep * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "kernel": "ringkey_knn_fewq_kernel" if args.rk_q <= 32 else "ringkey_knn_kernel (VALU-bound)"}}))
     if world > 1:
         import torch.distributed as dist
 
