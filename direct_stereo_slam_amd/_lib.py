@@ -107,6 +107,7 @@ SYMBOLS = {
     "dsm_ringdb_knn_packed_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "dsm_ringdb_knn_packed_host": (C.c_int, [_vp, c_float_p, C.c_int, c_int64_p]),
     "dsm_scancontext_generate": (C.c_int, [c_double_p, C.c_int, C.c_double, C.c_int, C.c_int, c_float_p, c_int_p, c_double_p, c_int_p, c_double_p]),
+    "dsm_generate_spherical_points": (C.c_int, [C.c_int, c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p]),
     "dsm_make_coarse_depth_l0": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, _pp_f, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
     "dsm_sc_distance": (C.c_float, [c_int_p, c_double_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
     "dsm_search_sc": (C.c_int, [c_int_p, c_double_p, C.c_int, C.c_int, c_int_p, _pp_i, _pp_d, c_int_p, C.c_int, c_int_p, c_float_p]),

@@ -178,6 +178,121 @@ int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int n
 }
 
 // ---------------------------------------------------------------------------------------------
+// generate_spherical_points, src/loop_closure/loop_detection/generate_spherical_points.h:27-85 (flat-array form)
+// ---------------------------------------------------------------------------------------------
+namespace {
+// Sophus SO3::exp as a rotation matrix (Rodrigues; the series below 1e-10 as Sophus does for the quaternion)
+void so3_exp_matrix(const double w[3], double R[9]) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double th = std::sqrt(th2);
+  double a, b; // R = I + a W + b W^2
+  if (th < 1e-10) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+  } else {
+    a = std::sin(th) / th;
+    b = (1.0 - std::cos(th)) / th2;
+  }
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double w2 = 0;
+      for (int k = 0; k < 3; k++) w2 += W[i * 3 + k] * W[k * 3 + j];
+      R[i * 3 + j] = (i == j ? 1.0 : 0.0) + a * W[i * 3 + j] + b * w2;
+    }
+}
+// |SO3::log(R)|: the angle of the shortest rotation, from the unit quaternion as Sophus does (2 atan(|v| / w))
+double rotation_angle(const double R[9]) {
+  // Eigen quaternion-from-matrix, the branch with the largest pivot
+  const double tr = R[0] + R[4] + R[8];
+  double q[4]; // x y z w
+  if (tr > 0) {
+    double t = std::sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t, q[1] = (R[2] - R[6]) * t, q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  if (n < 1e-10) return 0.0;
+  if (std::fabs(q[3]) < 1e-10) return M_PI;
+  return std::fabs(2.0 * std::atan(n / q[3]));
+}
+} // namespace
+
+int dsm_generate_spherical_points(int n_kf, const int *kf_ids, const double *kf_pose_wc, const double *cur_cw, double lidar_range,
+                                  int n_pts, const int *pt_kf_id, const double *pt_xyz, int *kf_keep, int *n_out, int *sel_idx,
+                                  double *pts_spherical) {
+  if (n_kf < 0 || n_pts < 0 || !cur_cw || !n_out || !(lidar_range > 0) || (n_kf && (!kf_ids || !kf_pose_wc || !kf_keep)) ||
+      (n_pts && (!pt_kf_id || !pt_xyz || !sel_idx || !pts_spherical)))
+    return DSM_ERR_INVALID;
+  // :33-41 keyframes whose orientation differs from the current one by more than 0.5 rad are trimmed
+  std::vector<std::pair<int, int>> keep_ids; // (id, kept)
+  for (int k = 0; k < n_kf; k++) {
+    double Rk[9], Rd[9];
+    so3_exp_matrix(kf_pose_wc + 6 * k + 3, Rk);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Rd[i * 3 + j] = cur_cw[i * 4 + 0] * Rk[0 * 3 + j] + cur_cw[i * 4 + 1] * Rk[1 * 3 + j] + cur_cw[i * 4 + 2] * Rk[2 * 3 + j];
+    kf_keep[k] = rotation_angle(Rd) > 0.5 ? 0 : 1;
+    keep_ids.push_back(std::make_pair(kf_ids[k], kf_keep[k]));
+  }
+  std::sort(keep_ids.begin(), keep_ids.end());
+  auto kept = [&](int id) {
+    auto it = std::lower_bound(keep_ids.begin(), keep_ids.end(), std::make_pair(id, 0));
+    for (; it != keep_ids.end() && it->first == id; ++it)
+      if (it->second) return true;
+    return false; // unknown keyframe: `find == end` (:55)
+  };
+  // :44-50
+  const double steps[3] = {1.0 / 1.0, 1.0 / 0.5, 1.0 / 1.0}; // RES_X, RES_Y, RES_Z (:23-25)
+  const long long vs0 = (long long)std::floor(2 * lidar_range * steps[0]) + 1, vs1 = (long long)std::floor(2 * lidar_range * steps[1]) + 1;
+  struct Cell {
+    int idx;
+    double p[3];
+  };
+  std::vector<std::pair<long long, Cell>> cells;
+  cells.reserve(n_pts);
+  for (int i = 0; i < n_pts; i++) { // :52-77
+    if (!kept(pt_kf_id[i])) continue;
+    const double *g = pt_xyz + 3 * (size_t)i;
+    double p[3];
+    for (int r = 0; r < 3; r++) p[r] = ((cur_cw[r * 4 + 0] * g[0] + cur_cw[r * 4 + 1] * g[1]) + cur_cw[r * 4 + 2] * g[2]) + cur_cw[r * 4 + 3] * 1.0;
+    if (std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) >= lidar_range) continue;
+    const long long xi = (long long)std::floor((p[0] + lidar_range) * steps[0]), yi = (long long)std::floor((p[1] + lidar_range) * steps[1]),
+                    zi = (long long)std::floor((p[2] + lidar_range) * steps[2]);
+    Cell c;
+    c.idx = i, c.p[0] = p[0], c.p[1] = p[1], c.p[2] = p[2];
+    cells.push_back(std::make_pair(xi + yi * vs0 + zi * vs0 * vs1, c));
+  }
+  // "store the highest points" (:73-76): per voxel the point with the smallest y; the first one wins ties.  The reference
+  // emits its unordered_map in implementation-defined order; here: ascending voxel index (ScanContext::generate does not
+  // depend on the order beyond the rounding of its PCA sums).
+  std::stable_sort(cells.begin(), cells.end(), [](const std::pair<long long, Cell> &a, const std::pair<long long, Cell> &b) { return a.first < b.first; });
+  int n = 0;
+  for (size_t a = 0; a < cells.size();) {
+    size_t b = a, win = a;
+    for (; b < cells.size() && cells[b].first == cells[a].first; b++)
+      if (cells[b].second.p[1] < cells[win].second.p[1]) win = b; // -stored.y < -p.y
+    sel_idx[n] = cells[win].second.idx;
+    for (int r = 0; r < 3; r++) pts_spherical[3 * (size_t)n + r] = cells[win].second.p[r];
+    n++;
+    a = b;
+  }
+  *n_out = n;
+  return DSM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // makeCoarseDepthL0, TrackerAndScaler.cpp:143-315 (flat-array form)
 // ---------------------------------------------------------------------------------------------
 int dsm_make_coarse_depth_l0(int w0, int h0, int nl, int npts, const float *pu, const float *pv, const float *pidepth,

@@ -126,3 +126,23 @@ def scancontext_generate(pts_spherical, lidar_range, num_s=60, num_r=20):
                                      sig_idx.ctypes.data_as(c_int_p), sig_val.ctypes.data_as(_lib.c_double_p), C.byref(n_sig),
                                      tfm.ctypes.data_as(_lib.c_double_p)))
     return ringkey, sig_idx[: n_sig.value].copy(), sig_val[: n_sig.value].copy(), tfm.reshape(4, 4)
+
+
+def generate_spherical_points(kf_ids, kf_pose_wc, cur_cw, lidar_range, pt_kf_id, pt_xyz):
+    """generate_spherical_points (generate_spherical_points.h:27-85) through the C ABI (host code).
+    Returns (kf_keep[n_kf] bool, sel_idx int32 -- the reference's updated pts_nearby -- and pts_spherical (n,3))."""
+    L = _lib.load()
+    kf_ids = np.ascontiguousarray(kf_ids, np.int32)
+    poses = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 6)
+    cw = np.ascontiguousarray(cur_cw, np.float64).reshape(3, 4)
+    pid = np.ascontiguousarray(pt_kf_id, np.int32)
+    xyz = np.ascontiguousarray(pt_xyz, np.float64).reshape(-1, 3)
+    keep = np.zeros(len(kf_ids), np.int32)
+    sel = np.zeros(max(1, len(pid)), np.int32)
+    out = np.zeros((max(1, len(pid)), 3))
+    n = C.c_int()
+    check(L.dsm_generate_spherical_points(len(kf_ids), kf_ids.ctypes.data_as(c_int_p), poses.ctypes.data_as(_lib.c_double_p),
+                                          cw.ctypes.data_as(_lib.c_double_p), lidar_range, len(pid), pid.ctypes.data_as(c_int_p),
+                                          xyz.ctypes.data_as(_lib.c_double_p), keep.ctypes.data_as(c_int_p), C.byref(n),
+                                          sel.ctypes.data_as(c_int_p), out.ctypes.data_as(_lib.c_double_p)))
+    return keep.astype(bool), sel[: n.value].copy(), out[: n.value].copy()

@@ -264,6 +264,17 @@ int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int n
                              float *ringkey_out, int *sig_idx_out, double *sig_val_out, int *n_sig_out,
                              double *tfm_pca_rig_out);
 
+/* replaces generate_spherical_points (loop_detection/generate_spherical_points.h:27-85; call site LoopHandler.cpp:233) in
+ * flat-array form.  kf_pose_wc: n_kf x 6 Sophus tangents (translation, rotation) as in id_pose_wc; cur_cw: row-major 3x4
+ * matrix of the current keyframe's camera<-world pose; pt_kf_id / pt_xyz: the nearby points with the keyframe that owns each.
+ * Outputs: kf_keep[n_kf] (0: the reference erases that keyframe, :33-41), *n_out selected points, sel_idx (their indices in the
+ * input list: the reference's updated pts_nearby) and pts_spherical (n_out x 3, current camera frame).  Per 1 x 0.5 x 1 m voxel the
+ * highest point (smallest y) is kept (:64-76).  Order of the output: ascending voxel index -- the reference emits its
+ * unordered_map in implementation-defined order.  Host side (tens of thousands of points per keyframe). */
+int dsm_generate_spherical_points(int n_kf, const int *kf_ids, const double *kf_pose_wc, const double *cur_cw,
+                                  double lidar_range, int n_pts, const int *pt_kf_id, const double *pt_xyz, int *kf_keep,
+                                  int *n_out, int *sel_idx, double *pts_spherical);
+
 /* replaces TrackerAndScaler::makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) for callers that hold
  * the active points as flat arrays: (pu,pv) = centerProjectedTo[0..1], pidepth = centerProjectedTo[2],
  * pweight = sqrtf(1e-3/(HdiF+1e-12)) (:155-158).  ref_dIp[lvl]: the keyframe's (I,dx,dy) pyramid.

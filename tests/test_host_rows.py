@@ -105,3 +105,40 @@ def test_ringkey_is_invariant_to_viewpoint_rotation(built):
     rk1 = scancontext_generate(pts @ R.T + np.array([4.0, -2.0, 1.0]), 40.0)[0]
     assert np.abs(rk0 - rk1).max() <= 2 / 60 + 1e-6
     assert ((rk0 - rk1) ** 2).sum() < 0.01  # far below RINGKEY_THRES = 0.1
+
+
+def test_generate_spherical_points_matches_oracle(built):
+    """N3 producer of the ScanContext input (generate_spherical_points.h:27-85): keyframe trimming by orientation, range
+    filter, one (highest) point per 1 x 0.5 x 1 m voxel -- C ABI vs the numpy/scipy oracle, then through ScanContext"""
+    from scipy.spatial.transform import Rotation
+
+    from direct_stereo_slam_amd.ringdb import generate_spherical_points, scancontext_generate
+    from oracle import scancontext as SC
+
+    rng = np.random.default_rng(7)
+    n_kf, n_pts, rng_m = 12, 6000, 40.0
+    kf_ids = np.arange(100, 100 + n_kf)
+    rot = rng.normal(0, 0.08, (n_kf, 3))
+    rot[3] = [0.0, 0.9, 0.0]   # rotated too far against the current keyframe: trimmed
+    rot[7] = [0.6, 0.0, 0.1]
+    poses = np.hstack([rng.normal(0, 5, (n_kf, 3)), rot])
+    Rc = Rotation.from_rotvec([0.02, -0.05, 0.01]).as_matrix()
+    cur_cw = np.hstack([Rc, rng.normal(0, 1, (3, 1))])
+    pt_kf = rng.choice(np.concatenate([kf_ids, [999]]), n_pts)  # 999: a keyframe that is not in the map
+    xyz = np.stack([rng.uniform(-55, 55, n_pts), rng.normal(0, 1.5, n_pts), rng.uniform(-55, 55, n_pts)], 1)
+    xyz[:50] = xyz[0] + rng.normal(0, 0.05, (50, 3))  # a crowded voxel
+    keep_c, sel_c, pts_c = generate_spherical_points(kf_ids, poses, cur_cw, rng_m, pt_kf, xyz)
+    keep_o, sel_o, pts_o = SC.generate_spherical_points(kf_ids, poses, cur_cw, rng_m, pt_kf, xyz)
+    assert not keep_c[3] and not keep_c[7] and keep_c.sum() == n_kf - 2
+    np.testing.assert_array_equal(keep_c, keep_o)
+    np.testing.assert_array_equal(sel_c, sel_o)
+    np.testing.assert_array_equal(pts_c, pts_o)
+    assert 0 < len(sel_c) < n_pts and np.all(np.linalg.norm(pts_c, axis=1) < rng_m)
+    assert np.all(keep_c[np.searchsorted(kf_ids, pt_kf[sel_c])])  # only points of kept, known keyframes survive
+    # feeds ScanContext::generate: the ring key of the selected points
+    rk = scancontext_generate(pts_c, rng_m)[0]
+    rk_o = SC.generate(pts_o, rng_m)[0]
+    np.testing.assert_array_equal(rk, rk_o)
+    # degenerate inputs
+    k0, s0, p0 = generate_spherical_points(kf_ids[:0], poses[:0], cur_cw, rng_m, pt_kf[:0], xyz[:0])
+    assert len(k0) == 0 and len(s0) == 0 and p0.shape == (0, 3)
