@@ -264,7 +264,7 @@ int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int n
                              float *ringkey_out, int *sig_idx_out, double *sig_val_out, int *n_sig_out,
                              double *tfm_pca_rig_out);
 
-/* replaces generate_spherical_points (loop_detection/generate_spherical_points.h:27-85; call site LoopHandler.cpp:233) in
+/* replaces generate_spherical_points (loop_detection/generate_spherical_points.h:27-85; call site LoopHandler.cpp:186-187) in
  * flat-array form.  kf_pose_wc: n_kf x 6 Sophus tangents (translation, rotation) as in id_pose_wc; cur_cw: row-major 3x4
  * matrix of the current keyframe's camera<-world pose; pt_kf_id / pt_xyz: the nearby points with the keyframe that owns each.
  * Outputs: kf_keep[n_kf] (0: the reference erases that keyframe, :33-41), *n_out selected points, sel_idx (their indices in the
