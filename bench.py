@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU oracle with one share of the frames per host core (forked workers)")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -194,6 +195,50 @@ def one_step(ctx, wl, kf_idx, with_upload=False):
     return good, poses, err, sc, st_track, st_scale
 
 
+_ALLCORE = {}
+
+
+def _allcore_worker(job):
+    """one independent sequence per core (leg ii): a forked worker tracks its share of the frames
+    on its own oracle trackers; returns the wall time of the tracking loop only"""
+    from direct_stereo_slam_amd import synth as S
+    from oracle import oracle as O
+
+    wl, kf_every, idx = _ALLCORE["wl"], _ALLCORE["kf_every"], job
+    nl, w, h = wl["nl"], wl["w"], wl["h"]
+    trks = []
+    for i in idx:
+        tpl, new, right = wl["host"][i]
+        orc = O.OracleTracker(w, h, nl, wl["T"], wl["K"], native=True)
+        orc.make_k(*wl["K"])
+        orc.set_ref(0, 0.0, 0.0, 1.0, *tpl)
+        orc.set_frame(0, O.make_images(new, nl, native=True), 1.0)
+        orc.set_frame(1, O.make_images(right, nl, native=True), 1.0)
+        trks.append((i, orc))
+    t0 = time.perf_counter()
+    for i, orc in trks:
+        orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        if i % kf_every == 0:
+            orc.optimize_scale(1.0, nl - 1)
+    return time.perf_counter() - t0
+
+
+def cpu_all_cores(args, wl):
+    """the same frames, one share per host core in forked processes (the workers never touch the GPU)"""
+    import multiprocessing as mp
+
+    n = len(wl["host"])
+    cores = min(os.cpu_count() or 1, n)
+    if cores < 2:
+        return None
+    _ALLCORE.update(wl={k: wl[k] for k in ("nl", "w", "h", "T", "K", "host")}, kf_every=args.kf_every)
+    jobs = [list(range(c, n, cores)) for c in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        times = pool.map(_allcore_worker, jobs)
+    return {"value": n / max(times), "unit": "stereo frames/s", "cores": cores,
+            "sample": f"the same {n} frames split over {cores} forked processes, slowest share {max(times):.2f} s"}
+
+
 def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
     """the oracle (kind 'port') timed on this box's host cores: 1 thread, as the reference runs this
     path on the image-callback thread.  Built with -O3 -march=native like CMakeLists.txt:4-6."""
@@ -242,6 +287,11 @@ def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
                                  "max_abs_translation_diff_converged_m": float(np.abs(gp[conv] - cp[conv]).max()) if conv.any() else None,
                                  "max_abs_translation_diff_gpu_vs_cpu_m": float(np.abs(gp - cp).max()),
                                  "good_flags_equal": bool(np.array_equal(np.asarray(gpu_good)[:n].astype(bool), np.array(cpu_good)))}
+    if args.cpu_all_cores:
+        try:
+            out["all_cores"] = cpu_all_cores(args, wl)
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            out["all_cores"] = {"error": repr(e)}
     return out
 
 
