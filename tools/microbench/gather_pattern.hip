@@ -1,0 +1,156 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef float fvec3u __attribute__((ext_vector_type(3), aligned(4)));
+// one block = one "chunk": 4096 template entries (16 B each, coalesced) + the matching image rows (12-byte texels)
+// mode 0: pts only; 1: pts + 2 taps (x, and next row); 2: pts + 4 taps; 3: 4 taps with one-ahead software pipelining like the eval kernel
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  float acc = 0.f;
+  const int base_px = chunk * 4096 + 2 * w + 2; // the chunk's points land on consecutive pixels (dense template, tiny motion)
+#pragma unroll 2
+  for (int kk = 0; kk < 16; kk++) {
+    const int i = kk * 256 + tid;
+    const fvec4 a = __builtin_nontemporal_load(p + i);
+    acc += a.x + a.w;
+    if (MODE >= 1) {
+      const unsigned off0 = 12u * (unsigned)(base_px + i), off1 = off0 + 12u * (unsigned)w;
+      const fvec3u t0 = *(const fvec3u *)(ib + off0), t2 = *(const fvec3u *)(ib + off1);
+      acc += t0.x + t2.z;
+      if (MODE >= 2) {
+        const fvec3u t1 = *(const fvec3u *)(ib + off0 + 12u), t3 = *(const fvec3u *)(ib + off1 + 12u);
+        acc += t1.y + t3.x;
+      }
+    }
+  }
+  if (acc == 123456.789f) out[0] = acc;
+}
+
+// mode 3: the proposed pipeline.  Tap addresses DEPEND on the template entry (as the warp does); taps are fetched two
+// points ahead straight into a per-wave LDS ring (global_load_lds_dwordx3, no VGPRs in flight), the template entry four ahead.
+#define VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+typedef const __attribute__((address_space(1))) void *gptr;
+typedef __attribute__((address_space(3))) void *lptr;
+template <int WORK, int PAD>
+__global__ __launch_bounds__(256) void k3(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+  __shared__ __attribute__((aligned(16))) float ring[4][2][4][64 * 3]; // [wave][slot][tap][lane*3]
+  __shared__ float pad[PAD > 0 ? PAD : 1];
+  if (PAD > 0 && threadIdx.x == 300) pad[0] = 1.f;
+  float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  float acc = 0.f;
+  auto issue = [&](const fvec4 &pt, int slot) {
+    const unsigned off0 = 12u * (unsigned)(int)pt.x, off1 = off0 + 12u * (unsigned)w;
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off0), (lptr)&ring[wave][slot][0][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off0 + 12u), (lptr)&ring[wave][slot][1][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off1), (lptr)&ring[wave][slot][2][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off1 + 12u), (lptr)&ring[wave][slot][3][0], 12, 0, 0);
+  };
+  // prologue
+  fvec4 q0 = __builtin_nontemporal_load(p + tid), q1 = __builtin_nontemporal_load(p + 256 + tid);
+  fvec4 q2 = __builtin_nontemporal_load(p + 512 + tid), q3 = __builtin_nontemporal_load(p + 768 + tid);
+  __builtin_amdgcn_s_waitcnt(0);
+  issue(q0, 0);
+  issue(q1, 1);
+  // steady state at iteration k: VMEM issue order of the previous two iterations was  [pts(k+2)] [taps(k) x4] | [pts(k+3)] [taps(k+1) x4]
+#pragma unroll 2
+  for (int kk = 0; kk < 16; kk++) {
+    const int slot = kk & 1;
+    const int i4 = (kk + 4) * 256 + tid;
+    const fvec4 q4 = __builtin_nontemporal_load(p + (i4 < 4096 ? i4 : tid)); // template entry four ahead
+    VMCNT(6); // taps(k) and pts(k+2) have landed; pts(k+3), taps(k+1) x4 and pts(k+4) stay in flight
+    asm volatile("" ::: "memory");
+    const float a0 = ring[wave][slot][0][lane * 3], a1 = ring[wave][slot][1][lane * 3 + 1], a2 = ring[wave][slot][2][lane * 3 + 2], a3 = ring[wave][slot][3][lane * 3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (kk + 2 < 16) issue(q2, slot); // taps(k+2) into the slot just read
+    acc += (a0 + a1) + (a2 + a3) + q0.w;
+#pragma unroll
+    for (int j = 0; j < WORK; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) c[e] = __builtin_fmaf(c[e], a0, a1 + (float)e);
+    q0 = q1, q1 = q2, q2 = q3, q3 = q4;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
+}
+
+template <int WORK, int PAD>
+__global__ __launch_bounds__(256) void k4(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+  __shared__ __attribute__((aligned(16))) float ring[4][2][4][64 * 3];
+  __shared__ float pad[PAD > 0 ? PAD : 1];
+  if (PAD > 0 && threadIdx.x == 300) pad[0] = 1.f;
+  float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  float acc = 0.f;
+  auto issue = [&](const fvec4 &pt, int slot) {
+    const unsigned off0 = 12u * (unsigned)(int)pt.x, off1 = off0 + 12u * (unsigned)w;
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off0), (lptr)&ring[wave][slot][0][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off0 + 12u), (lptr)&ring[wave][slot][1][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off1), (lptr)&ring[wave][slot][2][0], 12, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(ib + off1 + 12u), (lptr)&ring[wave][slot][3][0], 12, 0, 0);
+  };
+  fvec4 q0 = __builtin_nontemporal_load(p + tid), q1 = __builtin_nontemporal_load(p + 256 + tid);
+  fvec4 pn = __builtin_nontemporal_load(p + 512 + tid); // pts(k+2)
+  __builtin_amdgcn_s_waitcnt(0);
+  issue(q0, 0);
+  issue(q1, 1);
+  float w0 = q0.w, w1 = q1.w;
+  for (int kk = 0; kk < 16; kk++) {
+    const int slot = kk & 1;
+    const fvec4 pc = pn; // pts(k+2), loaded one iteration ago
+    const int i3 = (kk + 3) * 256 + tid;
+    pn = __builtin_nontemporal_load(p + (i3 < 4096 ? i3 : tid)); // pts(k+3): first vector-memory op of the iteration
+    asm volatile("" ::: "memory");
+    VMCNT(5); // younger than taps(k): taps(k+1) x4 and the load just issued
+    asm volatile("" ::: "memory");
+    const float a0 = ring[wave][slot][0][lane * 3], a1 = ring[wave][slot][1][lane * 3 + 1], a2 = ring[wave][slot][2][lane * 3 + 2], a3 = ring[wave][slot][3][lane * 3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue(pc, slot); // taps(k+2)
+    acc += (a0 + a1) + (a2 + a3) + w0;
+#pragma unroll
+    for (int j = 0; j < WORK; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) c[e] = __builtin_fmaf(c[e], a0, a1 + (float)e);
+    w0 = w1; w1 = pc.w;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
+}
+int main() {
+  const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = 96;
+  const int chunks = (npts - 4096) / 4096; // whole chunks only, rows stay inside the image
+  fvec4 *pts; float *img, *out;
+  hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
+  { std::vector<float> hp((size_t)npts * 4, 0.f); for (int i = 0; i < npts; i++) hp[4 * (size_t)i] = (float)(((i / 4096) * 4096) + 2 * w + 2 + (i % 4096)); for (int f = 0; f < frames; f++) hipMemcpy((char *)pts + (size_t)f * npts * 16, hp.data(), (size_t)npts * 16, hipMemcpyHostToDevice); } hipMemset(img, 0, (size_t)frames * npx * 12 + 65536);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int mode = 0; mode < 10; mode++) {
+    for (int rep = 0; rep < 2; rep++) {
+      hipEventRecord(a);
+      for (int it = 0; it < 5; it++) {
+        if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 3) hipLaunchKernelGGL((k3<0, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 4) hipLaunchKernelGGL((k3<0, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 5) hipLaunchKernelGGL((k3<25, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 7) hipLaunchKernelGGL((k4<0, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 8) hipLaunchKernelGGL((k4<25, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 9) hipLaunchKernelGGL((k4<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 6) hipLaunchKernelGGL((k3<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+      }
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b);
+      const double bytes = 5.0 * frames * chunks * 4096.0 * (16.0 + (mode ? 12.0 : 0.0)); // algorithmic: 16 B template + 12 B image per point
+      if (rep) printf("mode %d: %.3f ms per launch, %.0f GB/s algorithmic (16 + %d B per point)\n", mode, ms / 5, bytes / (ms * 1e-3) / 1e9, mode ? 12 : 0);
+    }
+  }
+  return 0;
+}
