@@ -510,3 +510,18 @@ def test_work_queue_kernel_batched_with_empty_level(ctx):
             np.testing.assert_array_equal(a, b)
         for a, b in zip(e, out[0][1]):
             np.testing.assert_array_equal(a, b)
+
+
+def test_upload_image_from_pinned_memory(ctx):
+    """dsm_host_alloc: a pinned caller buffer is handed over by DMA; same pyramid as from pageable memory, and the buffer may be
+    overwritten as soon as upload_image has returned (the call waits for the copy, not for the pyramid kernels)"""
+    from direct_stereo_slam_amd.tracker import pinned_array
+
+    sc = make_scene("small", seed=16)
+    trk = hip_tracker(ctx, sc)
+    buf = pinned_array(sc.new_img.shape)
+    buf[...] = sc.new_img
+    trk.upload_image(0, buf, 1.0)
+    buf[...] = -1.0  # must not affect the pyramid being built
+    for lvl in range(sc.nl):
+        np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
