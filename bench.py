@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
+    ap.add_argument("--u8", action="store_true", help="with --with-upload: camera bytes (mono8) are handed over instead of float images; the synthetic images are rounded to 0..255 for the whole run")
+    ap.add_argument("--single-uploads", action="store_true", help="with --with-upload: one dsm_tracker_upload_image call per image instead of one dsm_upload_images call per step")
     ap.add_argument("--pinned", action="store_true", help="with --with-upload: the host images live in pinned memory (dsm_host_alloc)")
     ap.add_argument("--queue", type=int, default=0,
                     help="dsm_params.work_queue: 0 (default here) launch-per-step form -- its dominant kernel, the level-0 evaluation, is "
@@ -146,6 +148,8 @@ def build_workload(args, ctx, rank):
         R, t = S.random_motion(rng)
         new = scene.render(K, w, h, R, t, a=0.02, b=3.0, noise=2.0, rng=rng)
         right = scene.render(K, w, h, T[:3, :3], T[:3, 3], noise=2.0, rng=rng)
+        if args.u8:
+            ref, new, right = (np.clip(np.rint(im), 0, 255).astype(np.float32) for im in (ref, new, right))
         scenes.append((scene, ref, new, right, S.pose_from_Rt(R, t)))
     trackers, gts, host, images = [], [], [], []
     for b in range(args.batch):
@@ -163,17 +167,19 @@ def build_workload(args, ctx, rank):
         trk.upload_image(1, right, 1.0)
         trackers.append(trk)
         gts.append(gt)
+        pix = np.uint8 if args.u8 else np.float32
         if args.with_upload and args.pinned:
             from direct_stereo_slam_amd.tracker import pinned_array
 
-            pl, pr = pinned_array(new.shape), pinned_array(right.shape)
+            pl, pr = pinned_array(new.shape, pix), pinned_array(right.shape, pix)
             pl[...], pr[...] = new, right
             images.append((pl, pr))
         else:
-            images.append((np.ascontiguousarray(new, np.float32), np.ascontiguousarray(right, np.float32)))
+            images.append((np.ascontiguousarray(new, pix), np.ascontiguousarray(right, pix)))
         if b < args.cpu_frames:
             host.append((tpl, new, right))
-    return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params, images=images)
+    return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params, images=images,
+                single_uploads=args.single_uploads)
 
 
 def one_step(ctx, wl, kf_idx, with_upload=False):
@@ -182,10 +188,14 @@ def one_step(ctx, wl, kf_idx, with_upload=False):
     B = len(wl["trackers"])
     if with_upload:  # host float images in, pyramids built on the device (dsm_tracker_upload_image, row N1)
         kfs = set(kf_idx)
-        for i, trk in enumerate(wl["trackers"]):
-            trk.upload_image(0, wl["images"][i][0], 1.0)
-            if i in kfs:
-                trk.upload_image(1, wl["images"][i][1], 1.0)
+        if wl["single_uploads"]:
+            for i, trk in enumerate(wl["trackers"]):
+                trk.upload_image(0, wl["images"][i][0], 1.0)
+                if i in kfs:
+                    trk.upload_image(1, wl["images"][i][1], 1.0)
+        else:  # one call: the B new left images and the keyframes' right images
+            trks = list(wl["trackers"]) + [wl["trackers"][i] for i in kf_idx]
+            ctx.upload_images(trks, [0] * B + [1] * len(kf_idx), [wl["images"][i][0] for i in range(B)] + [wl["images"][i][1] for i in kf_idx])
     poses0 = np.tile(S.IDENTITY_POSE, (B, 1))
     good, poses, affs, last, flow = ctx.track_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1)
     st_track = ctx.stats()

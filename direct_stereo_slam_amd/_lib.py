@@ -83,6 +83,7 @@ SYMBOLS = {
     "dsm_tracker_get_template": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "dsm_tracker_upload_frame": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
     "dsm_tracker_upload_image": (C.c_int, [_vp, C.c_int, c_float_p, C.c_float]),
+    "dsm_upload_images": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
     "dsm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "dsm_host_free": (C.c_int, [_vp]),
     "dsm_tracker_get_frame": (C.c_int, [_vp, C.c_int, C.c_int, c_float_p]),

@@ -86,6 +86,51 @@ int sync_desc(dsm_tracker *t) {
   return DSM_OK;
 }
 
+// the same for a batch: all changed descriptors through one pinned staging buffer, one copy and one scatter launch
+int sync_descs(dsm_context *ctx, dsm_tracker *const *ts, int n) {
+  int dirty = 0;
+  for (int i = 0; i < n; i++) dirty += ts[i]->desc_dirty ? 1 : 0;
+  if (dirty <= 2) {
+    for (int i = 0; i < n; i++) {
+      int rc = sync_desc(ts[i]);
+      if (rc) return rc;
+    }
+    return DSM_OK;
+  }
+  const size_t per = sizeof(TrackerDev) + sizeof(TrackerDev *);
+  if (dirty > ctx->desc_stage_cap) {
+    if (ctx->desc_stage_busy) DSM_HIP(hipEventSynchronize(ctx->desc_event));
+    ctx->desc_stage_busy = false;
+    int rc = realloc_dev(&ctx->d_desc_stage, per * dirty);
+    if (rc) return rc;
+    rc = realloc_pinned(&ctx->h_desc_stage, per * dirty);
+    if (rc) return rc;
+    ctx->desc_stage_cap = dirty;
+  }
+  if (!ctx->desc_event) DSM_HIP(hipEventCreateWithFlags(&ctx->desc_event, hipEventDisableTiming));
+  if (ctx->desc_stage_busy) DSM_HIP(hipEventSynchronize(ctx->desc_event)); // the previous copy still reads the buffer
+  TrackerDev *hd = (TrackerDev *)ctx->h_desc_stage;
+  TrackerDev **hp = (TrackerDev **)(ctx->h_desc_stage + sizeof(TrackerDev) * dirty);
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    if (!ts[i]->desc_dirty) continue;
+    bool seen = false; // the same tracker twice in a batch (hypotheses)
+    for (int j = 0; j < k && !seen; j++) seen = hp[j] == ts[i]->d_desc;
+    if (seen) continue;
+    hd[k] = ts[i]->desc;
+    hp[k] = ts[i]->d_desc;
+    k++;
+  }
+  DSM_HIP(hipMemcpyAsync(ctx->d_desc_stage, ctx->h_desc_stage, per * dirty, hipMemcpyHostToDevice, ctx->stream));
+  launch_desc_scatter(ctx->stream, k, (const TrackerDev *)ctx->d_desc_stage,
+                      (TrackerDev *const *)(ctx->d_desc_stage + sizeof(TrackerDev) * dirty));
+  DSM_HIP(hipGetLastError());
+  DSM_HIP(hipEventRecord(ctx->desc_event, ctx->stream));
+  ctx->desc_stage_busy = true;
+  for (int i = 0; i < n; i++) ts[i]->desc_dirty = false;
+  return DSM_OK;
+}
+
 // ---- small host math (float, contraction off): makeK, TrackerAndScaler.cpp:117-141 ----
 static float cof3(const float *m, int i, int j) {
   const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
@@ -228,6 +273,13 @@ int dsm_context_destroy(dsm_context *ctx) {
   for (hipStream_t st : ctx->extra_streams) hipStreamDestroy(st);
   hipEventDestroy(ctx->fork_event);
   hipEventDestroy(ctx->copy_event);
+  for (hipEvent_t ev : ctx->upload_events) hipEventDestroy(ev);
+  if (ctx->desc_event) hipEventDestroy(ctx->desc_event);
+  hipFree(ctx->d_desc_stage);
+  hipHostFree(ctx->h_desc_stage);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  hipFree(ctx->d_pyr_jobs);
+  hipHostFree(ctx->h_pyr_jobs);
   hipEventDestroy(ctx->ev_total[0]);
   hipEventDestroy(ctx->ev_total[1]);
   hipStreamDestroy(ctx->stream);
@@ -523,6 +575,111 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   return DSM_OK;
 }
 
+int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                      const float *ab_exposures, int pixel_type, size_t row_pitch_bytes) {
+  if (!ctx || n < 0 || (n > 0 && (!trackers || !slots || !images)))
+    return invalid("dsm_upload_images: bad argument");
+  if (pixel_type != DSM_PIXEL_F32 && pixel_type != DSM_PIXEL_U8) return invalid("dsm_upload_images: bad pixel type");
+  if (n == 0) return DSM_OK;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const size_t px = pixel_type == DSM_PIXEL_U8 ? 1 : 4;
+  const dsm_tracker *t0 = trackers[0];
+  for (int i = 0; i < n; i++) {
+    const dsm_tracker *t = trackers[i];
+    if (!t || !images[i] || slots[i] < 0 || slots[i] > 1) return invalid("dsm_upload_images: bad entry");
+    if (t->ctx != ctx) return invalid("dsm_upload_images: tracker of another context");
+    if (t->w != t0->w || t->h != t0->h || t->nlevels != t0->nlevels || t->desc.layout != t0->desc.layout)
+      return invalid("dsm_upload_images: trackers of different geometry in one call");
+    for (int j = 0; j < i; j++)
+      if (trackers[j] == t && slots[j] == slots[i]) return invalid("dsm_upload_images: the same slot twice");
+  }
+  const size_t row = (size_t)t0->w * px;
+  if (row_pitch_bytes != 0 && row_pitch_bytes < row) return invalid("dsm_upload_images: row pitch smaller than a row");
+  if (!ctx->copy_stream) DSM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (n > ctx->pyr_jobs_cap) {
+    int rc = realloc_dev(&ctx->d_pyr_jobs, (size_t)n);
+    if (rc) return rc;
+    rc = realloc_pinned(&ctx->h_pyr_jobs, (size_t)n);
+    if (rc) return rc;
+    ctx->pyr_jobs_cap = n;
+  }
+  const size_t npx0 = (size_t)t0->w * t0->h;
+  const size_t pitch = row_pitch_bytes ? row_pitch_bytes : row;
+  // pinned caller buffers (dsm_host_alloc, hipHostMalloc, hipHostRegister) are read by the GPU directly
+  bool all_pinned = true;
+  uintptr_t align = (uintptr_t)row | (uintptr_t)pitch;
+  for (int i = 0; i < n; i++) {
+    dsm_tracker *t = trackers[i];
+    if (!t->d_raw[slots[i]]) DSM_HIP(hipMalloc(&t->d_raw[slots[i]], npx0 * sizeof(float)));
+    ctx->h_pyr_jobs[i].raw = t->d_raw[slots[i]];
+    ctx->h_pyr_jobs[i].src = nullptr;
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) ctx->h_pyr_jobs[i].img[l] = l < t->nlevels ? t->d_img[slots[i]][l] : nullptr;
+    if (all_pinned) {
+      hipPointerAttribute_t attr{};
+      if (hipPointerGetAttributes(&attr, images[i]) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+        ctx->h_pyr_jobs[i].src = attr.devicePointer;
+        align |= (uintptr_t)attr.devicePointer;
+      } else {
+        (void)hipGetLastError(); // pageable memory: not an error
+        all_pinned = false;
+      }
+    }
+  }
+  if (all_pinned) {
+    const int unit = (align & 15) == 0 ? 16 : (align & 3) == 0 ? 4 : 1;
+    DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, ctx->stream));
+    launch_host_rows_copy(ctx->stream, ctx->d_pyr_jobs, n, (int)row, t0->h, pitch, unit);
+    DSM_HIP(hipGetLastError());
+    DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
+    launch_pyramid_batched(ctx->stream, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, t0->desc.layout, pixel_type == DSM_PIXEL_U8);
+    DSM_HIP(hipGetLastError());
+    DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
+    for (int i = 0; i < n; i++) {
+      dsm_tracker *t = trackers[i];
+      t->desc.exposure[slots[i]] = ab_exposures ? ab_exposures[i] : 1.0f;
+      t->have_frame[slots[i]] = true;
+      t->desc_dirty = true;
+    }
+    return DSM_OK;
+  }
+  // the staging buffers may still be read by the pyramid kernels of the previous hand-over
+  DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
+  DSM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0));
+  DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, ctx->copy_stream));
+  // groups: the pyramids of one group are built under the copies of the next
+  const int group = 16;
+  const int ngroups = (n + group - 1) / group;
+  while ((int)ctx->upload_events.size() < ngroups) {
+    hipEvent_t ev;
+    DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->upload_events.push_back(ev);
+  }
+  for (int g = 0; g < ngroups; g++) {
+    const int i0 = g * group, i1 = i0 + group < n ? i0 + group : n;
+    for (int i = i0; i < i1; i++) {
+      void *dst = trackers[i]->d_raw[slots[i]];
+      if (pitch == row)
+        DSM_HIP(hipMemcpyAsync(dst, images[i], npx0 * px, hipMemcpyHostToDevice, ctx->copy_stream));
+      else
+        DSM_HIP(hipMemcpy2DAsync(dst, row, images[i], pitch, row, (size_t)t0->h, hipMemcpyHostToDevice, ctx->copy_stream));
+    }
+    DSM_HIP(hipEventRecord(ctx->upload_events[g], ctx->copy_stream));
+    DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_events[g], 0));
+    launch_pyramid_batched(ctx->stream, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs + i0, i1 - i0, t0->desc.layout,
+                           pixel_type == DSM_PIXEL_U8);
+    DSM_HIP(hipGetLastError());
+  }
+  // the caller's buffers are free once the copies are through; the pyramid kernels run on behind
+  DSM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  for (int i = 0; i < n; i++) {
+    dsm_tracker *t = trackers[i];
+    t->desc.exposure[slots[i]] = ab_exposures ? ab_exposures[i] : 1.0f;
+    t->have_frame[slots[i]] = true;
+    t->desc_dirty = true;
+  }
+  return DSM_OK;
+}
+
 int dsm_host_alloc(size_t bytes, void **out) {
   if (!out || bytes == 0) return invalid("dsm_host_alloc: bad argument");
   *out = nullptr;
@@ -589,11 +746,9 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
   }
   int rc = ensure_batch_capacity(ctx, n, ps);
   if (rc) return rc;
-  for (int i = 0; i < n; i++) {
-    rc = sync_desc(ts[i]);
-    if (rc) return rc;
-    ctx->h_tracker_ptrs[i] = ts[i]->d_desc;
-  }
+  rc = sync_descs(ctx, ts, n);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) ctx->h_tracker_ptrs[i] = ts[i]->d_desc;
   DSM_HIP(hipMemcpyAsync(ctx->d_tracker_ptrs, ctx->h_tracker_ptrs, sizeof(TrackerDev *) * n, hipMemcpyHostToDevice, ctx->stream));
   return DSM_OK;
 }

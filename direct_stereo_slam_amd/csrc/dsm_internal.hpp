@@ -29,6 +29,16 @@ struct dsm_context {
   std::vector<hipEvent_t> join_events;
   hipEvent_t fork_event = nullptr;
   hipEvent_t copy_event = nullptr; // end of a host->device hand-over (dsm_tracker_upload_image)
+  // descriptor updates of a batch in one copy (sync_descs): [n descriptors][n destination pointers], pinned + device
+  unsigned char *h_desc_stage = nullptr, *d_desc_stage = nullptr;
+  int desc_stage_cap = 0;
+  hipEvent_t desc_event = nullptr;
+  bool desc_stage_busy = false;
+  // batched hand-over (dsm_upload_images): copies on a stream of their own, one event per group of images
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> upload_events;
+  dsm::PyrJob *d_pyr_jobs = nullptr, *h_pyr_jobs = nullptr; // h: pinned
+  int pyr_jobs_cap = 0;
   // batch workspaces (grown on demand)
   int cap_prob = 0;
   int partial_stride = 0; // floats per problem
@@ -79,4 +89,5 @@ namespace dsm {
 int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride);
 int ensure_stage(dsm_context *ctx, size_t floats);
 int sync_desc(dsm_tracker *t);
+int sync_descs(dsm_context *ctx, dsm_tracker *const *ts, int n);
 } // namespace dsm

@@ -83,6 +83,16 @@ void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out);
 void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out);
 // makeImages (upstream DSO): level 0 from the float image, level l from level l-1; layout aware
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout);
+// one image of a batched hand-over (dsm_upload_images): staged level-0 pixels (float or u8) and the pyramid levels
+struct PyrJob {
+  const void *raw;
+  float *img[DSM_MAX_LEVELS];
+  const void *src; // device-visible address of the caller's pinned image (kernel copy path), else null
+};
+void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerDev *const *d_dst);
+// raw <- src for every job, rows of row_bytes at pitch `pitch` in src (tight in raw); unit: 16, 4 or 1 bytes per access
+void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit);
+void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, int layout, bool u8);
 
 // ring-key kernels
 void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim,

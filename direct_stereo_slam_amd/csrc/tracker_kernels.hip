@@ -1673,20 +1673,21 @@ void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out) {
 // DSO FrameHessian::makeImages) and the intensities of level l+1 (2x2 mean, 0.25 * (a + b + c + d)) both read
 // only the intensities of level l.  src: those intensities with element stride `ss` (1: the raw level-0 image,
 // TS: the I channel of out_l itself for l >= 1).
-__global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, int ss, float *__restrict__ out_l,
-                                       float *__restrict__ out_next, int TS) {
+template <typename SRC>
+__device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__restrict__ src, int ss, float *__restrict__ out_l,
+                                               float *__restrict__ out_next, int TS, int first, int step) {
   const int npx = wl * hl, wn = wl >> 1, hn = hl >> 1;
   const int lo = wl, hi = wl * (hl - 1);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npx; idx += gridDim.x * blockDim.x) {
+  for (int idx = first; idx < npx; idx += step) {
     float dx = 0.f, dy = 0.f;
     if (idx >= lo && idx < hi) {
-      dx = 0.5f * (src[ss * (idx + 1)] - src[ss * (idx - 1)]);
-      dy = 0.5f * (src[ss * (idx + wl)] - src[ss * (idx - wl)]);
+      dx = 0.5f * ((float)src[ss * (idx + 1)] - (float)src[ss * (idx - 1)]);
+      dy = 0.5f * ((float)src[ss * (idx + wl)] - (float)src[ss * (idx - wl)]);
       if (!__builtin_isfinite(dx)) dx = 0;
       if (!__builtin_isfinite(dy)) dy = 0;
     }
     if (ss == 1) {
-      out_l[TS * idx] = src[idx];
+      out_l[TS * idx] = (float)src[idx];
       if (TS == 4) out_l[TS * idx + 3] = 0.f;
     }
     out_l[TS * idx + 1] = dx;
@@ -1694,10 +1695,66 @@ __global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__
     if (out_next && idx < wn * hn) {
       const int x = idx % wn, y = idx / wn;
       const int b = 2 * x + 2 * y * wl;
-      out_next[TS * idx] = 0.25f * (src[ss * b] + src[ss * (b + 1)] + src[ss * (b + wl)] + src[ss * (b + 1 + wl)]);
+      out_next[TS * idx] =
+          0.25f * ((float)src[ss * b] + (float)src[ss * (b + 1)] + (float)src[ss * (b + wl)] + (float)src[ss * (b + 1 + wl)]);
       if (TS == 4) out_next[TS * idx + 3] = 0.f;
     }
   }
+}
+__global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, int ss, float *__restrict__ out_l,
+                                       float *__restrict__ out_next, int TS) {
+  pyr_level_body<float>(wl, hl, src, ss, out_l, out_next, TS, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+// the same for a batch of images (dsm_upload_images): blockIdx.y = image; U8: the level-0 source holds camera bytes
+// (main.cpp:216-217 "mono8"), converted exactly
+template <bool U8>
+__global__ void pyr_level_batched_kernel(int l, int nlevels, int wl, int hl, const PyrJob *__restrict__ jobs, int TS) {
+  const PyrJob &j = jobs[blockIdx.y];
+  float *out_l = j.img[l];
+  float *out_next = l + 1 < nlevels ? j.img[l + 1] : nullptr;
+  const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+  if (l == 0) {
+    if (U8)
+      pyr_level_body<unsigned char>(wl, hl, (const unsigned char *)j.raw, 1, out_l, out_next, TS, first, step);
+    else
+      pyr_level_body<float>(wl, hl, (const float *)j.raw, 1, out_l, out_next, TS, first, step);
+  } else {
+    pyr_level_body<float>(wl, hl, out_l, TS, out_l, out_next, TS, first, step);
+  }
+}
+// descriptors of many trackers in one copy + one launch (after a batched hand-over every tracker's exposure changed)
+__global__ void desc_scatter_kernel(const TrackerDev *__restrict__ src, TrackerDev *const *__restrict__ dst) {
+  static_assert(sizeof(TrackerDev) % 16 == 0, "TrackerDev is copied in 16-byte units");
+  const uint4 *s = (const uint4 *)(src + blockIdx.x);
+  uint4 *d = (uint4 *)dst[blockIdx.x];
+  for (int i = threadIdx.x; i < (int)(sizeof(TrackerDev) / 16); i += blockDim.x) d[i] = s[i];
+}
+void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerDev *const *d_dst) {
+  if (n > 0) hipLaunchKernelGGL(desc_scatter_kernel, dim3(n), dim3(64), 0, s, d_src, d_dst);
+}
+// Pinned caller images are fetched by the GPU itself (one launch for the whole batch instead of one copy command per
+// image): every thread moves UNIT bytes per access straight from host memory.
+typedef unsigned copy_uvec4 __attribute__((ext_vector_type(4)));
+template <typename UNIT>
+__global__ void host_rows_copy_kernel(const PyrJob *__restrict__ jobs, int row_units, int rows, size_t pitch_units) {
+  const PyrJob &j = jobs[blockIdx.y];
+  const UNIT *__restrict__ src = (const UNIT *)j.src;
+  UNIT *__restrict__ dst = (UNIT *)j.raw;
+  const int total = row_units * rows;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int r = idx / row_units, c = idx - r * row_units;
+    dst[idx] = __builtin_nontemporal_load(src + (size_t)r * pitch_units + c);
+  }
+}
+void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit) {
+  const int row_units = row_bytes / unit;
+  const dim3 grid(grid_for(row_units * rows), njobs);
+  if (unit == 16)
+    hipLaunchKernelGGL(host_rows_copy_kernel<copy_uvec4>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch / 16);
+  else if (unit == 4)
+    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch / 4);
+  else
+    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned char>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch);
 }
 // raw: the level-0 float image; img[l]: the AoS pyramid levels
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout) {
@@ -1706,6 +1763,17 @@ void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, 
     const int wl = w >> l, hl = h >> l;
     hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, l == 0 ? raw : img[l], l == 0 ? 1 : TS, img[l],
                        l + 1 < nlevels ? img[l + 1] : nullptr, TS);
+  }
+}
+void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, int layout, bool u8) {
+  const int TS = layout == IMG_AOS3 ? 3 : 4;
+  for (int l = 0; l < nlevels; l++) {
+    const int wl = w >> l, hl = h >> l;
+    const dim3 grid(grid_for(wl * hl), njobs);
+    if (u8)
+      hipLaunchKernelGGL(pyr_level_batched_kernel<true>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs, TS);
+    else
+      hipLaunchKernelGGL(pyr_level_batched_kernel<false>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs, TS);
   }
 }
 

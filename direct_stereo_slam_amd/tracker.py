@@ -127,6 +127,33 @@ class Context:
                                      _dp(last), _dp(flow), good.ctypes.data_as(c_int_p)))
         return good.astype(bool), poses, affs, last, flow
 
+    def upload_images(self, trackers, slots, images, exposures=None):
+        """dsm_upload_images: hand over one level-0 image (float32 or uint8, all of one type) per (tracker, slot) in one
+        call.  Images may be row-strided views (e.g. the calibration crop of a larger camera image), all with one pitch."""
+        n = len(trackers)
+        if n == 0:
+            return
+        dt = np.dtype(images[0].dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.uint8)):
+            raise TypeError("upload_images: float32 or uint8 images")
+        keep, pitch = [], None
+        for im, t in zip(images, trackers):
+            if im.dtype != dt or im.shape != (t.hgt, t.w):
+                raise ValueError("upload_images: image type / shape mismatch")
+            if im.strides[1] != dt.itemsize or im.strides[0] < t.w * dt.itemsize:
+                im = np.ascontiguousarray(im)
+            if pitch is None:
+                pitch = im.strides[0]
+            elif im.strides[0] != pitch:
+                raise ValueError("upload_images: images of one call share one row pitch")
+            keep.append(im)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        ps = (C.c_void_p * n)(*[im.ctypes.data for im in keep])
+        sl = np.ascontiguousarray(slots, np.int32)
+        ex = np.ones(n, np.float32) if exposures is None else np.ascontiguousarray(exposures, np.float32)
+        check(self.L.dsm_upload_images(self.h, n, hs, sl.ctypes.data_as(c_int_p), ps, _fp(ex),
+                                       1 if dt == np.dtype(np.uint8) else 0, pitch))
+
     def optimize_scale_batch(self, trackers, scales, coarsest):
         n = len(trackers)
         hs = (C.c_void_p * n)(*[t.h for t in trackers])

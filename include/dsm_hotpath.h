@@ -163,6 +163,17 @@ int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, 
 /* "next" row N1: build the (I,dx,dy) pyramid on the device from the level-0 float image
  * (upstream DSO FrameHessian::makeImages, call sites FrontEnd.cpp:605,680). */
 int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure);
+/* the same hand-over for many frames in ONE call (the frames of a batched track / scale call): host->device copies
+ * back to back on a copy stream, pyramids of a group of images built under the copies of the next group, five batched
+ * launches per group instead of five per image.  images[i]: level-0 pixels of trackers[i]'s geometry (all trackers of one
+ * call share w, h, levels), DSM_PIXEL_F32 (the undistorted float image FrontEnd.cpp:605,680 consume) or DSM_PIXEL_U8
+ * (camera bytes, main.cpp:216-217 "mono8"; converted exactly on the device -- valid when no photometric calibration is
+ * applied, i.e. float(pixel) is what the reference's undistorter hands on).  row_pitch_bytes: distance between image
+ * rows in the caller's buffers, 0 = tight; with a pointer to the crop origin this applies the calibration file's crop
+ * (cams/kitti/0_2/camera0.txt:2-4).  Returns when every copy has completed. */
+enum { DSM_PIXEL_F32 = 0, DSM_PIXEL_U8 = 1 };
+int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                      const float *ab_exposures, int pixel_type, size_t row_pitch_bytes);
 /* pinned host memory for images handed to dsm_tracker_upload_image (straight DMA instead of a staged copy); no reference
  * counterpart -- the reference keeps its images in ordinary host memory */
 int dsm_host_alloc(size_t bytes, void **out);
