@@ -340,7 +340,7 @@ def bench_tracking(args):
     ctx.set_timing(False)
     stt = out_t[4]
     n0 = len(wl["trackers"][0].get_template(0)[0])
-    bytes_eval0 = 16 * n0 + 12 * wl["w"] * wl["h"]
+    bytes_eval0 = 16 * n0 + min(12 * wl["w"] * wl["h"], 48 * n0)  # sparse templates do not touch the whole image
     l0_ms = stt.eval_kernel_union_ms[0]
     l0_launches = stt.launches[0]
     l0_dispatches = stt.eval_dispatches[0]
@@ -374,7 +374,7 @@ def bench_tracking(args):
     per_level = []
     for l in range(wl["nl"]):
         nl_ = len(wl["trackers"][0].get_template(l)[0])
-        by = 16 * nl_ + 12 * (wl["w"] >> l) * (wl["h"] >> l)
+        by = 16 * nl_ + min(12 * (wl["w"] >> l) * (wl["h"] >> l), 48 * nl_)
         ms = stt.eval_kernel_union_ms[l]
         per_level.append({"lvl": l, "evals": int(stt.evals[l]), "launches": int(stt.launches[l]), "kernel_ms": round(ms, 4),
                           "GBps": round(stt.evals[l] * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})

@@ -974,8 +974,10 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     for (int l = 0; l < nlevels; l++) {
       if ((int)S.evals[l] > need[l]) need[l] = (int)S.evals[l];
       ctx->stats.evals[l] += S.evals[l];
-      ctx->stats.algorithmic_bytes +=
-          S.evals[l] * (16ll * ts[i]->desc.lv[l].n + 12ll * (ts[i]->w >> l) * (ts[i]->h >> l));
+      // compulsory bytes of one evaluation: the template once + the target image once, or, for a sparse template,
+      // the four 12-byte taps of every point if that is less
+      const long long nl = ts[i]->desc.lv[l].n, img = 12ll * (ts[i]->w >> l) * (ts[i]->h >> l);
+      ctx->stats.algorithmic_bytes += S.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
     }
   }
   // next call's schedule: what this batch needed plus one, decaying slowly towards it
