@@ -315,6 +315,8 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
   if (!ctx || !out || !T_f1_f0 || !K1) return invalid("dsm_tracker_create: null argument");
   if (nlevels < 1 || nlevels > DSM_MAX_LEVELS) return invalid("dsm_tracker_create: nlevels out of range");
   if ((w >> (nlevels - 1)) < 8 || (h >> (nlevels - 1)) < 8) return invalid("dsm_tracker_create: image too small for nlevels");
+  // the eval kernels address texels with 32-bit byte offsets (16 bytes per texel at most)
+  if ((long long)w * h * 16 >= (1ll << 32)) return invalid("dsm_tracker_create: image too large");
   DSM_HIP(hipSetDevice(ctx->device));
   dsm_tracker *t = new dsm_tracker();
   t->ctx = ctx;

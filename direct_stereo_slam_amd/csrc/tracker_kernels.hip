@@ -85,7 +85,7 @@ __device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, 
   const unsigned base = (unsigned)(ix + iy * w);
   if (LAYOUT == IMG_AOS3) {
     // 32-bit byte offsets from the (scalar) image base: global_load with saddr + voffset, no
-    // 64-bit vector address arithmetic
+    // 64-bit vector address arithmetic.  (Shift-add / 24-bit forms of these multiplies were measured: no gain.)
     const unsigned off0 = 12u * base, off1 = off0 + 12u * (unsigned)w;
     const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
     const fvec3u a = *(const DSM_GLOBAL fvec3u *)(cb + off0);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
         const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
         const bool ordinary = (unsigned)(ex + 32) <= 64u && (MODE == 2 || __builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
                               __builtin_fabsf(pt2) >= 0x1p-34f;
-        if (__builtin_expect(__ballot(!ordinary) != 0ull, 0)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ordinary) != 0ull, 0)) {
           W.u = pt0 / pt2;
           W.v = pt1 / pt2;
           W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2; // PoseEstimator.cpp:197: 1 / pt[2]
@@ -264,9 +264,9 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
       E += fin ? e_term : 0.0f;
       // integer outputs are counted per wave on the scalar unit (s_bcnt1 of the lane masks)
-      n_terms += __builtin_popcountll(__ballot(fin));
-      n_sat += __builtin_popcountll(__ballot(fin && sat));
-      n_warped += __builtin_popcountll(__ballot(use));
+      n_terms += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fin));
+      n_sat += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && sat));
+      n_warped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(use));
       const float wgt = use ? hw : 0.0f;
       if (MODE != 1) {
         // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
@@ -328,31 +328,56 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
         // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
         return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)));
       };
-      // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
-      // (Deeper register rings and bulk staging through LDS were measured and bought nothing -- the
-      // kernel is not bound by the latency of this stream)
       const int i = chunk_start + tid;
       const fvec4 p0 = load_pt(i);
-      int i2 = i + kThreads;
-      fvec4 p_next = load_pt(i2);
-      __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-      Warped Wc;
-      Taps Tc;
-      stage_a(p0, i < n, Wc, Tc);
-      for (int k = 0; k < P; k++) {
-        // stage A for point k+1 (its template entry was prefetched one iteration ago)
-        const fvec4 p = p_next;
-        const bool in_next = i2 < n && k + 1 < P;
-        const int i3 = i2 + kThreads;
-        p_next = load_pt(i3);
-        Warped Wn;
-        Taps Tn;
-        stage_a(p, in_next, Wn, Tn);
-        // stage B for point k
-        stage_b(Wc, Tc);
-        Wc = Wn;
-        Tc = Tn;
-        i2 = i3;
+      if (LVL0) {
+        // Level 0 (long loops, HBM-resident targets): two points per trip with FIXED register roles (sets a / b).
+        // The taps of point k+1 are issued before the arithmetic of point k and awaited only after the taps of
+        // point k+2 have been issued, so two points' gathers are in flight per wave; template entries are fetched
+        // two points ahead.  (The rotating single-body loop below makes the compiler copy the freshly loaded tap
+        // registers at the back-edge, which waits for them -- vmcnt(0) -- and leaves only the arithmetic of one
+        // point to cover the memory latency; it needs 7 VGPRs less, which is one more resident wave per SIMD and
+        // worth more than the deeper pipeline on the small, cache-resident levels: level 0 +5 %, levels 1-3 -7..-10 %
+        // with this form.)  Points beyond the chunk / the list are masked (they add exact zeros), so odd P needs
+        // no special case.
+        fvec4 ea = load_pt(i + kThreads), eb = load_pt(i + 2 * kThreads);
+        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+        Warped Wa, Wb;
+        Taps Ta, Tb;
+        stage_a(p0, i < n, Wa, Ta);
+        int ia = i + kThreads; // index of the entry held in ea (eb: ia + kThreads)
+        for (int k = 0; k < P; k += 2) {
+          stage_a(ea, ia < n && k + 1 < P, Wb, Tb); // point k+1
+          ea = load_pt(ia + 2 * kThreads);
+          stage_b(Wa, Ta); // point k
+          stage_a(eb, ia + kThreads < n && k + 2 < P, Wa, Ta); // point k+2
+          eb = load_pt(ia + 3 * kThreads);
+          stage_b(Wb, Tb); // point k+1 (masked when k+1 == P)
+          ia += 2 * kThreads;
+        }
+      } else {
+        // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
+        int i2 = i + kThreads;
+        fvec4 p_next = load_pt(i2);
+        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+        Warped Wc;
+        Taps Tc;
+        stage_a(p0, i < n, Wc, Tc);
+        for (int k = 0; k < P; k++) {
+          // stage A for point k+1 (its template entry was prefetched one iteration ago)
+          const fvec4 p = p_next;
+          const bool in_next = i2 < n && k + 1 < P;
+          const int i3 = i2 + kThreads;
+          p_next = load_pt(i3);
+          Warped Wn;
+          Taps Tn;
+          stage_a(p, in_next, Wn, Tn);
+          // stage B for point k
+          stage_b(Wc, Tc);
+          Wc = Wn;
+          Tc = Tn;
+          i2 = i3;
+        }
       }
     }
 

@@ -124,6 +124,53 @@ __global__ __launch_bounds__(256) void k4(const fvec4 *__restrict__ pts, const f
   __builtin_amdgcn_s_waitcnt(0);
   if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
 }
+// modes 10-12: register loads with tap addresses that DEPEND on the template entry, DEPTH points ahead (the eval
+// kernel's structure is DEPTH = 1), WORK x 8 dependent FMAs per point
+template <int DEPTH, int WORK, int PAD = 0>
+__global__ __launch_bounds__(256) void k5(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+  __shared__ float pad[PAD > 0 ? PAD : 1];
+  if (PAD > 0 && threadIdx.x == 300) pad[0] = 1.f;
+  float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  float acc = 0.f;
+  fvec3u T[DEPTH][4];
+  fvec4 q[DEPTH + 1];
+  auto issue = [&](const fvec4 &pt, fvec3u *t) {
+    const unsigned off0 = 12u * (unsigned)(int)pt.x, off1 = off0 + 12u * (unsigned)w;
+    t[0] = *(const fvec3u *)(ib + off0), t[1] = *(const fvec3u *)(ib + off0 + 12u);
+    t[2] = *(const fvec3u *)(ib + off1), t[3] = *(const fvec3u *)(ib + off1 + 12u);
+  };
+#pragma unroll
+  for (int d = 0; d <= DEPTH; d++) q[d] = __builtin_nontemporal_load(p + d * 256 + tid);
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) issue(q[d], T[d]);
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int inext = (kk + DEPTH + 1) * 256 + tid;
+    const fvec4 qn = __builtin_nontemporal_load(p + (inext < 4096 ? inext : tid));
+    fvec3u Tn[4];
+    issue(q[DEPTH], Tn); // taps of point k + DEPTH
+    const fvec3u *t = T[0];
+    const float a0 = t[0].x, a1 = t[1].y, a2 = t[2].z, a3 = t[3].x;
+    acc += (a0 + a1) + (a2 + a3) + q[0].w;
+#pragma unroll
+    for (int j = 0; j < WORK; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) c[e] = __builtin_fmaf(c[e], a0, a1 + (float)e);
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; d++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) T[d][j] = T[d + 1][j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) T[DEPTH - 1][j] = Tn[j];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) q[d] = q[d + 1];
+    q[DEPTH] = qn;
+  }
+  if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
+}
 int main() {
   const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = 96;
   const int chunks = (npts - 4096) / 4096; // whole chunks only, rows stay inside the image
@@ -131,7 +178,7 @@ int main() {
   hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
   { std::vector<float> hp((size_t)npts * 4, 0.f); for (int i = 0; i < npts; i++) hp[4 * (size_t)i] = (float)(((i / 4096) * 4096) + 2 * w + 2 + (i % 4096)); for (int f = 0; f < frames; f++) hipMemcpy((char *)pts + (size_t)f * npts * 16, hp.data(), (size_t)npts * 16, hipMemcpyHostToDevice); } hipMemset(img, 0, (size_t)frames * npx * 12 + 65536);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int mode = 0; mode < 10; mode++) {
+  for (int mode = 10; mode < 22; mode++) {
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(a);
       for (int it = 0; it < 5; it++) {
@@ -144,6 +191,18 @@ int main() {
         if (mode == 7) hipLaunchKernelGGL((k4<0, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 8) hipLaunchKernelGGL((k4<25, 2048>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 9) hipLaunchKernelGGL((k4<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 10) hipLaunchKernelGGL((k5<1, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 11) hipLaunchKernelGGL((k5<2, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 12) hipLaunchKernelGGL((k5<3, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 13) hipLaunchKernelGGL((k5<1, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 14) hipLaunchKernelGGL((k5<2, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 15) hipLaunchKernelGGL((k5<3, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 16) hipLaunchKernelGGL((k5<1, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 17) hipLaunchKernelGGL((k5<2, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 18) hipLaunchKernelGGL((k5<3, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 19) hipLaunchKernelGGL((k5<4, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 20) hipLaunchKernelGGL((k5<6, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 21) hipLaunchKernelGGL((k5<2, 0, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 6) hipLaunchKernelGGL((k3<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
       }
       hipEventRecord(b); hipEventSynchronize(b);
