@@ -178,7 +178,7 @@ int main() {
   hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
   { std::vector<float> hp((size_t)npts * 4, 0.f); for (int i = 0; i < npts; i++) hp[4 * (size_t)i] = (float)(((i / 4096) * 4096) + 2 * w + 2 + (i % 4096)); for (int f = 0; f < frames; f++) hipMemcpy((char *)pts + (size_t)f * npts * 16, hp.data(), (size_t)npts * 16, hipMemcpyHostToDevice); } hipMemset(img, 0, (size_t)frames * npx * 12 + 65536);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int mode = 10; mode < 22; mode++) {
+  for (int mode = 0; mode < 22; mode++) {
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(a);
       for (int it = 0; it < 5; it++) {
