@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent stereo frames in flight per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="independent stereo frames in flight per GPU")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes (cycled over the batch)")
     ap.add_argument("--config", default="S1", choices=["S1", "S2", "S3"], help="S1 = 1232x368x5 (reference), S2 = 1248x384x6 (metric-literal extension), S3 = 1920x1080x6 (floor-halved, BASELINE configs[3] shape)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])

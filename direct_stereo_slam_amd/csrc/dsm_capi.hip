@@ -777,7 +777,15 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
             ctx->partial_stride, ctx->d_start, nullptr, ctx->d_status);
   // Work-queue form: one launch of persistent workgroups for the whole call (queue_kernel).  Scheduling only:
   // results are bit-identical to the launch-per-step form below.
-  const bool use_queue = P.work_queue >= 2 || (P.work_queue == 1 && n >= 32);
+  // Default rule (measured): the queue form wins while the batch is large enough to fill the
+  // persistent workgroups and small enough that its per-item cost (a few microseconds per chunk) does not add up --
+  // up to about 32 k finest-level chunks per call (256 dense KITTI frames; thousands of sparse ones).
+  bool use_queue = P.work_queue >= 2;
+  if (P.work_queue == 1 && n >= 32) {
+    long long chunks0 = 0;
+    for (int i = 0; i < n; i++) chunks0 += num_chunks(ts[i]->desc.lv[0].n);
+    use_queue = chunks0 <= 32768;
+  }
   if (use_queue) {
     int max_items = 1;
     for (int L = 0; L <= coarsest; L++)

@@ -79,14 +79,16 @@ typedef struct dsm_params {
                                          items from a device-side queue; the workgroup completing an evaluation performs
                                          the LM step and enqueues the problem's next evaluation, so problems advance
                                          independently instead of in lock-step launches: 0 never, 1 (default) for batches
-                                         of at least 32 problems, 2 always.  Scheduling only -- results are bit-identical. */
+                                         of at least 32 problems with at most 32768 finest-level chunks in all (beyond
+                                         that the lock-step launches are faster), 2 always.  Scheduling only -- results
+                                         are bit-identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
 typedef struct dsm_stats {
   int64_t evals[DSM_MAX_LEVELS];        /* fused residual+Jacobian evaluations executed, summed over the batch */
   int64_t launches[DSM_MAX_LEVELS];     /* eval kernel launches per level */
-  int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + 12*w_l*h_l   */
+  int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + min(12*w_l*h_l, 48*n_l)   */
   double eval_kernel_ms[DSM_MAX_LEVELS];/* summed HIP-event durations of the eval kernel dispatches per level (timing enabled) */
   double eval_kernel_union_ms[DSM_MAX_LEVELS]; /* time during which at least one of them ran (stream groups overlap) */
   int64_t eval_dispatches[DSM_MAX_LEVELS];     /* timed dispatches per level (launches x stream groups) */

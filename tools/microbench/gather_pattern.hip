@@ -1,6 +1,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 typedef float fvec4 __attribute__((ext_vector_type(4)));
 typedef float fvec3u __attribute__((ext_vector_type(3), aligned(4)));
 // one block = one "chunk": 4096 template entries (16 B each, coalesced) + the matching image rows (12-byte texels)
@@ -127,13 +128,15 @@ __global__ __launch_bounds__(256) void k4(const fvec4 *__restrict__ pts, const f
 // modes 10-12: register loads with tap addresses that DEPEND on the template entry, DEPTH points ahead (the eval
 // kernel's structure is DEPTH = 1), WORK x 8 dependent FMAs per point
 template <int DEPTH, int WORK, int PAD = 0>
-__global__ __launch_bounds__(256) void k5(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+__global__ __launch_bounds__(256) void k5(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out,
+                                          const fvec4 *const *pts_tab = nullptr, const float *const *img_tab = nullptr) {
   __shared__ float pad[PAD > 0 ? PAD : 1];
   if (PAD > 0 && threadIdx.x == 300) pad[0] = 1.f;
   float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
   const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
-  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  // pts_tab / img_tab: every frame in allocations of its own (as the trackers of the product are)
+  const fvec4 *p = (pts_tab ? pts_tab[frame] : pts + (size_t)frame * npts_per_frame) + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img_tab ? img_tab[frame] : img + (size_t)frame * npx_per_frame * 3);
   float acc = 0.f;
   fvec3u T[DEPTH][4];
   fvec4 q[DEPTH + 1];
@@ -171,14 +174,28 @@ __global__ __launch_bounds__(256) void k5(const fvec4 *__restrict__ pts, const f
   }
   if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
 }
-int main() {
-  const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = 96;
+int main(int argc, char **argv) {
+  const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = argc > 1 ? atoi(argv[1]) : 96;
+  const int mode_lo = argc > 2 ? atoi(argv[2]) : 0, mode_hi = argc > 3 ? atoi(argv[3]) : 21;
   const int chunks = (npts - 4096) / 4096; // whole chunks only, rows stay inside the image
   fvec4 *pts; float *img, *out;
   hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
   { std::vector<float> hp((size_t)npts * 4, 0.f); for (int i = 0; i < npts; i++) hp[4 * (size_t)i] = (float)(((i / 4096) * 4096) + 2 * w + 2 + (i % 4096)); for (int f = 0; f < frames; f++) hipMemcpy((char *)pts + (size_t)f * npts * 16, hp.data(), (size_t)npts * 16, hipMemcpyHostToDevice); } hipMemset(img, 0, (size_t)frames * npx * 12 + 65536);
+  // argv[4] = 1: one allocation pair per frame + pointer tables (modes 16-21 only)
+  const bool separate = argc > 4 && atoi(argv[4]) == 1;
+  const fvec4 **pts_tab = nullptr; const float **img_tab = nullptr;
+  if (separate) {
+    std::vector<const fvec4 *> hp(frames); std::vector<const float *> hi(frames);
+    for (int f = 0; f < frames; f++) {
+      void *a, *b2; hipMalloc(&a, (size_t)npts * 16); hipMalloc(&b2, (size_t)npx * 12 + 4096);
+      hipMemcpy(a, pts, (size_t)npts * 16, hipMemcpyDeviceToDevice); hipMemset(b2, 0, (size_t)npx * 12 + 4096);
+      hp[f] = (const fvec4 *)a; hi[f] = (const float *)b2;
+    }
+    hipMalloc(&pts_tab, frames * 8); hipMalloc(&img_tab, frames * 8);
+    hipMemcpy(pts_tab, hp.data(), frames * 8, hipMemcpyHostToDevice); hipMemcpy(img_tab, hi.data(), frames * 8, hipMemcpyHostToDevice);
+  }
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int mode = 0; mode < 22; mode++) {
+  for (int mode = mode_lo; mode <= mode_hi; mode++) {
     for (int rep = 0; rep < 2; rep++) {
       hipEventRecord(a);
       for (int it = 0; it < 5; it++) {
@@ -197,12 +214,12 @@ int main() {
         if (mode == 13) hipLaunchKernelGGL((k5<1, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 14) hipLaunchKernelGGL((k5<2, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 15) hipLaunchKernelGGL((k5<3, 25>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 16) hipLaunchKernelGGL((k5<1, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 17) hipLaunchKernelGGL((k5<2, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 18) hipLaunchKernelGGL((k5<3, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 19) hipLaunchKernelGGL((k5<4, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 20) hipLaunchKernelGGL((k5<6, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
-        if (mode == 21) hipLaunchKernelGGL((k5<2, 0, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 16) hipLaunchKernelGGL((k5<1, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 17) hipLaunchKernelGGL((k5<2, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 18) hipLaunchKernelGGL((k5<3, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 19) hipLaunchKernelGGL((k5<4, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 20) hipLaunchKernelGGL((k5<6, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 21) hipLaunchKernelGGL((k5<2, 0, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
         if (mode == 6) hipLaunchKernelGGL((k3<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
       }
       hipEventRecord(b); hipEventSynchronize(b);
