@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
     ap.add_argument("--u8", action="store_true", help="with --with-upload: camera bytes (mono8) are handed over instead of float images; the synthetic images are rounded to 0..255 for the whole run")
+    ap.add_argument("--overlap", action="store_true", help="with --with-upload: double-buffered frame slots -- the images of the next step are handed over asynchronously (dsm_upload_images_async into DSM_SLOT_NEXT_*) while this step is tracked")
     ap.add_argument("--single-uploads", action="store_true", help="with --with-upload: one dsm_tracker_upload_image call per image instead of one dsm_upload_images call per step")
     ap.add_argument("--pinned", action="store_true", help="with --with-upload: the host images live in pinned memory (dsm_host_alloc)")
     ap.add_argument("--queue", type=int, default=0,
@@ -179,7 +180,7 @@ def build_workload(args, ctx, rank):
         if b < args.cpu_frames:
             host.append((tpl, new, right))
     return dict(w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params, images=images,
-                single_uploads=args.single_uploads)
+                single_uploads=args.single_uploads, overlap=args.overlap, primed=False)
 
 
 def one_step(ctx, wl, kf_idx, with_upload=False):
@@ -193,6 +194,16 @@ def one_step(ctx, wl, kf_idx, with_upload=False):
                 trk.upload_image(0, wl["images"][i][0], 1.0)
                 if i in kfs:
                     trk.upload_image(1, wl["images"][i][1], 1.0)
+        elif wl["overlap"]:
+            # double-buffered: swap in what travelled during the previous step, start the next hand-over, track
+            trks = list(wl["trackers"]) + [wl["trackers"][i] for i in kf_idx]
+            imgs = [wl["images"][i][0] for i in range(B)] + [wl["images"][i][1] for i in kf_idx]
+            if not wl["primed"]:
+                ctx.upload_images(trks, [2] * B + [3] * len(kf_idx), imgs)
+                wl["primed"] = True
+            ctx.upload_wait()
+            ctx.advance_frames(trks, [0] * B + [1] * len(kf_idx))
+            ctx.upload_images(trks, [2] * B + [3] * len(kf_idx), imgs, asynchronous=True)
         else:  # one call: the B new left images and the keyframes' right images
             trks = list(wl["trackers"]) + [wl["trackers"][i] for i in kf_idx]
             ctx.upload_images(trks, [0] * B + [1] * len(kf_idx), [wl["images"][i][0] for i in range(B)] + [wl["images"][i][1] for i in kf_idx])

@@ -84,6 +84,9 @@ SYMBOLS = {
     "dsm_tracker_upload_frame": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
     "dsm_tracker_upload_image": (C.c_int, [_vp, C.c_int, c_float_p, C.c_float]),
     "dsm_upload_images": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
+    "dsm_upload_images_async": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
+    "dsm_upload_wait": (C.c_int, [_vp]),
+    "dsm_frames_advance": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p]),
     "dsm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "dsm_host_free": (C.c_int, [_vp]),
     "dsm_tracker_get_frame": (C.c_int, [_vp, C.c_int, C.c_int, c_float_p]),

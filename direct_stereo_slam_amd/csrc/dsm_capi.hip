@@ -244,6 +244,10 @@ int dsm_context_create(int device_ordinal, dsm_context **out) {
   DSM_HIP(hipEventCreate(&ctx->ev_total[1]));
   DSM_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
   DSM_HIP(hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
+  if (const char *e = getenv("DSM_ASYNC_COPY_BLOCKS")) {
+    const int v = atoi(e);
+    if (v > 0) ctx->async_copy_blocks = v;
+  }
   *out = ctx;
   return DSM_OK;
 }
@@ -278,6 +282,12 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipFree(ctx->d_desc_stage);
   hipHostFree(ctx->h_desc_stage);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  if (ctx->upload_stream) {
+    hipStreamSynchronize(ctx->upload_stream);
+    hipStreamDestroy(ctx->upload_stream);
+    hipEventDestroy(ctx->upload_copies_event);
+    hipEventDestroy(ctx->upload_done_event);
+  }
   hipFree(ctx->d_pyr_jobs);
   hipHostFree(ctx->h_pyr_jobs);
   hipEventDestroy(ctx->ev_total[0]);
@@ -385,6 +395,10 @@ int dsm_tracker_destroy(dsm_tracker *t) {
   }
   hipFree(t->d_raw[0]);
   hipFree(t->d_raw[1]);
+  for (int s = 0; s < 2; s++) {
+    hipFree(t->d_raw_back[s]);
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) hipFree(t->d_img_back[s][l]);
+  }
   hipFree(t->d_desc);
   delete t;
   return DSM_OK;
@@ -577,8 +591,43 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   return DSM_OK;
 }
 
-int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
-                      const float *ab_exposures, int pixel_type, size_t row_pitch_bytes) {
+// Target buffers of a hand-over: the frame slot itself (0, 1) or its back buffers (DSM_SLOT_NEXT_*), which
+// dsm_frames_advance later swaps in.  Back buffers are allocated on first use.
+static int upload_target(dsm_tracker *t, int slot, float **raw, float **img) {
+  const size_t npx0 = (size_t)t->w * t->h;
+  const int s = slot & 1;
+  const bool back = slot >= 2;
+  const int ts = t->desc.layout == IMG_AOS3 ? 3 : 4;
+  if (back) {
+    for (int l = 0; l < t->nlevels; l++)
+      if (!t->d_img_back[s][l]) {
+        const size_t npx = (size_t)(t->w >> l) * (t->h >> l);
+        DSM_HIP(hipMalloc(&t->d_img_back[s][l], sizeof(float) * ts * npx));
+      }
+    if (!t->d_raw_back[s]) DSM_HIP(hipMalloc(&t->d_raw_back[s], npx0 * sizeof(float)));
+  } else if (!t->d_raw[s]) {
+    DSM_HIP(hipMalloc(&t->d_raw[s], npx0 * sizeof(float)));
+  }
+  *raw = back ? t->d_raw_back[s] : t->d_raw[s];
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) img[l] = l < t->nlevels ? (back ? t->d_img_back[s][l] : t->d_img[s][l]) : nullptr;
+  return DSM_OK;
+}
+
+static void upload_mark(dsm_tracker *t, int slot, float exposure) {
+  if (slot >= 2) {
+    t->have_back[slot & 1] = true;
+    t->back_exposure[slot & 1] = exposure;
+  } else {
+    t->desc.exposure[slot] = exposure;
+    t->have_frame[slot] = true;
+    t->desc_dirty = true;
+  }
+}
+
+// async = false: copies and pyramids ordered on the context's stream, returns when the copies are through.
+// async = true: everything on the context's upload stream, returns at once; dsm_upload_wait waits for the copies.
+static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                              const float *ab_exposures, int pixel_type, size_t row_pitch_bytes, bool async) {
   if (!ctx || n < 0 || (n > 0 && (!trackers || !slots || !images)))
     return invalid("dsm_upload_images: bad argument");
   if (pixel_type != DSM_PIXEL_F32 && pixel_type != DSM_PIXEL_U8) return invalid("dsm_upload_images: bad pixel type");
@@ -588,7 +637,7 @@ int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, con
   const dsm_tracker *t0 = trackers[0];
   for (int i = 0; i < n; i++) {
     const dsm_tracker *t = trackers[i];
-    if (!t || !images[i] || slots[i] < 0 || slots[i] > 1) return invalid("dsm_upload_images: bad entry");
+    if (!t || !images[i] || slots[i] < 0 || slots[i] > 3) return invalid("dsm_upload_images: bad entry");
     if (t->ctx != ctx) return invalid("dsm_upload_images: tracker of another context");
     if (t->w != t0->w || t->h != t0->h || t->nlevels != t0->nlevels || t->desc.layout != t0->desc.layout)
       return invalid("dsm_upload_images: trackers of different geometry in one call");
@@ -598,7 +647,20 @@ int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, con
   const size_t row = (size_t)t0->w * px;
   if (row_pitch_bytes != 0 && row_pitch_bytes < row) return invalid("dsm_upload_images: row pitch smaller than a row");
   if (!ctx->copy_stream) DSM_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (async && !ctx->upload_stream) {
+    DSM_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    DSM_HIP(hipEventCreateWithFlags(&ctx->upload_copies_event, hipEventDisableTiming));
+    DSM_HIP(hipEventCreateWithFlags(&ctx->upload_done_event, hipEventDisableTiming));
+  }
+  // the job table and the caller's buffers of the previous asynchronous hand-over are still being read until its
+  // copies are through
+  if (ctx->upload_pending) {
+    DSM_HIP(hipEventSynchronize(ctx->upload_copies_event));
+    ctx->upload_pending = false;
+  }
   if (n > ctx->pyr_jobs_cap) {
+    if (ctx->upload_stream) DSM_HIP(hipStreamSynchronize(ctx->upload_stream)); // pyramid kernels read the old table
+    DSM_HIP(hipStreamSynchronize(ctx->stream));
     int rc = realloc_dev(&ctx->d_pyr_jobs, (size_t)n);
     if (rc) return rc;
     rc = realloc_pinned(&ctx->h_pyr_jobs, (size_t)n);
@@ -611,11 +673,11 @@ int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, con
   bool all_pinned = true;
   uintptr_t align = (uintptr_t)row | (uintptr_t)pitch;
   for (int i = 0; i < n; i++) {
-    dsm_tracker *t = trackers[i];
-    if (!t->d_raw[slots[i]]) DSM_HIP(hipMalloc(&t->d_raw[slots[i]], npx0 * sizeof(float)));
-    ctx->h_pyr_jobs[i].raw = t->d_raw[slots[i]];
+    float *raw = nullptr;
+    int rc = upload_target(trackers[i], slots[i], &raw, ctx->h_pyr_jobs[i].img);
+    if (rc) return rc;
+    ctx->h_pyr_jobs[i].raw = raw;
     ctx->h_pyr_jobs[i].src = nullptr;
-    for (int l = 0; l < DSM_MAX_LEVELS; l++) ctx->h_pyr_jobs[i].img[l] = l < t->nlevels ? t->d_img[slots[i]][l] : nullptr;
     if (all_pinned) {
       hipPointerAttribute_t attr{};
       if (hipPointerGetAttributes(&attr, images[i]) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
@@ -627,56 +689,114 @@ int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, con
       }
     }
   }
+  const hipStream_t work = async ? ctx->upload_stream : ctx->stream; // job table, copy kernel, pyramid kernels
+  const bool u8 = pixel_type == DSM_PIXEL_U8;
+  // the job table of the previous hand-over may still be read by its pyramid kernels on the other work stream
+  if (async) {
+    DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
+    DSM_HIP(hipStreamWaitEvent(work, ctx->copy_event, 0));
+  } else if (ctx->upload_stream) {
+    DSM_HIP(hipStreamWaitEvent(work, ctx->upload_done_event, 0));
+  }
   if (all_pinned) {
     const int unit = (align & 15) == 0 ? 16 : (align & 3) == 0 ? 4 : 1;
-    DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, ctx->stream));
-    launch_host_rows_copy(ctx->stream, ctx->d_pyr_jobs, n, (int)row, t0->h, pitch, unit);
+    DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, work));
+    // asynchronous: few workgroups, so that the host reads (microseconds of latency each) do not sit in the memory
+    // pipelines of the CUs the tracking kernels run on
+    launch_host_rows_copy(work, ctx->d_pyr_jobs, n, (int)row, t0->h, pitch, unit, async ? ctx->async_copy_blocks : 1 << 20);
     DSM_HIP(hipGetLastError());
-    DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
-    launch_pyramid_batched(ctx->stream, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, t0->desc.layout, pixel_type == DSM_PIXEL_U8);
+    DSM_HIP(hipEventRecord(async ? ctx->upload_copies_event : ctx->copy_event, work));
+    launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, t0->desc.layout, u8);
     DSM_HIP(hipGetLastError());
-    DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
-    for (int i = 0; i < n; i++) {
-      dsm_tracker *t = trackers[i];
-      t->desc.exposure[slots[i]] = ab_exposures ? ab_exposures[i] : 1.0f;
-      t->have_frame[slots[i]] = true;
-      t->desc_dirty = true;
+    if (!async) DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
+  } else {
+    // the staging buffers may still be read by the pyramid kernels of the previous hand-over
+    DSM_HIP(hipEventRecord(ctx->copy_event, work));
+    DSM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0));
+    DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, ctx->copy_stream));
+    // groups: the pyramids of one group are built under the copies of the next
+    const int group = 16;
+    const int ngroups = (n + group - 1) / group;
+    while ((int)ctx->upload_events.size() < ngroups) {
+      hipEvent_t ev;
+      DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx->upload_events.push_back(ev);
     }
-    return DSM_OK;
-  }
-  // the staging buffers may still be read by the pyramid kernels of the previous hand-over
-  DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
-  DSM_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->copy_event, 0));
-  DSM_HIP(hipMemcpyAsync(ctx->d_pyr_jobs, ctx->h_pyr_jobs, sizeof(dsm::PyrJob) * n, hipMemcpyHostToDevice, ctx->copy_stream));
-  // groups: the pyramids of one group are built under the copies of the next
-  const int group = 16;
-  const int ngroups = (n + group - 1) / group;
-  while ((int)ctx->upload_events.size() < ngroups) {
-    hipEvent_t ev;
-    DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    ctx->upload_events.push_back(ev);
-  }
-  for (int g = 0; g < ngroups; g++) {
-    const int i0 = g * group, i1 = i0 + group < n ? i0 + group : n;
-    for (int i = i0; i < i1; i++) {
-      void *dst = trackers[i]->d_raw[slots[i]];
-      if (pitch == row)
-        DSM_HIP(hipMemcpyAsync(dst, images[i], npx0 * px, hipMemcpyHostToDevice, ctx->copy_stream));
-      else
-        DSM_HIP(hipMemcpy2DAsync(dst, row, images[i], pitch, row, (size_t)t0->h, hipMemcpyHostToDevice, ctx->copy_stream));
+    for (int g = 0; g < ngroups; g++) {
+      const int i0 = g * group, i1 = i0 + group < n ? i0 + group : n;
+      for (int i = i0; i < i1; i++) {
+        void *dst = const_cast<void *>(ctx->h_pyr_jobs[i].raw);
+        if (pitch == row)
+          DSM_HIP(hipMemcpyAsync(dst, images[i], npx0 * px, hipMemcpyHostToDevice, ctx->copy_stream));
+        else
+          DSM_HIP(hipMemcpy2DAsync(dst, row, images[i], pitch, row, (size_t)t0->h, hipMemcpyHostToDevice, ctx->copy_stream));
+      }
+      DSM_HIP(hipEventRecord(ctx->upload_events[g], ctx->copy_stream));
+      DSM_HIP(hipStreamWaitEvent(work, ctx->upload_events[g], 0));
+      launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs + i0, i1 - i0, t0->desc.layout, u8);
+      DSM_HIP(hipGetLastError());
     }
-    DSM_HIP(hipEventRecord(ctx->upload_events[g], ctx->copy_stream));
-    DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_events[g], 0));
-    launch_pyramid_batched(ctx->stream, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs + i0, i1 - i0, t0->desc.layout,
-                           pixel_type == DSM_PIXEL_U8);
-    DSM_HIP(hipGetLastError());
+    if (async)
+      DSM_HIP(hipEventRecord(ctx->upload_copies_event, ctx->copy_stream));
+    else
+      DSM_HIP(hipStreamSynchronize(ctx->copy_stream)); // the caller's buffers are free; the pyramid kernels run on behind
   }
-  // the caller's buffers are free once the copies are through; the pyramid kernels run on behind
-  DSM_HIP(hipStreamSynchronize(ctx->copy_stream));
+  if (async) {
+    DSM_HIP(hipEventRecord(ctx->upload_done_event, work));
+    ctx->upload_pending = true;
+  }
+  for (int i = 0; i < n; i++) upload_mark(trackers[i], slots[i], ab_exposures ? ab_exposures[i] : 1.0f);
+  return DSM_OK;
+}
+
+int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                      const float *ab_exposures, int pixel_type, size_t row_pitch_bytes) {
+  return upload_images_impl(ctx, n, trackers, slots, images, ab_exposures, pixel_type, row_pitch_bytes, false);
+}
+
+int dsm_upload_images_async(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                            const float *ab_exposures, int pixel_type, size_t row_pitch_bytes) {
+  return upload_images_impl(ctx, n, trackers, slots, images, ab_exposures, pixel_type, row_pitch_bytes, true);
+}
+
+int dsm_upload_wait(dsm_context *ctx) {
+  if (!ctx) return invalid("dsm_upload_wait: null context");
+  if (ctx->upload_pending) {
+    DSM_HIP(hipSetDevice(ctx->device));
+    DSM_HIP(hipEventSynchronize(ctx->upload_copies_event));
+    ctx->upload_pending = false;
+  }
+  return DSM_OK;
+}
+
+int dsm_frames_advance(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots) {
+  if (!ctx || n < 0 || (n > 0 && (!trackers || !slots))) return invalid("dsm_frames_advance: bad argument");
+  for (int i = 0; i < n; i++) {
+    const dsm_tracker *t = trackers[i];
+    if (!t || t->ctx != ctx || slots[i] < 0 || slots[i] > 1) return invalid("dsm_frames_advance: bad entry");
+    if (!t->have_back[slots[i]]) return invalid("dsm_frames_advance: nothing was handed over to DSM_SLOT_NEXT_* of this slot");
+    for (int j = 0; j < i; j++)
+      if (trackers[j] == t && slots[j] == slots[i]) return invalid("dsm_frames_advance: the same slot twice");
+  }
+  if (n == 0) return DSM_OK;
+  DSM_HIP(hipSetDevice(ctx->device));
+  // everything enqueued on the context's stream from here on sees the finished pyramids
+  if (ctx->upload_stream) DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_done_event, 0));
   for (int i = 0; i < n; i++) {
     dsm_tracker *t = trackers[i];
-    t->desc.exposure[slots[i]] = ab_exposures ? ab_exposures[i] : 1.0f;
-    t->have_frame[slots[i]] = true;
+    const int s = slots[i];
+    for (int l = 0; l < t->nlevels; l++) {
+      float *f = t->d_img[s][l];
+      t->d_img[s][l] = t->d_img_back[s][l];
+      t->d_img_back[s][l] = f;
+      t->desc.lv[l].img[s] = t->d_img[s][l];
+    }
+    float *r = t->d_raw[s];
+    t->d_raw[s] = t->d_raw_back[s];
+    t->d_raw_back[s] = r;
+    t->desc.exposure[s] = t->back_exposure[s];
+    t->have_frame[s] = true;
+    t->have_back[s] = false;
     t->desc_dirty = true;
   }
   return DSM_OK;

@@ -36,6 +36,12 @@ struct dsm_context {
   bool desc_stage_busy = false;
   // batched hand-over (dsm_upload_images): copies on a stream of their own, one event per group of images
   hipStream_t copy_stream = nullptr;
+  // asynchronous hand-over (dsm_upload_images_async): its own work stream; copies_event = the caller's buffers are
+  // free, done_event = the pyramids are built
+  hipStream_t upload_stream = nullptr;
+  hipEvent_t upload_copies_event = nullptr, upload_done_event = nullptr;
+  bool upload_pending = false;
+  int async_copy_blocks = 48;  // DSM_ASYNC_COPY_BLOCKS (developer knob)
   std::vector<hipEvent_t> upload_events;
   dsm::PyrJob *d_pyr_jobs = nullptr, *h_pyr_jobs = nullptr; // h: pinned
   int pyr_jobs_cap = 0;
@@ -80,6 +86,11 @@ struct dsm_tracker {
   int pts_cap[DSM_MAX_LEVELS] = {}; // template capacity per level (w_l*h_l; w*h on every level for the pose estimator)
   float *d_img[2][DSM_MAX_LEVELS] = {};
   float *d_raw[2] = {nullptr, nullptr}; // raw level-0 images of dsm_tracker_upload_image, per slot
+  // back buffers of the two frame slots (DSM_SLOT_NEXT_*), swapped in by dsm_frames_advance
+  float *d_img_back[2][DSM_MAX_LEVELS] = {};
+  float *d_raw_back[2] = {nullptr, nullptr};
+  bool have_back[2] = {false, false};
+  float back_exposure[2] = {1.f, 1.f};
   bool have_k = false, have_ref = false, have_frame[2] = {false, false};
   int ref_frame_id = -1;
   bool desc_dirty = true;

@@ -91,7 +91,7 @@ struct PyrJob {
 };
 void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerDev *const *d_dst);
 // raw <- src for every job, rows of row_bytes at pitch `pitch` in src (tight in raw); unit: 16, 4 or 1 bytes per access
-void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit);
+void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit, int max_blocks);
 void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, int layout, bool u8);
 
 // ring-key kernels

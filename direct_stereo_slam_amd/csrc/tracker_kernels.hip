@@ -1761,25 +1761,27 @@ void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerD
 // image): every thread moves UNIT bytes per access straight from host memory.
 typedef unsigned copy_uvec4 __attribute__((ext_vector_type(4)));
 template <typename UNIT>
-__global__ void host_rows_copy_kernel(const PyrJob *__restrict__ jobs, int row_units, int rows, size_t pitch_units) {
-  const PyrJob &j = jobs[blockIdx.y];
-  const UNIT *__restrict__ src = (const UNIT *)j.src;
-  UNIT *__restrict__ dst = (UNIT *)j.raw;
-  const int total = row_units * rows;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+__global__ void host_rows_copy_kernel(const PyrJob *__restrict__ jobs, int njobs, int row_units, int rows, size_t pitch_units) {
+  // one grid-stride loop over all images: a small grid (asynchronous hand-over) keeps the slow host reads on a few CUs
+  const long long per = (long long)row_units * rows, total = per * njobs;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const int job = (int)(g / per), idx = (int)(g - (long long)job * per);
     const int r = idx / row_units, c = idx - r * row_units;
-    dst[idx] = __builtin_nontemporal_load(src + (size_t)r * pitch_units + c);
+    const PyrJob &j = jobs[job];
+    ((UNIT *)j.raw)[idx] = __builtin_nontemporal_load((const UNIT *)j.src + (size_t)r * pitch_units + c);
   }
 }
-void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit) {
+void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit, int max_blocks) {
   const int row_units = row_bytes / unit;
-  const dim3 grid(grid_for(row_units * rows), njobs);
+  long long blocks = ((long long)row_units * rows * njobs + 255) / 256;
+  if (blocks > max_blocks) blocks = max_blocks;
+  const dim3 grid((unsigned)blocks);
   if (unit == 16)
-    hipLaunchKernelGGL(host_rows_copy_kernel<copy_uvec4>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch / 16);
+    hipLaunchKernelGGL(host_rows_copy_kernel<copy_uvec4>, grid, dim3(256), 0, s, d_jobs, njobs, row_units, rows, pitch / 16);
   else if (unit == 4)
-    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch / 4);
+    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned>, grid, dim3(256), 0, s, d_jobs, njobs, row_units, rows, pitch / 4);
   else
-    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned char>, grid, dim3(256), 0, s, d_jobs, row_units, rows, pitch);
+    hipLaunchKernelGGL(host_rows_copy_kernel<unsigned char>, grid, dim3(256), 0, s, d_jobs, njobs, row_units, rows, pitch);
 }
 // raw: the level-0 float image; img[l]: the AoS pyramid levels
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout) {

@@ -127,9 +127,11 @@ class Context:
                                      _dp(last), _dp(flow), good.ctypes.data_as(c_int_p)))
         return good.astype(bool), poses, affs, last, flow
 
-    def upload_images(self, trackers, slots, images, exposures=None):
-        """dsm_upload_images: hand over one level-0 image (float32 or uint8, all of one type) per (tracker, slot) in one
-        call.  Images may be row-strided views (e.g. the calibration crop of a larger camera image), all with one pitch."""
+    def upload_images(self, trackers, slots, images, exposures=None, asynchronous=False):
+        """dsm_upload_images[_async]: hand over one level-0 image (float32 or uint8, all of one type) per (tracker, slot)
+        in one call.  Images may be row-strided views (e.g. the calibration crop of a larger camera image), all with one
+        pitch.  Slots 2 / 3 (DSM_SLOT_NEXT_LEFT / RIGHT) are the back buffers that advance_frames swaps in.
+        asynchronous=True returns at once; the images must not be modified until upload_wait()."""
         n = len(trackers)
         if n == 0:
             return
@@ -151,8 +153,23 @@ class Context:
         ps = (C.c_void_p * n)(*[im.ctypes.data for im in keep])
         sl = np.ascontiguousarray(slots, np.int32)
         ex = np.ones(n, np.float32) if exposures is None else np.ascontiguousarray(exposures, np.float32)
-        check(self.L.dsm_upload_images(self.h, n, hs, sl.ctypes.data_as(c_int_p), ps, _fp(ex),
-                                       1 if dt == np.dtype(np.uint8) else 0, pitch))
+        fn = self.L.dsm_upload_images_async if asynchronous else self.L.dsm_upload_images
+        check(fn(self.h, n, hs, sl.ctypes.data_as(c_int_p), ps, _fp(ex), 1 if dt == np.dtype(np.uint8) else 0, pitch))
+        if asynchronous:
+            self._pending_images = keep  # alive until upload_wait
+
+    def upload_wait(self):
+        check(self.L.dsm_upload_wait(self.h))
+        self._pending_images = None
+
+    def advance_frames(self, trackers, slots):
+        """dsm_frames_advance: swap the back buffers of the given (tracker, slot in {0, 1}) pairs in"""
+        n = len(trackers)
+        if n == 0:
+            return
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        sl = np.ascontiguousarray(slots, np.int32)
+        check(self.L.dsm_frames_advance(self.h, n, hs, sl.ctypes.data_as(c_int_p)))
 
     def optimize_scale_batch(self, trackers, scales, coarsest):
         n = len(trackers)

@@ -176,6 +176,19 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
 enum { DSM_PIXEL_F32 = 0, DSM_PIXEL_U8 = 1 };
 int dsm_upload_images(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
                       const float *ab_exposures, int pixel_type, size_t row_pitch_bytes);
+/* Double-buffered hand-over, so that the images of step i+1 travel while step i is being tracked:
+ *   slots DSM_SLOT_NEXT_LEFT / DSM_SLOT_NEXT_RIGHT name the BACK buffers of the two frame slots (allocated on first
+ *   use); dsm_frames_advance swaps back and front of the given (tracker, slot in {0,1}) pairs -- a host-side pointer
+ *   swap -- and orders the context's stream after the pyramids of the last asynchronous hand-over.
+ *   dsm_upload_images_async enqueues copies and pyramid kernels on a stream of its own and returns at once; the caller's
+ *   buffers must stay untouched until dsm_upload_wait returns (pinned buffers are read by the GPU itself).  Track /
+ *   scale calls issued meanwhile read the front buffers only.  No reference counterpart: the reference processes one
+ *   frame at a time on one thread (FrontEnd.cpp:589). */
+enum { DSM_SLOT_NEXT_LEFT = 2, DSM_SLOT_NEXT_RIGHT = 3 };
+int dsm_upload_images_async(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                            const float *ab_exposures, int pixel_type, size_t row_pitch_bytes);
+int dsm_upload_wait(dsm_context *ctx);
+int dsm_frames_advance(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots);
 /* pinned host memory for images handed to dsm_tracker_upload_image (straight DMA instead of a staged copy); no reference
  * counterpart -- the reference keeps its images in ordinary host memory */
 int dsm_host_alloc(size_t bytes, void **out);

@@ -96,8 +96,71 @@ def test_batched_upload_argument_errors(ctx):
     with pytest.raises(DsmError):  # the same slot twice
         ctx.upload_images([a, a], [0, 0], [small.new_img, small.new_img])
     with pytest.raises(DsmError):
-        ctx.upload_images([a], [2], [small.new_img])
+        ctx.upload_images([a], [4], [small.new_img])
     ctx.upload_images([], [], [])  # empty batch: nothing to do
     # the tracker is still usable
     ctx.upload_images([a], [0], [small.new_img])
     _pyramids_equal(a, 0, small.new_p)
+
+
+def test_double_buffered_async_handover(ctx):
+    """DSM_SLOT_NEXT_* + dsm_upload_images_async + dsm_frames_advance: the images of step i+1 travel while step i is
+    tracked from the front buffers; every step's pyramids and results equal the synchronous path's"""
+    from direct_stereo_slam_amd.tracker import pinned_array
+
+    sc = make_scene("small", seed=27)
+    rng = np.random.default_rng(17)
+    n = 6
+    sync = [hip_tracker(ctx, sc) for _ in range(n)]
+    dbl = [hip_tracker(ctx, sc) for _ in range(n)]
+    frames = []
+    for step in range(4):
+        left = [(sc.new_img + rng.normal(0, 2.0 + step, sc.new_img.shape)).astype(np.float32) for _ in range(n)]
+        right = [(sc.right_img + rng.normal(0, 2.0 + step, sc.right_img.shape)).astype(np.float32) for _ in range(n)]
+        frames.append((left, right))
+    pin = [[pinned_array(sc.new_img.shape) for _ in range(2 * n)] for _ in range(2)]  # two sets, alternating
+    poses0 = np.tile(S.IDENTITY_POSE, (n, 1))
+
+    def hand_over(step, asynchronous):
+        bufs = pin[step & 1] if step % 2 == 0 else None  # even steps from pinned, odd steps from pageable memory
+        left, right = frames[step]
+        imgs = left + right
+        if bufs is not None:
+            for b, im in zip(bufs, imgs):
+                b[...] = im
+            imgs = bufs
+        ctx.upload_images(dbl + dbl, [2] * n + [3] * n, imgs, np.full(2 * n, 1.0 + 0.1 * step), asynchronous=asynchronous)
+
+    hand_over(0, False)
+    for step in range(4):
+        ctx.advance_frames(dbl + dbl, [0] * n + [1] * n)
+        if step + 1 < 4:
+            hand_over(step + 1, True)  # travels while this step is tracked
+        left, right = frames[step]
+        for i, t in enumerate(sync):
+            t.upload_image(0, left[i], 1.0 + 0.1 * step)
+            t.upload_image(1, right[i], 1.0 + 0.1 * step)
+        ra = ctx.track_batch(sync, poses0, np.zeros((n, 2)), sc.nl - 1)
+        rb = ctx.track_batch(dbl, poses0, np.zeros((n, 2)), sc.nl - 1)
+        for x, y in zip(ra, rb):
+            np.testing.assert_array_equal(x, y)
+        ea, sa = ctx.optimize_scale_batch(sync, np.ones(n), sc.nl - 1)
+        eb, sb = ctx.optimize_scale_batch(dbl, np.ones(n), sc.nl - 1)
+        np.testing.assert_array_equal(ea, eb)
+        np.testing.assert_array_equal(sa, sb)
+        _pyramids_equal(dbl[step % n], 0, O.make_images(left[step % n], sc.nl))
+        ctx.upload_wait()
+    with pytest.raises(DsmError):  # nothing handed over to the back buffers since the last advance
+        ctx.advance_frames([dbl[0]], [0])
+
+
+def test_back_buffer_upload_leaves_the_front_untouched(ctx):
+    sc = make_scene("small", seed=28)
+    trk = hip_tracker(ctx, sc)
+    trk.upload_image(0, sc.new_img, 1.0)
+    other = (sc.new_img[::-1]).copy()
+    ctx.upload_images([trk], [2], [other])
+    _pyramids_equal(trk, 0, sc.new_p)
+    ctx.advance_frames([trk], [0])
+    _pyramids_equal(trk, 0, O.make_images(other, sc.nl))
+    ctx.advance_frames([], [])
