@@ -388,6 +388,8 @@ int dsm_tracker_destroy(dsm_tracker *t) {
   if (!t) return DSM_OK;
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
+  if (t->ctx->upload_stream) hipStreamSynchronize(t->ctx->upload_stream); // an asynchronous hand-over may still write its buffers
+  if (t->ctx->copy_stream) hipStreamSynchronize(t->ctx->copy_stream);
   for (int l = 0; l < t->nlevels; l++) {
     hipFree(t->d_pts[l]);
     hipFree(t->d_img[0][l]);
