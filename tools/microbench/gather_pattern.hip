@@ -174,9 +174,60 @@ __global__ __launch_bounds__(256) void k5(const fvec4 *__restrict__ pts, const f
   }
   if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
 }
+// modes 22-24: "span" form of the gathers -- the wave's 64 points land on consecutive texels of two rows, so each row is
+// fetched by ONE coalesced 16-byte-per-lane load (3 vector-memory instructions per point instead of 5) and the lanes pick
+// their 2 x 24 bytes out of a per-wave LDS block.  DEPTH points in flight, WORK x 8 dependent FMAs per point.
+template <int DEPTH, int WORK, int PAD>
+__global__ __launch_bounds__(256) void k6(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out) {
+  __shared__ __attribute__((aligned(16))) float span[4][2][272]; // [wave][row][68 lanes x 4 floats]
+  __shared__ float pad[PAD > 0 ? PAD : 1];
+  if (PAD > 0 && threadIdx.x == 300) pad[0] = 1.f;
+  float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const char *ib = (const char *)(img + (size_t)frame * npx_per_frame * 3);
+  float acc = 0.f;
+  fvec4 R[DEPTH][2];
+  fvec4 q[DEPTH + 1];
+  auto issue = [&](const fvec4 &pt, fvec4 *r) {
+    const unsigned b0 = 12u * (unsigned)__builtin_amdgcn_readfirstlane((int)pt.x); // lane 0's texel
+    const unsigned lo = (unsigned)lane < 49u ? 16u * (unsigned)lane : 768u;        // 65 texels = 780 bytes
+    r[0] = *(const fvec4 *)(ib + b0 + lo);
+    r[1] = *(const fvec4 *)(ib + b0 + 12u * (unsigned)w + lo);
+  };
+#pragma unroll
+  for (int d = 0; d <= DEPTH; d++) q[d] = __builtin_nontemporal_load(p + d * 256 + tid);
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) issue(q[d], R[d]);
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int inext = (kk + DEPTH + 1) * 256 + tid;
+    const fvec4 qn = __builtin_nontemporal_load(p + (inext < 4096 ? inext : tid));
+    fvec4 Rn[2];
+    issue(q[DEPTH], Rn);
+    // redistribute point k's rows through LDS: 16 bytes per lane in, 24 bytes per lane and row out
+    *(fvec4 *)&span[wave][0][4 * lane] = R[0][0];
+    *(fvec4 *)&span[wave][1][4 * lane] = R[0][1];
+    const fvec3u t00 = *(const fvec3u *)&span[wave][0][3 * lane], t10 = *(const fvec3u *)&span[wave][0][3 * lane + 3];
+    const fvec3u t01 = *(const fvec3u *)&span[wave][1][3 * lane], t11 = *(const fvec3u *)&span[wave][1][3 * lane + 3];
+    const float a0 = t00.x + t00.y + t00.z, a1 = t10.y + t10.x + t10.z, a2 = t01.z + t01.x + t01.y, a3 = t11.x + t11.y + t11.z; // all 12 floats
+    acc += (a0 + a1) + (a2 + a3) + q[0].w;
+#pragma unroll
+    for (int j = 0; j < WORK; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) c[e] = __builtin_fmaf(c[e], a0, a1 + (float)e);
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; d++) R[d][0] = R[d + 1][0], R[d][1] = R[d + 1][1];
+    R[DEPTH - 1][0] = Rn[0], R[DEPTH - 1][1] = Rn[1];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) q[d] = q[d + 1];
+    q[DEPTH] = qn;
+  }
+  if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
+}
 int main(int argc, char **argv) {
   const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = argc > 1 ? atoi(argv[1]) : 96;
-  const int mode_lo = argc > 2 ? atoi(argv[2]) : 0, mode_hi = argc > 3 ? atoi(argv[3]) : 21;
+  const int mode_lo = argc > 2 ? atoi(argv[2]) : 0, mode_hi = argc > 3 ? atoi(argv[3]) : 26;
   const int chunks = (npts - 4096) / 4096; // whole chunks only, rows stay inside the image
   fvec4 *pts; float *img, *out;
   hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
@@ -220,6 +271,11 @@ int main(int argc, char **argv) {
         if (mode == 19) hipLaunchKernelGGL((k5<4, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
         if (mode == 20) hipLaunchKernelGGL((k5<6, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
         if (mode == 21) hipLaunchKernelGGL((k5<2, 0, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out, pts_tab, img_tab);
+        if (mode == 22) hipLaunchKernelGGL((k6<1, 25, 7168>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 23) hipLaunchKernelGGL((k6<2, 25, 7168>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 24) hipLaunchKernelGGL((k6<3, 25, 7168>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 25) hipLaunchKernelGGL((k6<2, 25, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 26) hipLaunchKernelGGL((k6<2, 0, 0>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 6) hipLaunchKernelGGL((k3<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
       }
       hipEventRecord(b); hipEventSynchronize(b);
