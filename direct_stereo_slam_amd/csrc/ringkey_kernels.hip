@@ -264,7 +264,7 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
     else if (nq <= 4)
       DSM_FEWQ(4);
     else
-      DSM_FEWQ(8);
+      DSM_FEWQ(kRkQG);
 #undef DSM_FEWQ
   } else if (dim == 20)
     hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
