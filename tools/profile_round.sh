@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py > $OUT/bench_default.log 2>&1
 tail -1 $OUT/bench_default.log > $OUT/bench_default.json
 # 2. per-kernel statistics of the same command (no CPU leg: it only adds host time)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu --no-six-level > $OUT/trace.log 2>&1
 # 3. HBM traffic counters, one pass each (never combined with other trace domains)
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu --no-six-level --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu --no-six-level --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
 # 4. read-bandwidth ceilings and the single-frame latency line
 timeout 300 python $R/bench.py --membw > $OUT/membw.log 2>&1
 timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu > $OUT/bench_b1.log 2>&1

@@ -69,7 +69,7 @@ if trace:
     B = cfg["frames_in_flight_per_gpu"]
     bytes_eval = bench["roofline"]["bytes_per_launch"] * bench["roofline"]["launches"] / l0["evals"]
     summary = {
-        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu",
+        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu --no-six-level",
         "kernel": "dsm::" + L0,
         "dispatches": len(d), "dispatches_with_work": len(work),
         "avg_ns_dispatches_with_work": sum(work) / max(1, len(work)),
@@ -118,7 +118,7 @@ if fetch is not None:
     corrected = raw_fetch + 0.5 * n_evals * 16 * n0
     wr = (write or 0.0) * 1024.0
     out = {
-        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --steps 2 --warmup 1",
+        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-six-level --steps 2 --warmup 1",
         "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; tap gathers (12-byte texels) taken as reported",
