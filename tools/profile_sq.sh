@@ -1,0 +1,14 @@
+#!/bin/bash
+# Instruction mix and issue / wait split of the level-0 eval kernel:  bash tools/profile_sq.sh rNN   (through gpurun)
+# Three counter passes (never combined with other trace domains), summarised by tools/summarize_sq.py into profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/${TAG}_sq
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --no-cpu --no-six-level --batch 256 --steps 2 --warmup 1"
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/p1 -- $CMD > $OUT/p1.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/p2 -- $CMD > $OUT/p2.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/p3 -- $CMD > $OUT/p3.log 2>&1
+python $R/tools/summarize_sq.py $OUT $TAG
