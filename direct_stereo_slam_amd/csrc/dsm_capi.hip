@@ -182,15 +182,6 @@ static void se3_from_matrix(const double T[16], double pose[7]) {
   pose[6] = T[11];
 }
 
-static int default_layout() {
-  const char *e = getenv("DSM_IMG_LAYOUT");
-  if (e && !strcmp(e, "aos4")) return IMG_AOS4;
-  if (e && !strcmp(e, "aos3")) return IMG_AOS3;
-  return IMG_AOS3;
-}
-
-static int texel_floats(int layout) { return layout == IMG_AOS3 ? 3 : 4; }
-
 static int round8(int x) { return (x + 7) & ~7; }
 
 // record an event pair around a launch when timing is on
@@ -320,6 +311,9 @@ int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out) {
 void *dsm_context_stream(dsm_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 // ---- tracker ------------------------------------------------------------------------------
+static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
+                               const float K1[4], const dsm_params *params);
+
 int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
                        const float K1[4], const dsm_params *params, dsm_tracker **out) {
   if (!ctx || !out || !T_f1_f0 || !K1) return invalid("dsm_tracker_create: null argument");
@@ -329,6 +323,19 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
   if ((long long)w * h * 16 >= (1ll << 32)) return invalid("dsm_tracker_create: image too large");
   DSM_HIP(hipSetDevice(ctx->device));
   dsm_tracker *t = new dsm_tracker();
+  const int rc = tracker_create_fill(t, ctx, w, h, nlevels, T_f1_f0, K1, params);
+  if (rc != DSM_OK) { // e.g. out of device memory half way: give back what was allocated (hipFree(nullptr) is a no-op)
+    const std::string keep = g_err;
+    dsm_tracker_destroy(t);
+    g_err = keep;
+    return rc;
+  }
+  *out = t;
+  return DSM_OK;
+}
+
+static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
+                               const float K1[4], const dsm_params *params) {
   t->ctx = ctx;
   t->w = w;
   t->h = h;
@@ -340,7 +347,6 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
   TrackerDev &D = t->desc;
   memset(&D, 0, sizeof D);
   D.nlevels = nlevels;
-  D.layout = default_layout();
   D.p.huber_th = t->params.huber_th;
   D.p.coarse_cutoff_th = t->params.coarse_cutoff_th;
   D.p.scale_xi_rot = t->params.scale_xi_rot;
@@ -352,7 +358,7 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
   D.p.lambda_extrapolation_limit = t->params.lambda_extrapolation_limit;
   for (int l = 0; l < DSM_MAX_LEVELS; l++) D.p.max_iterations[l] = t->params.max_iterations[l];
   se3_from_matrix(T_f1_f0, D.T10);
-  const int ts = texel_floats(D.layout);
+  const int ts = kTexel;
   for (int l = 0; l < nlevels; l++) { // TrackerAndScaler.cpp:52-64
     const int wl = w >> l, hl = h >> l;
     D.lv[l].w = wl;
@@ -380,7 +386,6 @@ int dsm_tracker_create(dsm_context *ctx, int w, int h, int nlevels, const double
   }
   DSM_HIP(hipMalloc(&t->d_desc, sizeof(TrackerDev)));
   t->desc_dirty = true;
-  *out = t;
   return DSM_OK;
 }
 
@@ -467,9 +472,8 @@ int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, in
   if (!t || !frame_owner || slot < 0 || slot > 1 || npts < 0 || (npts > 0 && (!pu || !pv || !pidepth || !pweight)))
     return invalid("dsm_tracker_set_ref_from_points: bad argument");
   dsm_context *ctx = t->ctx;
-  if (frame_owner->ctx != ctx || frame_owner->w != t->w || frame_owner->h != t->h || frame_owner->nlevels != t->nlevels ||
-      frame_owner->desc.layout != t->desc.layout)
-    return invalid("dsm_tracker_set_ref_from_points: the frame owner must share context, size, levels and layout");
+  if (frame_owner->ctx != ctx || frame_owner->w != t->w || frame_owner->h != t->h || frame_owner->nlevels != t->nlevels)
+    return invalid("dsm_tracker_set_ref_from_points: the frame owner must share context, size and levels");
   if (!frame_owner->have_frame[slot]) {
     set_error("dsm_tracker_set_ref_from_points: the keyframe's pyramid has not been uploaded to that slot");
     return DSM_ERR_STATE;
@@ -490,7 +494,7 @@ int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, in
   int *d_n = (int *)(ws + floats - 64);
   const float *ref[DSM_MAX_LEVELS];
   for (int l = 0; l < t->nlevels; l++) ref[l] = frame_owner->d_img[slot][l];
-  launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, npts, ws, ref, t->desc.layout == IMG_AOS3 ? 3 : 4, t->d_pts, d_n);
+  launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, npts, ws, ref, kTexel, t->d_pts, d_n);
   DSM_HIP(hipGetLastError());
   int h_n[DSM_MAX_LEVELS + 1];
   DSM_HIP(hipMemcpyAsync(h_n, d_n, sizeof(int) * (t->nlevels + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -550,20 +554,9 @@ int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, 
   if (!t || !dIp || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_frame: bad argument");
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
-  const int layout = t->desc.layout;
-  if (layout != IMG_AOS3) {
-    int rc = ensure_stage(ctx, 3 * (size_t)t->w * t->h);
-    if (rc) return rc;
-  }
   for (int l = 0; l < t->nlevels; l++) {
     const size_t npx = (size_t)(t->w >> l) * (t->h >> l);
-    if (layout == IMG_AOS3) {
-      DSM_HIP(hipMemcpyAsync(t->d_img[slot][l], dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-      DSM_HIP(hipMemcpyAsync(ctx->d_stage, dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
-      launch_aos3_to_aos4(ctx->stream, (int)npx, ctx->d_stage, (float4 *)t->d_img[slot][l]);
-      DSM_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    DSM_HIP(hipMemcpyAsync(t->d_img[slot][l], dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
   }
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   t->desc.exposure[slot] = ab_exposure;
@@ -576,7 +569,6 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   if (!t || !image || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_image: bad argument");
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
-  const int layout = t->desc.layout;
   const size_t npx0 = (size_t)t->w * t->h;
   // the raw image is staged in a buffer of this tracker and slot, so that nothing but the host->device copy has to finish
   // before the call returns (the caller's buffer is free again); the pyramid kernels run on behind it.  With a pinned
@@ -584,7 +576,7 @@ int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float
   if (!t->d_raw[slot]) DSM_HIP(hipMalloc(&t->d_raw[slot], npx0 * sizeof(float)));
   DSM_HIP(hipMemcpyAsync(t->d_raw[slot], image, npx0 * 4, hipMemcpyHostToDevice, ctx->stream));
   DSM_HIP(hipEventRecord(ctx->copy_event, ctx->stream));
-  launch_pyramid(ctx->stream, t->w, t->h, t->nlevels, t->d_raw[slot], t->d_img[slot], layout);
+  launch_pyramid(ctx->stream, t->w, t->h, t->nlevels, t->d_raw[slot], t->d_img[slot]);
   DSM_HIP(hipGetLastError());
   DSM_HIP(hipEventSynchronize(ctx->copy_event));
   t->desc.exposure[slot] = ab_exposure;
@@ -599,7 +591,7 @@ static int upload_target(dsm_tracker *t, int slot, float **raw, float **img) {
   const size_t npx0 = (size_t)t->w * t->h;
   const int s = slot & 1;
   const bool back = slot >= 2;
-  const int ts = t->desc.layout == IMG_AOS3 ? 3 : 4;
+  const int ts = kTexel;
   if (back) {
     for (int l = 0; l < t->nlevels; l++)
       if (!t->d_img_back[s][l]) {
@@ -641,7 +633,7 @@ static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *track
     const dsm_tracker *t = trackers[i];
     if (!t || !images[i] || slots[i] < 0 || slots[i] > 3) return invalid("dsm_upload_images: bad entry");
     if (t->ctx != ctx) return invalid("dsm_upload_images: tracker of another context");
-    if (t->w != t0->w || t->h != t0->h || t->nlevels != t0->nlevels || t->desc.layout != t0->desc.layout)
+    if (t->w != t0->w || t->h != t0->h || t->nlevels != t0->nlevels)
       return invalid("dsm_upload_images: trackers of different geometry in one call");
     for (int j = 0; j < i; j++)
       if (trackers[j] == t && slots[j] == slots[i]) return invalid("dsm_upload_images: the same slot twice");
@@ -708,7 +700,7 @@ static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *track
     launch_host_rows_copy(work, ctx->d_pyr_jobs, n, (int)row, t0->h, pitch, unit, async ? ctx->async_copy_blocks : 1 << 20);
     DSM_HIP(hipGetLastError());
     DSM_HIP(hipEventRecord(async ? ctx->upload_copies_event : ctx->copy_event, work));
-    launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, t0->desc.layout, u8);
+    launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, u8);
     DSM_HIP(hipGetLastError());
     if (!async) DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
   } else {
@@ -735,7 +727,7 @@ static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *track
       }
       DSM_HIP(hipEventRecord(ctx->upload_events[g], ctx->copy_stream));
       DSM_HIP(hipStreamWaitEvent(work, ctx->upload_events[g], 0));
-      launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs + i0, i1 - i0, t0->desc.layout, u8);
+      launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs + i0, i1 - i0, u8);
       DSM_HIP(hipGetLastError());
     }
     if (async)
@@ -821,14 +813,7 @@ int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out) {
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
   const size_t npx = (size_t)(t->w >> lvl) * (t->h >> lvl);
-  if (t->desc.layout == IMG_AOS3) {
-    DSM_HIP(hipMemcpyAsync(dIp_out, t->d_img[slot][lvl], npx * 12, hipMemcpyDeviceToHost, ctx->stream));
-  } else {
-    int rc = ensure_stage(ctx, 3 * npx);
-    if (rc) return rc;
-    launch_aos4_to_aos3(ctx->stream, (int)npx, (const float4 *)t->d_img[slot][lvl], ctx->d_stage);
-    DSM_HIP(hipMemcpyAsync(dIp_out, ctx->d_stage, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  DSM_HIP(hipMemcpyAsync(dIp_out, t->d_img[slot][lvl], npx * 12, hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   return DSM_OK;
 }
@@ -861,8 +846,8 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
   for (int i = 0; i < n; i++) {
     dsm_tracker *t = ts[i];
     if (!t || t->ctx != ctx) return invalid("batch: tracker does not belong to this context");
-    if (t->w != ts[0]->w || t->h != ts[0]->h || t->nlevels != ts[0]->nlevels || t->desc.layout != ts[0]->desc.layout)
-      return invalid("batch: all trackers must share image size, levels and layout");
+    if (t->w != ts[0]->w || t->h != ts[0]->h || t->nlevels != ts[0]->nlevels)
+      return invalid("batch: all trackers must share image size and levels");
     int rc = check_ready(t, mode);
     if (rc) return rc;
     const int need = max_chunks_upto(t->w * t->h) * kPartialStride;
@@ -891,7 +876,6 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   const int nlevels = ts[0]->nlevels;
   if (coarsest < 0 || coarsest >= nlevels) return invalid("coarsest level out of range"); // :457 / :856
   const dsm_params &P = ts[0]->params;
-  const int layout = ts[0]->desc.layout;
   memset(&ctx->stats, 0, sizeof ctx->stats);
   DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
   DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -932,13 +916,13 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     if (ctx->queue_blocks[mode] == 0) {
       hipDeviceProp_t prop;
       DSM_HIP(hipGetDeviceProperties(&prop, ctx->device));
-      const int per_cu = queue_kernel_blocks_per_cu(mode, layout);
+      const int per_cu = queue_kernel_blocks_per_cu(mode);
       if (per_cu < 1) return invalid("work queue: kernel does not fit the device");
       ctx->queue_blocks[mode] = per_cu * prop.multiProcessorCount; // all workgroups must be co-resident
     }
     hipEvent_t qa = ctx->timing ? get_event(ctx, 0) : nullptr, qb = ctx->timing ? get_event(ctx, 1) : nullptr;
     if (qa) DSM_HIP(hipEventRecord(qa, ctx->stream));
-    launch_queue(ctx->stream, mode, layout, ctx->queue_blocks[mode], n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
+    launch_queue(ctx->stream, mode, ctx->queue_blocks[mode], n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
                  ctx->partial_stride, ctx->d_tickets, ctx->d_queue, ctx->d_qitems, (unsigned)(ctx->qcap - 1));
     if (qb) DSM_HIP(hipEventRecord(qb, ctx->stream));
     DSM_HIP(hipGetLastError());
@@ -981,7 +965,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     // Small levels: the whole LM loop in one launch per problem (coarse_kernel).  It hands a problem
     // back (still RUNNING) at the first level with more than coarse_max_points() template points.
     const int max_pts = P.persistent_coarse < coarse_max_points() ? P.persistent_coarse : coarse_max_points();
-    launch_coarse(ctx->stream, mode, layout, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_status, max_pts);
+    launch_coarse(ctx->stream, mode, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_status, max_pts);
     ctx->stats.coarse_launches = 1;
     top = -1;
     for (int L = coarsest; L >= 0 && top < 0; L--)
@@ -1018,7 +1002,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
           // levels >= 1: the eval kernel's last-arriving workgroup per problem performs the LM step itself
           // (measured: -6 % latency for one frame in flight, -11 % throughput at 256 -- hence the batch rule)
           const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n <= 8));
-          launch_eval(st, mode, layout, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
+          launch_eval(st, mode, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
                       ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride,
                       fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0);
           if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
@@ -1211,9 +1195,13 @@ int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const
   if (rc) return rc;
   // the loop-closure point set is the same on every level: give every level the level-0 capacity
   for (int l = 1; l < nlevels; l++) {
-    DSM_HIP(hipFree(t->d_pts[l]));
+    hipFree(t->d_pts[l]);
     t->d_pts[l] = nullptr;
-    DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)w * h));
+    const hipError_t e = hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)w * h);
+    if (e != hipSuccess) {
+      dsm_tracker_destroy(t);
+      DSM_HIP(e);
+    }
     t->pts_cap[l] = w * h;
     t->desc.lv[l].pts = t->d_pts[l];
   }
@@ -1308,7 +1296,7 @@ static int single_eval(dsm_tracker *t, int mode, int lvl, const double *pose, co
   DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo), hipMemcpyHostToDevice, ctx->stream));
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_PREP, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, nullptr);
-  launch_eval(ctx->stream, mode, t->desc.layout, lvl, round8(num_chunks(t->desc.lv[lvl].n) > 0 ? num_chunks(t->desc.lv[lvl].n) : 1), 1, ctx->d_tracker_ptrs,
+  launch_eval(ctx->stream, mode, lvl, round8(num_chunks(t->desc.lv[lvl].n) > 0 ? num_chunks(t->desc.lv[lvl].n) : 1), 1, ctx->d_tracker_ptrs,
               ctx->d_states, ctx->d_partials, ctx->partial_stride, nullptr, nullptr);
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_FINISH, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, nullptr, ctx->d_single, nullptr);

@@ -5,7 +5,7 @@
 //               global_load_dwordx4 per lane)           <- pc_u/pc_v/pc_idepth/pc_color SoA of the
 //               reference (TrackerAndScaler.h:90-94), interleaved at upload time
 //   target    : per level the reference's AoS (I,dx,dy) float3 texels (FrameHessian::dIp,
-//               TrackerAndScaler.cpp:709,1016) -- either as is (12 B) or padded to float4
+//               TrackerAndScaler.cpp:709,1016), 12 B per texel, row-major
 //   partials  : per problem, per chunk 64 floats (45 upper-triangular 9x9 sums, E, flow sums,
 //               integer counts)
 #pragma once
@@ -24,11 +24,11 @@ constexpr int kSlotE = 45, kSlotFlowT = 46, kSlotFlowRT = 47, kSlotFlowNum = 48;
 constexpr int kSlotNTerms = 49, kSlotNSat = 50, kSlotNWarped = 51;
 constexpr int kNumSlots = 52;
 
-enum ImgLayout { IMG_AOS3 = 0, IMG_AOS4 = 1 };
+constexpr int kTexel = 3;         // floats per target texel (I, dx, dy)
 
 struct LevelDev {
   const float4 *pts;   // n template points
-  const float *img[2]; // slot 0 = new left frame, slot 1 = right frame; layout per TrackerDev::layout
+  const float *img[2]; // slot 0 = new left frame, slot 1 = right frame; kTexel floats per texel
   int n, w, h, pad;
   float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
   float Ki[9];              // inverse of K at this level (float, :135-140)
@@ -48,7 +48,7 @@ struct alignas(16) TrackerDev {
   LevelDev lv[DSM_MAX_LEVELS];
   ParamsDev p;
   int nlevels;
-  int layout;
+  int pad0;
   double ref_a, ref_b; // lastRef_aff_g2l
   float ref_exposure;  // lastRef->ab_exposure
   float exposure[2];   // new_frame_->ab_exposure, fh1_->ab_exposure

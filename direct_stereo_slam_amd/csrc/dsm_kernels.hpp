@@ -44,7 +44,7 @@ struct StartInfo { // host -> device, one per problem
 };
 
 // mode: 0 = pose (calcResPose + calcGSSSEPose), 1 = scale (calcResScale + calcGSSSEScale)
-void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
+void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
                  int partial_stride, int *tickets, int *status_out);
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
@@ -60,12 +60,12 @@ struct WorkQueue {
   int error, pad3[31];     // a bounded wait expired
 };
 constexpr int kQueueChunkBits = 12;
-int queue_kernel_blocks_per_cu(int mode, int layout);
-void launch_queue(hipStream_t s, int mode, int layout, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
+int queue_kernel_blocks_per_cu(int mode);
+void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
                   float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask);
 
 // persistent LM loop of the small levels (levels with <= coarse_max_points() template points)
-void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const TrackerDev *const *trackers, LMState *states,
+void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_pts);
 int coarse_max_points();
 
@@ -79,10 +79,8 @@ void launch_interleave_template(hipStream_t s, int n, const float *u, const floa
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
                                   float *c);
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
-void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out);
-void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out);
-// makeImages (upstream DSO): level 0 from the float image, level l from level l-1; layout aware
-void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout);
+// makeImages (upstream DSO): level 0 from the float image, level l from level l-1
+void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img);
 // one image of a batched hand-over (dsm_upload_images): staged level-0 pixels (float or u8) and the pyramid levels
 struct PyrJob {
   const void *raw;
@@ -92,7 +90,7 @@ struct PyrJob {
 void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerDev *const *d_dst);
 // raw <- src for every job, rows of row_bytes at pitch `pitch` in src (tight in raw); unit: 16, 4 or 1 bytes per access
 void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit, int max_blocks);
-void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, int layout, bool u8);
+void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, bool u8);
 
 // ring-key kernels
 void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim,

@@ -2,6 +2,7 @@
 // LoopHandler.cpp:35-39 and the function-static delay queue of search_ringkey
 // (search_place.h:41-56).  Host code keeps the queue and the ordinal bookkeeping; the scan runs
 // in ringkey_kernels.hip.
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -38,11 +39,16 @@ static int rdb_reserve(dsm_ringdb *db, int64_t need_local) {
   while (ncap < need_local) ncap *= 2;
   float *nk = nullptr;
   DSM_HIP(hipMalloc(&nk, sizeof(float) * (size_t)ncap * db->dim));
+  hipError_t e = hipSuccess;
   if (db->d_keysT && db->n_local > 0)
-    for (int j = 0; j < db->dim; j++)
-      DSM_HIP(hipMemcpyAsync(nk + (size_t)j * ncap, db->d_keysT + (size_t)j * db->cap, sizeof(float) * db->n_local,
-                             hipMemcpyDeviceToDevice, db->ctx->stream));
-  DSM_HIP(hipStreamSynchronize(db->ctx->stream));
+    for (int j = 0; j < db->dim && e == hipSuccess; j++)
+      e = hipMemcpyAsync(nk + (size_t)j * ncap, db->d_keysT + (size_t)j * db->cap, sizeof(float) * db->n_local,
+                         hipMemcpyDeviceToDevice, db->ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(db->ctx->stream);
+  if (e != hipSuccess) { // the old planes stay valid; give the new allocation back
+    hipFree(nk);
+    DSM_HIP(e);
+  }
   if (db->d_keysT) DSM_HIP(hipFree(db->d_keysT));
   db->d_keysT = nk;
   db->cap = ncap;
@@ -60,6 +66,9 @@ static int rdb_stage(dsm_ringdb *db, size_t floats) {
 
 // append n keys with global ordinals size_global .. size_global+n-1; keep those of this shard
 static int rdb_append(dsm_ringdb *db, const float *keys, int64_t n) {
+  // candidates are packed (float_bits(d^2) << 32) | global index, and dsm_ringdb_query_then_enqueue hands indices out
+  // as int (search_place.h:36): the global index must stay below 2^31
+  if (db->size_global + n > (int64_t)INT32_MAX) return invalid("ring-key index full: global ordinals are limited to 2^31 - 1");
   std::vector<float> mine;
   mine.reserve((size_t)(n / db->shard_count + 1) * db->dim);
   for (int64_t i = 0; i < n; i++) {
@@ -103,6 +112,7 @@ static int rdb_knn_dev(dsm_ringdb *db, const float *d_queries, int nq, unsigned 
 }
 
 extern "C" {
+int dsm_ringdb_destroy(dsm_ringdb *db);
 
 int dsm_ringdb_create(dsm_context *ctx, int dim, int margin, int k, float thres, const float *dummy_key,
                       int64_t capacity, int shard_rank, int shard_count, dsm_ringdb **out) {
@@ -122,12 +132,18 @@ int dsm_ringdb_create(dsm_context *ctx, int dim, int margin, int k, float thres,
   db->shard_count = shard_count;
   db->queue.assign((size_t)margin * dim, 0.f);
   int rc = rdb_reserve(db, capacity > 16 ? capacity : 16);
-  if (rc) return rc;
+  if (rc) {
+    dsm_ringdb_destroy(db);
+    return rc;
+  }
   // index slot 0: the reference's dummy entry (LoopHandler.cpp:35-39, quirk Q8)
   std::vector<float> dummy(dim, 0.f);
   if (dummy_key) memcpy(dummy.data(), dummy_key, sizeof(float) * dim);
   rc = rdb_append(db, dummy.data(), 1);
-  if (rc) return rc;
+  if (rc) {
+    dsm_ringdb_destroy(db);
+    return rc;
+  }
   *out = db;
   return DSM_OK;
 }

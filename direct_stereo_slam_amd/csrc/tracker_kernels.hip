@@ -1,6 +1,6 @@
 // tracker_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the direct photometric hot path.
 //
-//   eval_kernel<MODE, LAYOUT>  fused calcResPose+calcGSSSEPose (TrackerAndScaler.cpp:699-852,
+//   eval_kernel<MODE, ...>    fused calcResPose+calcGSSSEPose (TrackerAndScaler.cpp:699-852,
 //                              640-697) or calcResScale+calcGSSSEScale (:1007-1172, :966-1005)
 //                              for a batch of independent problems: grid = (chunks, problems).
 //   lm_kernel                  per problem: fixed-order reduction of the chunk partials and one
@@ -18,21 +18,6 @@
 #include "dsm_kernels.hpp"
 #include "lm_math.hpp"
 
-// DSM_ABLATE: developer-only ablation switches for roofline diagnosis (never set in the shipped
-// build): 1 = drop the 45-entry accumulation, 2 = gather all taps from one texel, 4 = read all
-// template points from one address.
-#ifdef DSM_LM_PROFILE // developer-only: 100 MHz clock stamps of an LM step, printed by problem 0
-__shared__ unsigned long long lm_prof[16];
-#define LM_STAMP(i)                                                                                                    \
-  do {                                                                                                                 \
-    if (threadIdx.x == 0) lm_prof[i] = wall_clock64();                                                                 \
-  } while (0)
-#else
-#define LM_STAMP(i)
-#endif
-#ifndef DSM_ABLATE
-#define DSM_ABLATE 0
-#endif
 
 namespace dsm {
 
@@ -75,7 +60,6 @@ struct Taps {
   float dx, dy; // fractional position
 };
 
-template <int LAYOUT>
 __device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
   const int iy = (int)y;
@@ -83,27 +67,18 @@ __device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, 
   T.dx = __builtin_amdgcn_fractf(x);
   T.dy = __builtin_amdgcn_fractf(y);
   const unsigned base = (unsigned)(ix + iy * w);
-  if (LAYOUT == IMG_AOS3) {
-    // 32-bit byte offsets from the (scalar) image base: global_load with saddr + voffset, no
-    // 64-bit vector address arithmetic.  (Shift-add / 24-bit forms of these multiplies were measured: no gain.)
-    const unsigned off0 = 12u * base, off1 = off0 + 12u * (unsigned)w;
-    const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
-    const fvec3u a = *(const DSM_GLOBAL fvec3u *)(cb + off0);
-    const fvec3u b = *(const DSM_GLOBAL fvec3u *)(cb + off0 + 12u);
-    const fvec3u c = *(const DSM_GLOBAL fvec3u *)(cb + off1);
-    const fvec3u d = *(const DSM_GLOBAL fvec3u *)(cb + off1 + 12u);
-    T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
-    T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
-    T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
-    T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
-  } else {
-    const DSM_GLOBAL fvec4 *bp = (const DSM_GLOBAL fvec4 *)img + base;
-    const fvec4 a = bp[0], b = bp[1], c = bp[w], d = bp[w + 1];
-    T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
-    T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
-    T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
-    T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
-  }
+  // 32-bit byte offsets from the (scalar) image base: global_load with saddr + voffset, no
+  // 64-bit vector address arithmetic.  (Shift-add / 24-bit forms of these multiplies were measured: no gain.)
+  const unsigned off0 = 12u * base, off1 = off0 + 12u * (unsigned)w;
+  const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
+  const fvec3u a = *(const DSM_GLOBAL fvec3u *)(cb + off0);
+  const fvec3u b = *(const DSM_GLOBAL fvec3u *)(cb + off0 + 12u);
+  const fvec3u c = *(const DSM_GLOBAL fvec3u *)(cb + off1);
+  const fvec3u d = *(const DSM_GLOBAL fvec3u *)(cb + off1 + 12u);
+  T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
+  T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
+  T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
+  T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
 }
 
 // h0 (the intensity) decides in/out, Huber and cut-off: exact reference operation order.  h1/h2
@@ -144,6 +119,17 @@ struct EvalConsts {
 // different XCD and -- in the fused eval+LM kernel -- inside the same launch: written and read with
 // device-scope accesses (write-through / L2-coherent), so no cache-wide write-back or invalidate is
 // ever needed for them.
+//
+// Ordering between workgroups (arrival tickets, queue items): the producer's stores must be PERFORMED at device scope
+// before the device-scope atomic that announces them -- a release fence at AGENT scope (s_waitcnt vmcnt(0) + L2
+// write-back of anything not yet written through); a workgroup-scope fence emits neither and leaves the announcing
+// atomic free to overtake the stores.  The consumer pairs it with an agent-scope acquire after it has seen the
+// announcement.
+// Measured on MI355X (work-queue form, 256 dense frames): the pair costs nothing against the old workgroup-scope
+// fence (33.1 k vs 32.7-33.0 k frames/s) -- the release finds nothing to write back (partials, state and items are
+// written through), and the acquire's cache invalidate hits lines that are streamed once anyway.
+__device__ __forceinline__ void xwg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void xwg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 __device__ __forceinline__ void store_partial(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -161,7 +147,7 @@ __device__ __forceinline__ fvec4 load_partial4(const float *p) {
 // partial `out` (global memory in eval_kernel, LDS in coarse_kernel).  `red` is this thread group's
 // [16][kNumSlots] LDS scratch.  Contains two workgroup barriers: every thread of the workgroup must
 // call it; thread groups without a chunk pass active = false.
-template <int MODE, int LAYOUT, bool LVL0>
+template <int MODE, bool LVL0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                            float *out) {
   const int n = c.n;
@@ -244,10 +230,7 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       W.refColor = p.w;
       W.x = x, W.y = y, W.id = id;
       W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-      if (DSM_ABLATE & 2)
-        taps_load<LAYOUT>(img, W.inb ? 2.25f : 2.5f, W.inb ? 2.75f : 2.5f, wl, T);
-      else
-        taps_load<LAYOUT>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
+      taps_load(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
       float h0, h1, h2;
@@ -256,8 +239,10 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       const bool fin = W.inb && __builtin_isfinite(h0); // :791
       const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
       const float ar = __builtin_fabsf(residual);
-      // Huber weight (:794-795).  It scales E and the normal equations only (no decision depends
-      // on it), so the hardware reciprocal (1 ulp) replaces the IEEE division.
+      // Huber weight (:794-795).  It is off the per-point decision path (in/out, cut-off, Huber branch): it only
+      // scales this point's terms of E and of the normal equations -- sums that are compared to tolerance, E then
+      // entering the LM accept test like any other rounding of the sum -- so the hardware reciprocal (1 ulp)
+      // replaces the IEEE division.
       const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
       const bool sat = ar > cutoff;                    // :797
       const bool use = fin && !sat;
@@ -285,15 +270,9 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
         J[6] = keep(aff0 * (b0 - refColor));
         J[7] = -1.0f;
         J[8] = keep(residual);
-        if (DSM_ABLATE & 1) {
-          float t = 0;
-  #pragma unroll
-          for (int r = 0; r < 9; r++) t += J[r];
-          acc[0] = __builtin_fmaf(t, wgt, acc[0]);
-        }
         int idx = 0;
   #pragma unroll
-        for (int r = 0; r < ((DSM_ABLATE & 1) ? 0 : 9); r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
+        for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
           const float Jw = J[r] * wgt;
   #pragma unroll
           for (int c = r; c < 9; c++) {
@@ -324,7 +303,6 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
     {
       const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
       auto load_pt = [pb, n](int idx) {
-        if (DSM_ABLATE & 4) idx &= 255;
         // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
         return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)));
       };
@@ -807,9 +785,7 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, do
     a = __shfl(a, 8 * mr + mc, 64);
     y = __shfl(y, 8 * mr, 64);
   }
-  LM_STAMP(4);
   const double x = wave_ldlt_solve(a, y, active, lane);
-  LM_STAMP(5);
   // gather the 8 increments into every lane (row r's value sits in lanes 8r..8r+7)
   double inc[8];
 #pragma unroll
@@ -852,9 +828,7 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, do
     S.inc_norm = sqrt(nrm);
     S.phase = PH_ITER;
   }
-  LM_STAMP(6);
   make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0);
-  LM_STAMP(7);
 }
 
 // lane 0 only: :897-913
@@ -1094,10 +1068,6 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  LM_STAMP(4);
-  LM_STAMP(5);
-  LM_STAMP(6);
-  LM_STAMP(7);
   if (do_propose) {
     if (pose_like)
       propose_pose(T, S, h, bneg, lambda_next, lane);
@@ -1116,28 +1086,23 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
                                               const float *partials_prob, LmShared &sh, int tid, int *status_out) {
   constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
   static_assert(kS16 <= kThreads && kT16 <= kThreads, "one 16-byte block per thread");
-  LM_STAMP(0);
   // one round trip: state block, tracker descriptor and the chunk partials together
   uint4 sv = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
   if (tid < kS16) sv = COH ? load16_coherent((const uint4 *)&S + tid) : ((const uint4 *)&S)[tid];
   if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
   // the pending evaluation was built for this level
   const int n_lvl = COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
-  LM_STAMP(1);
   reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh);
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
   if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
   __syncthreads();
-  LM_STAMP(2);
   if (tid >= 64) return; // wave 0 carries on
   const int lane = tid;
   reduce_partials_final(lane, sh);
-  LM_STAMP(3);
   lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  LM_STAMP(8);
   if (COH) {
     for (int i = lane; i < kS16; i += 64) store16_coherent((uint4 *)&S + i, ((const uint4 *)&sh.st)[i]);
   } else {
@@ -1147,15 +1112,6 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
     status_out[2 * prob] = sh.st.status;
     status_out[2 * prob + 1] = sh.st.lvl;
   }
-#ifdef DSM_LM_PROFILE
-  __builtin_amdgcn_s_waitcnt(0);
-  LM_STAMP(9);
-  if (lane == 0 && prob == 0)
-    printf("LMPROF lvl %d: load %llu reduce %llu final %llu decide %llu ldlt %llu se3 %llu mkeval %llu end %llu out %llu (x10ns)\n", lvl,
-           lm_prof[1] - lm_prof[0], lm_prof[2] - lm_prof[1], lm_prof[3] - lm_prof[2], lm_prof[4] - lm_prof[3],
-           lm_prof[5] - lm_prof[4], lm_prof[6] - lm_prof[5], lm_prof[7] - lm_prof[6], lm_prof[8] - lm_prof[7],
-           lm_prof[9] - lm_prof[8]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1167,7 +1123,7 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
 // rewritten) also runs the LM step -- no separate lm_kernel launch for this evaluation.  The step
 // reads the same partials in the same order: results are bit-identical to the two-kernel form.
 // ------------------------------------------------------------------------------------------
-template <int MODE, int LAYOUT, bool LVL0, bool FUSED>
+template <int MODE, bool LVL0, bool FUSED>
 __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
@@ -1195,8 +1151,8 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
     __shared__ float red[16][kNumSlots];
-    eval_chunk<MODE, LAYOUT, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (size_t)chunk * kPartialStride);
-    if (FUSED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // partial stores performed before the ticket
+    eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (size_t)chunk * kPartialStride);
+    if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
   } else if (!FUSED) {
     return;
   }
@@ -1210,48 +1166,39 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     }
     __syncthreads();
     if (!last) return;
+    xwg_acquire(); // the other workgroups' partials were announced by their tickets
     __shared__ LmShared sh;
     lm_step_block(MODE, lvl, prob, trackers[prob], const_cast<LMState &>(states[prob]), partials_prob, sh, threadIdx.x,
                   status_out);
   }
 }
 
-template <int MODE, int LAYOUT>
+template <int MODE>
 static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
                            float *partials, int partial_stride, int *tickets, int *status_out) {
   if (tickets) { // fused LM step (never level 0: its kernel stays a pure evaluation)
-    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+    hipLaunchKernelGGL((eval_kernel<MODE, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out);
   } else if (lvl == 0)
-    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+    hipLaunchKernelGGL((eval_kernel<MODE, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out);
   else
-    hipLaunchKernelGGL((eval_kernel<MODE, LAYOUT, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+    hipLaunchKernelGGL((eval_kernel<MODE, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out);
 }
 
 // tickets != nullptr (levels >= 1 only): the kernel also performs the LM step (no lm_kernel launch needed)
-void launch_eval(hipStream_t s, int mode, int layout, int lvl, int grid_x, int nprob,
+void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
                  int partial_stride, int *tickets, int *status_out) {
   dim3 grid(grid_x, nprob);
   if (lvl == 0) tickets = nullptr;
-  if (mode == 0) {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<0, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-    else
-      launch_eval_ml<0, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-  } else if (mode == 2) {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<2, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-    else
-      launch_eval_ml<2, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-  } else {
-    if (layout == IMG_AOS3)
-      launch_eval_ml<1, IMG_AOS3>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-    else
-      launch_eval_ml<1, IMG_AOS4>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
-  }
+  if (mode == 0)
+    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+  else if (mode == 2)
+    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+  else
+    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
 }
 
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
@@ -1369,7 +1316,7 @@ constexpr int kCoarseGroups = kCoarseThreads / 256;
 constexpr int kCoarseMaxPts = 32768;
 constexpr int kCoarseMaxChunks = 32; // 32768 points / (256 threads * 4 points)
 
-template <int MODE, int LAYOUT>
+template <int MODE>
 __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev *const *__restrict__ trackers,
                                                                 LMState *__restrict__ states, int *__restrict__ status_out,
                                                                 int max_pts) {
@@ -1415,9 +1362,9 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
       const int chunk = c0 + vb;
       const bool active = chunk < nch;
       if (lvl == 0)
-        eval_chunk<MODE, LAYOUT, true>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
+        eval_chunk<MODE, true>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
       else
-        eval_chunk<MODE, LAYOUT, false>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
+        eval_chunk<MODE, false>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
       __syncthreads(); // red[] is reused by the next round
     }
     reduce_partials_groups(&part[0][0], nch, tid, sh);
@@ -1435,23 +1382,16 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
   }
 }
 
-void launch_coarse(hipStream_t s, int mode, int layout, int nprob, const TrackerDev *const *trackers, LMState *states,
+void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_pts) {
   if (max_pts > kCoarseMaxPts) max_pts = kCoarseMaxPts;
   dim3 grid(nprob), block(kCoarseThreads);
-#define DSM_COARSE(M)                                                                                                 \
-  if (layout == IMG_AOS3)                                                                                             \
-    hipLaunchKernelGGL((coarse_kernel<M, IMG_AOS3>), grid, block, 0, s, trackers, states, status_out, max_pts);             \
-  else                                                                                                                \
-    hipLaunchKernelGGL((coarse_kernel<M, IMG_AOS4>), grid, block, 0, s, trackers, states, status_out, max_pts);
-  if (mode == 0) {
-    DSM_COARSE(0)
-  } else if (mode == 1) {
-    DSM_COARSE(1)
-  } else {
-    DSM_COARSE(2)
-  }
-#undef DSM_COARSE
+  if (mode == 0)
+    hipLaunchKernelGGL((coarse_kernel<0>), grid, block, 0, s, trackers, states, status_out, max_pts);
+  else if (mode == 1)
+    hipLaunchKernelGGL((coarse_kernel<1>), grid, block, 0, s, trackers, states, status_out, max_pts);
+  else
+    hipLaunchKernelGGL((coarse_kernel<2>), grid, block, 0, s, trackers, states, status_out, max_pts);
 }
 int coarse_max_points() { return kCoarseMaxPts; }
 
@@ -1463,24 +1403,52 @@ int coarse_max_points() { return kCoarseMaxPts; }
 // problems' evaluations.  Same chunks, same partials, same reduction order as the launch-per-step path:
 // bit-identical results.  Everything one workgroup writes and another reads inside the launch (queue
 // items, partials, LMState, tickets) uses device-scope accesses; the XCD L2s are not mutually coherent.
-// All workgroups must be co-resident (the host sizes the grid from the occupancy query); waits are bounded
-// and raise q->error instead of hanging.
+// The grid is sized for co-residency (occupancy query) because that is what performs; correctness does not depend
+// on it: the queue is seeded by its own launch and a workgroup only ever waits for an item that some running
+// workgroup will publish.  One queue kernel per context at a time (the header and ring belong to the context).
+// Waits are bounded and raise q->error instead of hanging.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned q_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // whole wave: append `nitems` chunk items of problem `prob`.  The caller has made the problem's new state visible.
+// A ring slot is reused only after its previous item has been READ (the reader stores 0 into it): a workgroup that
+// is delayed between taking its ticket and reading its slot can therefore never find the slot overwritten, however
+// far the other problems have advanced meanwhile.
 __device__ __forceinline__ void queue_push(WorkQueue *q, unsigned long long *items, unsigned qmask, int prob, int nitems, int lane) {
   unsigned base = 0;
   if (lane == 0) base = atomicAdd(&q->tail, (unsigned)nitems);
   base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
   for (int i = lane; i < nitems; i += 64) {
     const unsigned idx = base + (unsigned)i;
-    __hip_atomic_store(&items[idx & qmask], ((unsigned long long)(idx + 1u) << 32) | ((unsigned)prob << kQueueChunkBits) | (unsigned)i,
+    unsigned long long *slot = &items[idx & qmask];
+    for (unsigned spins = 0; __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull; spins++) {
+      if (spins > (1u << 22)) { // never hang the GPU
+        __hip_atomic_store(&q->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_store(slot, ((unsigned long long)(idx + 1u) << 32) | ((unsigned)prob << kQueueChunkBits) | (unsigned)i,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-template <int MODE, int LAYOUT>
+// The first evaluation of every problem enters the queue in a launch of its own (one wave per problem, after
+// LM_OP_START): the persistent kernel's progress then never depends on which of its workgroups are resident.
+__global__ __launch_bounds__(256) void queue_seed_kernel(int mode, const LMState *__restrict__ states, WorkQueue *__restrict__ q,
+                                                         unsigned long long *__restrict__ items, unsigned qmask, int nprob) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= nprob) return;
+  const LMState &S0 = states[p];
+  if (S0.status == ST_RUNNING && S0.is_scale == mode) {
+    const int nch = num_chunks(S0.in.n);
+    queue_push(q, items, qmask, p, nch > 0 ? nch : 1, lane);
+  } else if (lane == 0) {
+    atomicAdd(&q->done, 1u);
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *const *__restrict__ trackers, LMState *__restrict__ states,
                                                          float *__restrict__ partials, int partial_stride, int *__restrict__ tickets,
                                                          WorkQueue *__restrict__ q, unsigned long long *__restrict__ items, unsigned qmask,
@@ -1490,18 +1458,6 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
   __shared__ __attribute__((aligned(16))) EvalIn s_in;
   __shared__ int s_ctl[4]; // problem (-1: leave), chunk, level, "last arrival" flag
   const int tid = threadIdx.x;
-
-  // seed: the first evaluation of every problem (LM_OP_START ran as its own launch before this kernel)
-  if (tid < 64)
-    for (int p = blockIdx.x; p < nprob; p += gridDim.x) {
-      const LMState &S0 = states[p];
-      if (S0.status == ST_RUNNING && S0.is_scale == MODE) {
-        const int nch = num_chunks(S0.in.n);
-        queue_push(q, items, qmask, p, nch > 0 ? nch : 1, tid);
-      } else if (tid == 0) {
-        atomicAdd(&q->done, 1u);
-      }
-    }
 
   constexpr int kIn16 = sizeof(EvalIn) / 16;
   static_assert(sizeof(EvalIn) % 16 == 0 && kIn16 < 63, "EvalIn is staged with 16-byte copies by wave 0");
@@ -1515,6 +1471,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
           const unsigned long long v = __hip_atomic_load(&items[t & qmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == t + 1u) {
             it = (unsigned)v;
+            __hip_atomic_store(&items[t & qmask], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // slot free again
             break;
           }
           if (q_load(&q->done) >= (unsigned)nprob || q_load((const unsigned *)&q->error)) break;
@@ -1527,6 +1484,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
       }
       it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
       if (it != 0xFFFFFFFFu) {
+        xwg_acquire(); // the item's publication tag announced the problem's new state
         const LMState &Sp = states[it >> kQueueChunkBits];
         if (tid < kIn16) ((uint4 *)&s_in)[tid] = load16_coherent((const uint4 *)&Sp.in + tid);
         if (tid == kIn16) s_ctl[2] = __hip_atomic_load(&Sp.lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1565,12 +1523,12 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
     float *partials_prob = partials + (size_t)prob * partial_stride;
     if (chunk < nch) {
       if (lvl == 0)
-        eval_chunk<MODE, LAYOUT, true>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
+        eval_chunk<MODE, true>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
       else
-        eval_chunk<MODE, LAYOUT, false>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
+        eval_chunk<MODE, false>(c, chunk, tid, true, red, partials_prob + (size_t)chunk * kPartialStride);
     }
     if (tid < 64) { // the chunk's partial was stored by threads of wave 0 only (eval_chunk's final sum)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // performed before the arrival ticket
+      xwg_release(); // the partial is performed at device scope before the arrival ticket
       if (tid == 0) {
         const int tk = atomicAdd(&tickets[prob], 1);
         const int last = tk == nitems - 1;
@@ -1580,9 +1538,10 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
     }
     __syncthreads();
     if (s_ctl[3]) { // workgroup-uniform: the problem's evaluation is complete -> its LM step, then its next evaluation
+      xwg_acquire(); // the other chunks' partials were announced by their tickets
       lm_step_block<true>(MODE, lvl, prob, trackers[prob], S, partials_prob, sh, tid, nullptr);
       if (tid < 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // new state (and the ticket reset) performed before the items appear
+        xwg_release(); // new state (and the ticket reset) performed at device scope before the items appear
         if (sh.st.status == ST_RUNNING) {
           const int nn = num_chunks(sh.st.in.n);
           queue_push(q, items, qmask, prob, nn > 0 ? nn : 1, tid);
@@ -1596,31 +1555,29 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
   }
 }
 
-int queue_kernel_blocks_per_cu(int mode, int layout) {
+int queue_kernel_blocks_per_cu(int mode) {
   int nb = 0;
-#define DSM_QOCC(M, L) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, queue_kernel<M, L>, kThreads, 0)
   if (mode == 0)
-    layout == IMG_AOS3 ? DSM_QOCC(0, IMG_AOS3) : DSM_QOCC(0, IMG_AOS4);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, queue_kernel<0>, kThreads, 0);
   else if (mode == 1)
-    layout == IMG_AOS3 ? DSM_QOCC(1, IMG_AOS3) : DSM_QOCC(1, IMG_AOS4);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, queue_kernel<1>, kThreads, 0);
   else
-    layout == IMG_AOS3 ? DSM_QOCC(2, IMG_AOS3) : DSM_QOCC(2, IMG_AOS4);
-#undef DSM_QOCC
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, queue_kernel<2>, kThreads, 0);
   return nb;
 }
 
-void launch_queue(hipStream_t s, int mode, int layout, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
+void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
                   float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask) {
-#define DSM_QL(M, L)                                                                                                  \
-  hipLaunchKernelGGL((queue_kernel<M, L>), dim3(nblocks), dim3(kThreads), 0, s, trackers, states, partials, partial_stride, tickets, \
+  hipLaunchKernelGGL(queue_seed_kernel, dim3((nprob + 3) / 4), dim3(256), 0, s, mode, states, q, items, qmask, nprob);
+#define DSM_QL(M)                                                                                                     \
+  hipLaunchKernelGGL((queue_kernel<M>), dim3(nblocks), dim3(kThreads), 0, s, trackers, states, partials, partial_stride, tickets, \
                      q, items, qmask, nprob)
-  if (mode == 0) {
-    if (layout == IMG_AOS3) DSM_QL(0, IMG_AOS3); else DSM_QL(0, IMG_AOS4);
-  } else if (mode == 1) {
-    if (layout == IMG_AOS3) DSM_QL(1, IMG_AOS3); else DSM_QL(1, IMG_AOS4);
-  } else {
-    if (layout == IMG_AOS3) DSM_QL(2, IMG_AOS3); else DSM_QL(2, IMG_AOS4);
-  }
+  if (mode == 0)
+    DSM_QL(0);
+  else if (mode == 1)
+    DSM_QL(1);
+  else
+    DSM_QL(2);
 #undef DSM_QL
 }
 
@@ -1654,19 +1611,6 @@ __global__ void deinterleave_kernel(int n, const float4 *__restrict__ in, float 
 __global__ void scale_depth_kernel(int n, float4 *pts, float scale) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pts[i].z = pts[i].z / scale;
 }
-__global__ void aos3_to_aos4_kernel(int npx, const float *__restrict__ in, float4 *__restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x)
-    out[i] = make_float4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0.f);
-}
-__global__ void aos4_to_aos3_kernel(int npx, const float4 *__restrict__ in, float *__restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const float4 p = in[i];
-    out[3 * i] = p.x;
-    out[3 * i + 1] = p.y;
-    out[3 * i + 2] = p.z;
-  }
-}
-
 static inline int grid_for(int n, int block = 256) {
   int g = (n + block - 1) / block;
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
@@ -1683,24 +1627,19 @@ void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float 
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale) {
   if (n > 0) hipLaunchKernelGGL(scale_depth_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, pts, scale);
 }
-void launch_aos3_to_aos4(hipStream_t s, int npx, const float *in, float4 *out) {
-  hipLaunchKernelGGL(aos3_to_aos4_kernel, dim3(grid_for(npx)), dim3(256), 0, s, npx, in, out);
-}
-void launch_aos4_to_aos3(hipStream_t s, int npx, const float4 *in, float *out) {
-  hipLaunchKernelGGL(aos4_to_aos3_kernel, dim3(grid_for(npx)), dim3(256), 0, s, npx, in, out);
-}
 
 // ------------------------------------------------------------------------------------------
 // makeImages (upstream DSO FrameHessian::makeImages; call sites FrontEnd.cpp:605,680)
-// texel stride TS = 3 (AOS3) or 4 (AOS4)
+// texels are the reference's AoS (I, dx, dy): stride kTexel = 3 floats
 // ------------------------------------------------------------------------------------------
 // One launch per pyramid level: gradients of level l (central differences on the flat index, borders zero -- upstream
 // DSO FrameHessian::makeImages) and the intensities of level l+1 (2x2 mean, 0.25 * (a + b + c + d)) both read
 // only the intensities of level l.  src: those intensities with element stride `ss` (1: the raw level-0 image,
-// TS: the I channel of out_l itself for l >= 1).
+// kTexel: the I channel of out_l itself for l >= 1).
 template <typename SRC>
 __device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__restrict__ src, int ss, float *__restrict__ out_l,
-                                               float *__restrict__ out_next, int TS, int first, int step) {
+                                               float *__restrict__ out_next, int first, int step) {
+  constexpr int TS = kTexel;
   const int npx = wl * hl, wn = wl >> 1, hn = hl >> 1;
   const int lo = wl, hi = wl * (hl - 1);
   for (int idx = first; idx < npx; idx += step) {
@@ -1713,7 +1652,6 @@ __device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__rest
     }
     if (ss == 1) {
       out_l[TS * idx] = (float)src[idx];
-      if (TS == 4) out_l[TS * idx + 3] = 0.f;
     }
     out_l[TS * idx + 1] = dx;
     out_l[TS * idx + 2] = dy;
@@ -1722,29 +1660,28 @@ __device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__rest
       const int b = 2 * x + 2 * y * wl;
       out_next[TS * idx] =
           0.25f * ((float)src[ss * b] + (float)src[ss * (b + 1)] + (float)src[ss * (b + wl)] + (float)src[ss * (b + 1 + wl)]);
-      if (TS == 4) out_next[TS * idx + 3] = 0.f;
     }
   }
 }
 __global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, int ss, float *__restrict__ out_l,
-                                       float *__restrict__ out_next, int TS) {
-  pyr_level_body<float>(wl, hl, src, ss, out_l, out_next, TS, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+                                       float *__restrict__ out_next) {
+  pyr_level_body<float>(wl, hl, src, ss, out_l, out_next, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 // the same for a batch of images (dsm_upload_images): blockIdx.y = image; U8: the level-0 source holds camera bytes
 // (main.cpp:216-217 "mono8"), converted exactly
 template <bool U8>
-__global__ void pyr_level_batched_kernel(int l, int nlevels, int wl, int hl, const PyrJob *__restrict__ jobs, int TS) {
+__global__ void pyr_level_batched_kernel(int l, int nlevels, int wl, int hl, const PyrJob *__restrict__ jobs) {
   const PyrJob &j = jobs[blockIdx.y];
   float *out_l = j.img[l];
   float *out_next = l + 1 < nlevels ? j.img[l + 1] : nullptr;
   const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
   if (l == 0) {
     if (U8)
-      pyr_level_body<unsigned char>(wl, hl, (const unsigned char *)j.raw, 1, out_l, out_next, TS, first, step);
+      pyr_level_body<unsigned char>(wl, hl, (const unsigned char *)j.raw, 1, out_l, out_next, first, step);
     else
-      pyr_level_body<float>(wl, hl, (const float *)j.raw, 1, out_l, out_next, TS, first, step);
+      pyr_level_body<float>(wl, hl, (const float *)j.raw, 1, out_l, out_next, first, step);
   } else {
-    pyr_level_body<float>(wl, hl, out_l, TS, out_l, out_next, TS, first, step);
+    pyr_level_body<float>(wl, hl, out_l, kTexel, out_l, out_next, first, step);
   }
 }
 // descriptors of many trackers in one copy + one launch (after a batched hand-over every tracker's exposure changed)
@@ -1784,23 +1721,21 @@ void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int r
     hipLaunchKernelGGL(host_rows_copy_kernel<unsigned char>, grid, dim3(256), 0, s, d_jobs, njobs, row_units, rows, pitch);
 }
 // raw: the level-0 float image; img[l]: the AoS pyramid levels
-void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img, int layout) {
-  const int TS = layout == IMG_AOS3 ? 3 : 4;
+void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img) {
   for (int l = 0; l < nlevels; l++) {
     const int wl = w >> l, hl = h >> l;
-    hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, l == 0 ? raw : img[l], l == 0 ? 1 : TS, img[l],
-                       l + 1 < nlevels ? img[l + 1] : nullptr, TS);
+    hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, l == 0 ? raw : img[l], l == 0 ? 1 : kTexel, img[l],
+                       l + 1 < nlevels ? img[l + 1] : nullptr);
   }
 }
-void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, int layout, bool u8) {
-  const int TS = layout == IMG_AOS3 ? 3 : 4;
+void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, bool u8) {
   for (int l = 0; l < nlevels; l++) {
     const int wl = w >> l, hl = h >> l;
     const dim3 grid(grid_for(wl * hl), njobs);
     if (u8)
-      hipLaunchKernelGGL(pyr_level_batched_kernel<true>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs, TS);
+      hipLaunchKernelGGL(pyr_level_batched_kernel<true>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs);
     else
-      hipLaunchKernelGGL(pyr_level_batched_kernel<false>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs, TS);
+      hipLaunchKernelGGL(pyr_level_batched_kernel<false>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs);
   }
 }
 
