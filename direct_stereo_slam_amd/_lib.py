@@ -61,6 +61,10 @@ _vp = C.c_void_p
 _pp_f = C.POINTER(c_float_p)
 _pp_i = C.POINTER(c_int_p)
 _pp_d = C.POINTER(c_double_p)
+# transports of dsm_ringdb_merge_topk_with: (user, d_buf, count, hip_stream) / (user, d_send, d_recv, count, hip_stream)
+ALLREDUCE_MIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+MERGE_ALGOS = {"allreduce_min": 0, "allgather": 1}
 SYMBOLS = {
     "dsm_last_error": (C.c_char_p, []),
     "dsm_abi_version": (C.c_int, []),
@@ -110,6 +114,14 @@ SYMBOLS = {
     "dsm_ringdb_knn_packed": (C.c_int, [_vp, c_float_p, C.c_int, _vp]),
     "dsm_ringdb_knn_packed_dev": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "dsm_ringdb_knn_packed_host": (C.c_int, [_vp, c_float_p, C.c_int, c_int64_p]),
+    "dsm_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "dsm_comm_create": (C.c_int, [_vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dsm_comm_destroy": (C.c_int, [_vp]),
+    "dsm_comm_rank": (C.c_int, [_vp]),
+    "dsm_comm_size": (C.c_int, [_vp]),
+    "dsm_ringdb_merge_topk": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    "dsm_ringdb_merge_topk_with": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, ALLREDUCE_MIN_FN, ALLGATHER_FN, _vp]),
+    "dsm_ringdb_attach_comm": (C.c_int, [_vp, _vp]),
     "dsm_scancontext_generate": (C.c_int, [c_double_p, C.c_int, C.c_double, C.c_int, C.c_int, c_float_p, c_int_p, c_double_p, c_int_p, c_double_p]),
     "dsm_generate_spherical_points": (C.c_int, [C.c_int, c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p]),
     "dsm_make_coarse_depth_l0": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, _pp_f, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),

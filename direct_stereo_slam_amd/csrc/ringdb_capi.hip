@@ -7,26 +7,9 @@
 #include <vector>
 
 #include "dsm_internal.hpp"
+#include "ringdb_internal.hpp"
 
 using namespace dsm;
-
-struct dsm_ringdb {
-  dsm_context *ctx = nullptr;
-  int dim = 20, margin = 100, k = 3;
-  float thres = 0.1f;
-  int shard_rank = 0, shard_count = 1;
-  int64_t size_global = 0; // entries in the (global) index, dummy included
-  int64_t n_local = 0, cap = 0;
-  float *d_keysT = nullptr;
-  std::vector<float> queue; // margin x dim ring buffer (search_place.h:43-45)
-  int64_t queue_idx = 0;
-  float *d_q = nullptr; // query / insert staging
-  size_t q_floats = 0;
-  unsigned long long *d_scratch = nullptr;
-  size_t scratch_words = 0;
-  unsigned long long *d_out = nullptr;
-  size_t out_words = 0;
-};
 
 static int invalid(const char *m) {
   set_error(m);
@@ -156,6 +139,7 @@ int dsm_ringdb_destroy(dsm_ringdb *db) {
   hipFree(db->d_q);
   hipFree(db->d_scratch);
   hipFree(db->d_out);
+  hipFree(db->d_merge);
   delete db;
   return DSM_OK;
 }
@@ -217,15 +201,40 @@ int dsm_ringdb_knn_packed_host(dsm_ringdb *db, const float *queries, int nq, int
 
 int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_out, int *ncand_out) {
   if (!db || !key || !cand_out || !ncand_out) return invalid("dsm_ringdb_query_then_enqueue: bad argument");
-  if (db->shard_count != 1) {
-    set_error("dsm_ringdb_query_then_enqueue needs an unsharded DB; sharded callers use knn_packed + enqueue");
+  // Sharded handle: a COLLECTIVE call -- every rank passes the same key, scans its shard, the candidates are merged
+  // through the attached communicator (RCCL all-reduce(min)), and every rank returns the same candidate list and
+  // enqueues the key (each shard keeps the ordinals that are its own).
+  if (db->shard_count != 1 && !db->comm) {
+    set_error("dsm_ringdb_query_then_enqueue on a sharded DB needs a communicator (dsm_ringdb_attach_comm); "
+              "without one use knn_packed + your own merge + enqueue");
     return DSM_ERR_STATE;
   }
   int nc = 0;
   if (db->size_global > db->k) { // `ringkeys->size() > FLANN_NN`, search_place.h:29
     int64_t packed[4];
-    int rc = dsm_ringdb_knn_packed_host(db, key, 1, packed);
-    if (rc) return rc;
+    int rc;
+    if (db->shard_count == 1) {
+      rc = dsm_ringdb_knn_packed_host(db, key, 1, packed);
+      if (rc) return rc;
+    } else {
+      DSM_HIP(hipSetDevice(db->ctx->device));
+      if ((size_t)db->k > db->out_words) {
+        if (db->d_out) DSM_HIP(hipFree(db->d_out));
+        db->d_out = nullptr;
+        db->out_words = 0;
+        DSM_HIP(hipMalloc(&db->d_out, 4 * sizeof(unsigned long long)));
+        db->out_words = 4;
+      }
+      rc = rdb_stage(db, (size_t)db->dim);
+      if (rc) return rc;
+      DSM_HIP(hipMemcpyAsync(db->d_q, key, sizeof(float) * db->dim, hipMemcpyHostToDevice, db->ctx->stream));
+      rc = rdb_knn_dev(db, db->d_q, 1, db->d_out);
+      if (rc) return rc;
+      rc = ringdb_merge_attached(db, db->d_out, 1);
+      if (rc) return rc;
+      DSM_HIP(hipMemcpyAsync(packed, db->d_out, sizeof(unsigned long long) * db->k, hipMemcpyDeviceToHost, db->ctx->stream));
+      DSM_HIP(hipStreamSynchronize(db->ctx->stream));
+    }
     for (int i = 0; i < db->k; i++) {
       if (packed[i] == DSM_RINGDB_NO_CANDIDATE) continue; // dist >= RINGKEY_THRES was filtered on the device
       const int idx = (int)(packed[i] & 0xFFFFFFFFll);

@@ -1,17 +1,20 @@
 """Ring-key database: host mirror of `search_ringkey` (src/loop_closure/loop_detection/search_place.h:25-57)
 on the C ABI, plus the cross-GPU merge for the sharded DB.
 
-The device scan lives in csrc/ringkey_kernels.hip.  `merge_topk_allreduce_min` is the only
-collective on the whole hot path: k rounds of an element-wise all-reduce(min) over packed
-(dist2 << 32 | global index) int64 candidates with winner pop -- RCCL on GPUs (backend "nccl"),
-gloo in the CPU tests.  A slot-wise min of sorted triples would NOT be a correct top-k.
+The device scan lives in csrc/ringkey_kernels.hip, the cross-shard merge -- the only collective on the whole hot
+path -- in csrc/comm_capi.hip behind the C ABI: `Comm` wraps dsm_comm (RCCL, loaded by the library itself) and
+`RingKeyDB.merge_topk_device` calls dsm_ringdb_merge_topk: k rounds of all-reduce(min) over packed
+(dist2 << 32 | global index) candidates with winner pop, or one all-gather + local merge.  A slot-wise min of sorted
+triples would NOT be a correct top-k.  `merge_topk_allreduce_min` is the same algorithm on torch tensors, kept for hosts
+without a GPU (the gloo plumbing test); `RingKeyDB.merge_topk_with` runs the C ABI's merge kernels over a caller-supplied
+transport (threads or gloo processes sharing one GPU in the tests).
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
-from ._lib import NO_CANDIDATE, c_float_p, c_int64_p, c_int_p, check
+from ._lib import ALLGATHER_FN, ALLREDUCE_MIN_FN, MERGE_ALGOS, NO_CANDIDATE, c_float_p, c_int64_p, c_int_p, check
 
 
 def _fp(a):
@@ -60,6 +63,31 @@ def merge_topk_allreduce_min(local_sorted, k, all_reduce_min):
     return out
 
 
+class Comm:
+    """dsm_comm: one rank per GPU over RCCL.  rank 0 calls Comm.unique_id() and hands the 128 bytes to every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        check(_lib.load().dsm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, unique_id, rank, nranks):
+        self.ctx, self.L = ctx, ctx.L
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        check(self.L.dsm_comm_create(ctx.h, buf, rank, nranks, C.byref(h)))
+        self.h, self.rank, self.nranks = h, rank, nranks
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.L.dsm_comm_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class RingKeyDB:
     """flann::Index replacement + delay queue.  shard_rank/shard_count: this handle stores only the
     global ordinals with ordinal % shard_count == shard_rank."""
@@ -92,8 +120,45 @@ class RingKeyDB:
         key = np.ascontiguousarray(key, np.float32)
         check(self.L.dsm_ringdb_enqueue(self.h, _fp(key)))
 
+    def attach_comm(self, comm):
+        """sharded handle: search_ringkey becomes a collective over `comm` (None detaches)"""
+        check(self.L.dsm_ringdb_attach_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
+
+    def merge_topk_device(self, comm, d_packed_ptr, nq, algo="allreduce_min"):
+        """cross-shard merge of the nq x k packed candidates at the raw device pointer, in place (dsm_ringdb_merge_topk);
+        asynchronous on the context stream"""
+        check(self.L.dsm_ringdb_merge_topk(self.h, comm.h, C.c_void_p(d_packed_ptr), nq, MERGE_ALGOS[algo]))
+
+    def merge_topk_with(self, d_packed_ptr, nq, nranks, allreduce_min=None, allgather=None, algo="allreduce_min"):
+        """the same merge kernels over a caller-supplied transport: allreduce_min(d_buf_ptr, count, stream_ptr) /
+        allgather(d_send_ptr, d_recv_ptr, count, stream_ptr) act on device buffers of unsigned 64-bit words"""
+        def _ar(user, buf, count, stream):
+            try:
+                allreduce_min(buf, count, stream)
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the C ABI's return code
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        def _ag(user, send, recv, count, stream):
+            try:
+                allgather(send, recv, count, stream)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        far = ALLREDUCE_MIN_FN(_ar) if allreduce_min else C.cast(None, ALLREDUCE_MIN_FN)
+        fag = ALLGATHER_FN(_ag) if allgather else C.cast(None, ALLGATHER_FN)
+        check(self.L.dsm_ringdb_merge_topk_with(self.h, C.c_void_p(d_packed_ptr), nq, MERGE_ALGOS[algo], nranks, far, fag, None))
+
     def search_ringkey(self, key):
-        """search_place.h:25-57 for an unsharded DB: returns the candidate list"""
+        """search_place.h:25-57: returns the candidate list (a collective call on a sharded handle with a communicator)"""
         key = np.ascontiguousarray(key, np.float32)
         cand = (C.c_int * self.k)()
         nc = C.c_int()

@@ -48,6 +48,7 @@ typedef enum dsm_status {
 typedef struct dsm_context dsm_context; /* device + stream + workspaces */
 typedef struct dsm_tracker dsm_tracker; /* one TrackerAndScaler instance */
 typedef struct dsm_ringdb dsm_ringdb;   /* ring-key database + delay queue */
+typedef struct dsm_comm dsm_comm;       /* communicator of the sharded ring-key database: one rank per GPU (RCCL) */
 typedef struct dsm_pose_estimator dsm_pose_estimator; /* loop-closure direct alignment (PoseEstimator) */
 
 /* Runtime parameters.  These are DSO globals / literals in the reference; the values
@@ -261,7 +262,10 @@ int dsm_ringdb_destroy(dsm_ringdb *db);
 /* number of entries in the (global) index, dummy included (flann Index::size()) */
 int64_t dsm_ringdb_size(dsm_ringdb *db);
 /* replaces search_ringkey (search_place.h:25-57): query, threshold, then delay-queue insert.
- * cand_out[k] receives 0..k candidate ordinals (index-1) in ascending-distance order. */
+ * cand_out[k] receives 0..k candidate ordinals (index-1) in ascending-distance order.
+ * On a sharded handle this is a COLLECTIVE call (the call site LoopHandler.cpp:247 runs once per rank with the same
+ * key): needs dsm_ringdb_attach_comm; every rank scans its shard, the candidates are merged by RCCL all-reduce(min)
+ * and every rank returns the same list.  Without a communicator a sharded handle fails with DSM_ERR_STATE. */
 int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_out, int *ncand_out);
 /* bulk insert (bench / sharded DB): n_keys keys appended directly to the index */
 int dsm_ringdb_add_points(dsm_ringdb *db, const float *keys, int64_t n_keys);
@@ -271,14 +275,43 @@ int dsm_ringdb_enqueue(dsm_ringdb *db, const float *key);
 /* batched exact k-NN over this shard: for each of nq queries (host pointer, nq x dim) writes k packed
  * candidates  (int64 = float_bits(dist2) << 32 | global index), ascending, into the DEVICE buffer
  * d_packed_out (nq*k int64).  Only entries with dist2 < thres are candidates; empty slots hold
- * DSM_RINGDB_NO_CANDIDATE.  The cross-shard merge is k rounds of an element-wise min over ranks
- * (RCCL all-reduce(min)) with winner pop, see direct_stereo_slam_amd/ringdb.py. */
+ * DSM_RINGDB_NO_CANDIDATE.  The cross-shard merge is dsm_ringdb_merge_topk below. */
 #define DSM_RINGDB_NO_CANDIDATE 0x7FFFFFFFFFFFFFFFll
 int dsm_ringdb_knn_packed(dsm_ringdb *db, const float *queries, int nq, void *d_packed_out);
 /* same, queries already on the device (nq x dim float32) */
 int dsm_ringdb_knn_packed_dev(dsm_ringdb *db, const void *d_queries, int nq, void *d_packed_out);
 /* same, result copied to host memory (nq*k int64) */
 int dsm_ringdb_knn_packed_host(dsm_ringdb *db, const float *queries, int nq, int64_t *packed_out);
+
+/* ---- sharded ring-key database across the GPUs of a node -------- */
+/* The index of LoopHandler.cpp:35-39 split `ordinal mod G` over G processes (one per GPU); search_ringkey's k-NN
+ * (search_place.h:29-33) becomes a local scan per shard + a cross-shard merge of the packed candidates over xGMI.
+ * The communicator wraps an RCCL communicator (librccl.so.1 is loaded at run time, on first use):
+ *   rank 0: dsm_comm_unique_id(id) -> the host distributes the 128 bytes to all ranks (its launcher's business: MPI,
+ *   a file, a socket; bench.py uses torch.distributed) -> every rank: dsm_comm_create(ctx, id, rank, nranks, &comm). */
+#define DSM_COMM_ID_BYTES 128
+int dsm_comm_unique_id(unsigned char id_out[DSM_COMM_ID_BYTES]);
+int dsm_comm_create(dsm_context *ctx, const unsigned char id[DSM_COMM_ID_BYTES], int rank, int nranks, dsm_comm **out);
+int dsm_comm_destroy(dsm_comm *comm);
+int dsm_comm_rank(dsm_comm *comm);
+int dsm_comm_size(dsm_comm *comm);
+/* Cross-shard merge, collective over the communicator: d_packed (DEVICE, nq*k int64) holds this rank's sorted local
+ * candidates (dsm_ringdb_knn_packed*) on entry and the global top-k (identical on every rank, ascending) on return.
+ * Enqueued on the context's stream; synchronise the context before reading the buffer from the host.
+ * algo: DSM_MERGE_ALLREDUCE_MIN = k rounds of ncclAllReduce(ncclMin, ncclUint64) with winner pop (8*nq bytes per round);
+ *       DSM_MERGE_ALLGATHER     = one ncclAllGather of every rank's nq*k candidates + local k-way merge.  Same result. */
+enum { DSM_MERGE_ALLREDUCE_MIN = 0, DSM_MERGE_ALLGATHER = 1 };
+int dsm_ringdb_merge_topk(dsm_ringdb *db, dsm_comm *comm, void *d_packed, int nq, int algo);
+/* the same merge over a caller-supplied transport (hosts that do not use RCCL; tests that run the ranks as threads or
+ * gloo processes): the callbacks run the collective on DEVICE buffers, in order, on `hip_stream`, and return 0 on success.
+ * allreduce_min: element-wise unsigned 64-bit min over the ranks, in place.  allgather: recv[r*count .. ] = rank r's send. */
+typedef int (*dsm_allreduce_min_u64_fn)(void *user, void *d_buf, size_t count, void *hip_stream);
+typedef int (*dsm_allgather_u64_fn)(void *user, const void *d_send, void *d_recv, size_t count, void *hip_stream);
+int dsm_ringdb_merge_topk_with(dsm_ringdb *db, void *d_packed, int nq, int algo, int nranks,
+                               dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather, void *user);
+/* attach (or, with NULL, detach) the communicator dsm_ringdb_query_then_enqueue uses on a sharded handle; borrowed:
+ * destroy the database or detach before destroying the communicator */
+int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm);
 
 /* replaces ScanContext::generate (src/loop_closure/loop_detection/ScanContext.cpp:78-141, with
  * align_points_PCA :19-66).  Host side by design: a few 10^3 points per

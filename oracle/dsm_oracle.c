@@ -9,7 +9,7 @@
  * "UPSTREAM" marks arithmetic that lives in un-vendored dependencies (DSO, Sophus, Eigen,
  * FLANN); it is restated from the published algorithm and the reference's call sites.
  */
-#include "dsm_oracle.h"
+#include "dsm_oracle_internal.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -308,8 +308,7 @@ static void mat3f_mul(const float *a, const float *b, float *o) {
 }
 
 /* AffLight::fromToVecExposure (UPSTREAM DSO util/NumType.h), call sites :647-649,:717-720 */
-static void aff_from_to(float expF, float expT, double g2F_a, double g2F_b, double g2T_a,
-                        double g2T_b, double out[2]) {
+void orc_aff_from_to(float expF, float expT, double g2F_a, double g2F_b, double g2T_a, double g2T_b, double out[2]) {
   if (expF == 0 || expT == 0) expT = expF = 1;
   const double a = exp(g2T_a - g2F_a) * expT / expF;
   const double b = g2T_b - a * g2F_b;
@@ -333,34 +332,6 @@ static inline void interp33(const float *mat, float x, float y, int width, float
 /* ------------------------------------------------------------------------------------ */
 /* tracker state                                                                         */
 /* ------------------------------------------------------------------------------------ */
-struct orc_tracker {
-  orc_params p;
-  int nlevels;
-  int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
-  float fx[ORC_MAX_LEVELS], fy[ORC_MAX_LEVELS], cx[ORC_MAX_LEVELS], cy[ORC_MAX_LEVELS];
-  float Ki[ORC_MAX_LEVELS][9];
-  float fx1[ORC_MAX_LEVELS], fy1[ORC_MAX_LEVELS], cx1[ORC_MAX_LEVELS], cy1[ORC_MAX_LEVELS];
-  double T10[7]; /* tfm_f1_f0_ */
-  /* template */
-  float *pc_u[ORC_MAX_LEVELS], *pc_v[ORC_MAX_LEVELS], *pc_id[ORC_MAX_LEVELS], *pc_c[ORC_MAX_LEVELS];
-  int pc_n[ORC_MAX_LEVELS];
-  float *idepth[ORC_MAX_LEVELS], *wsum[ORC_MAX_LEVELS], *wsum_bak[ORC_MAX_LEVELS];
-  int ref_id;
-  double ref_a, ref_b;
-  float ref_exposure;
-  /* frames (borrowed) */
-  const float *dIp[2][ORC_MAX_LEVELS];
-  float exposure[2];
-  /* warped buffers: pose (idepth,u,v,dx,dy,residual,weight,refColor) */
-  float *pb[8];
-  int pb_n;
-  /* scale (rx1,rx2,rx3,dx,dy,residual,weight,refColor) */
-  float *sb[8];
-  int sb_n;
-  int64_t res_evals[ORC_MAX_LEVELS], gs_evals[ORC_MAX_LEVELS];
-  double last_E_f64; /* the same per-point float terms summed in double (test aid, see orc_last_energy_f64) */
-};
-
 orc_tracker *orc_tracker_create(int ww, int hh, int nlevels, const double T[16], const float K1[4],
                                 const orc_params *p) {
   orc_tracker *t = (orc_tracker *)xcalloc(1, sizeof *t);
@@ -470,6 +441,7 @@ void orc_tracker_set_frame(orc_tracker *t, int slot, const float *const *dIp, fl
   t->exposure[slot] = ab_exposure;
 }
 
+void orc_tracker_use_sse(orc_tracker *t, int on) { t->use_sse = on; }
 int orc_pose_warped_n(orc_tracker *t) { return t->pb_n; }
 double orc_last_energy_f64(orc_tracker *t) { return t->last_E_f64; }
 int orc_scale_warped_n(orc_tracker *t) { return t->sb_n; }
@@ -497,7 +469,7 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
   mat3f_mul(Rf, Ki, RKi);                                                     /* :715 */
   const float tt[3] = {(float)pose[4], (float)pose[5], (float)pose[6]};       /* :716 */
   double affd[2];
-  aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff[0], aff[1], affd); /* :717-720 */
+  orc_aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff[0], aff[1], affd); /* :717-720 */
   const float affLL0 = (float)affd[0], affLL1 = (float)affd[1];
 
   float sumSquaredShiftT = 0, sumSquaredShiftRT = 0, sumSquaredShiftNum = 0;
@@ -630,12 +602,16 @@ static float acc_finish_entry(const lane_acc *a, int idx) {
 void orc_calc_gs_pose(orc_tracker *t, int lvl, const double pose[7], const double aff[2],
                       double H_out[64], double b_out[8]) {
   (void)pose;
+  if (t->use_sse) {
+    orc_calc_gs_pose_sse(t, lvl, aff, H_out, b_out);
+    return;
+  }
   static lane_acc acc; /* single-threaded test infrastructure */
   acc_init(&acc, 45);
   const float fxl = t->fx[lvl], fyl = t->fy[lvl];
   const float b0 = (float)t->ref_b; /* :646 */
   double affd[2];
-  aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff[0], aff[1], affd);
+  orc_aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff[0], aff[1], affd);
   const float a = (float)affd[0]; /* :647-649 */
   float **B = t->pb;
   const int n = t->pb_n;
@@ -814,7 +790,7 @@ int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsestL
   if ((modeA != 0 && (fabsf((float)aff_io[0]) > 1.2)) || (modeB != 0 && (fabsf((float)aff_io[1]) > 200))) /* :615-617 */
     return 0;
   double rel[2];
-  aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff_io[0], aff_io[1], rel);
+  orc_aff_from_to(t->ref_exposure, t->exposure[0], t->ref_a, t->ref_b, aff_io[0], aff_io[1], rel);
   const float rel0 = (float)rel[0], rel1 = (float)rel[1];
   if ((modeA == 0 && (fabsf(logf(rel0)) > 1.5)) || (modeB == 0 && (fabsf(rel1) > 200))) return 0; /* :624-626 */
   if (modeA < 0) aff_io[0] = 0;
@@ -923,6 +899,10 @@ void orc_calc_res_scale(orc_tracker *t, int lvl, float scale, float cutoffTH, do
 
 /* calcGSSSEScale, TrackerAndScaler.cpp:966-1005 with ScaleAccumulator.h:34-105 */
 void orc_calc_gs_scale(orc_tracker *t, int lvl, float scale, float *H_out, float *b_out) {
+  if (t->use_sse) {
+    orc_calc_gs_scale_sse(t, lvl, scale, H_out, b_out);
+    return;
+  }
   static lane_acc acc;
   acc_init(&acc, 3);
   const float fx1l = t->fx1[lvl], fy1l = t->fy1[lvl];
@@ -1320,7 +1300,7 @@ static void pe_calc_res(orc_pose_estimator *e, int lvl, const double pose[7], co
   for (int i = 0; i < 9; i++) R[i] = (float)Rd[i]; /* :155 */
   const float t[3] = {(float)pose[4], (float)pose[5], (float)pose[6]};
   double affd[2];
-  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd); /* :157-160, ref_aff_g2l_ = (0,0) */
+  orc_aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd); /* :157-160, ref_aff_g2l_ = (0,0) */
   const float affLL0 = (float)affd[0], affLL1 = (float)affd[1];
   float sumSquaredShiftT = 0, sumSquaredShiftRT = 0, sumSquaredShiftNum = 0;
   const float huberTH = e->p.huber_th;
@@ -1394,7 +1374,7 @@ static void pe_calc_gs(orc_pose_estimator *e, int lvl, const double aff[2], doub
   const float fxl = e->fx[lvl], fyl = e->fy[lvl];
   const float b0 = 0.0f;
   double affd[2];
-  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd);
+  orc_aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff[0], aff[1], affd);
   const float a = (float)affd[0];
   float **B = e->B;
   const int n = e->bn;
@@ -1569,7 +1549,7 @@ int orc_pe_estimate(orc_pose_estimator *e, int n, const double *xyz, const float
   int aff_good = 1; /* :469-482 */
   if ((modeA != 0 && (fabsf((float)aff_cur[0]) > 1.2)) || (modeB != 0 && (fabsf((float)aff_cur[1]) > 200))) aff_good = 0;
   double rel[2];
-  aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff_cur[0], aff_cur[1], rel);
+  orc_aff_from_to(e->ref_exposure, e->new_exposure, 0.0, 0.0, aff_cur[0], aff_cur[1], rel);
   const float rel0 = (float)rel[0], rel1 = (float)rel[1];
   if ((modeA == 0 && (fabsf(logf(rel0)) > 1.5)) || (modeB == 0 && (fabsf(rel1) > 200))) aff_good = 0;
   const int low_res = *pose_error < 10.0; /* RES_THRES, PoseEstimator.h:26 */

@@ -55,6 +55,10 @@ void orc_calc_res_pose(orc_tracker *t, int lvl, const double pose[7], const doub
 void orc_calc_gs_pose(orc_tracker *t, int lvl, const double pose[7], const double aff[2],
                       double H[64], double b[8]);
 int orc_pose_warped_n(orc_tracker *t);
+/* on != 0: calcGSSSEPose / calcGSSSEScale run in their SSE-intrinsics form (dsm_oracle_sse.c, the reference's own
+ * form and the TIMED CPU baseline of bench.py); 0 (default): the scalar lane emulation (the parity oracle).  Same
+ * results bit for bit in the parity build. */
+void orc_tracker_use_sse(orc_tracker *t, int on);
 /* test aid: the energy of the last calcRes* with the SAME per-point float terms summed in double.
  * The reference accumulates E in float in point order (quirk Q1); with 1e5..5e5 terms that sum
  * carries a relative error up to ~n*2^-24, far above the device's tree reduction error. */

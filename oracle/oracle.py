@@ -66,6 +66,7 @@ def lib(native=False):
     L.orc_last_energy_f64.argtypes = [vp]
     L.orc_last_energy_f64.restype = C.c_double
     L.orc_pose_warped_n.argtypes = [vp]
+    L.orc_tracker_use_sse.argtypes = [vp, C.c_int]
     L.orc_pose_warped_n.restype = C.c_int
     L.orc_track.argtypes = [vp, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p]
     L.orc_track.restype = C.c_int
@@ -153,6 +154,10 @@ class OracleTracker:
         if getattr(self, "h_", None):
             self.L.orc_tracker_destroy(self.h_)
             self.h_ = None
+
+    def use_sse(self, on=True):
+        """calcGSSSE* in the SSE-intrinsics form (dsm_oracle_sse.c): the reference's own form, the timed CPU baseline"""
+        self.L.orc_tracker_use_sse(self.h_, 1 if on else 0)
 
     def make_k(self, fx, fy, cx, cy):
         self.L.orc_tracker_make_k(self.h_, fx, fy, cx, cy)

@@ -28,20 +28,42 @@ def test_metric_is_baseline_jsons_and_defaults_are_the_contracts(monkeypatch):
     assert (a.gpus, a.steps, a.warmup) == (4, 7, 3)
 
 
-@pytest.mark.gpu
-def test_bench_line_carries_every_key_of_the_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--scenes", "2", "--steps", "2",
-                          "--warmup", "1", "--cpu-frames", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+def test_gpus_flag_is_honoured_or_fails_loudly():
+    """`--gpus N` without a launcher spawns N ranks itself; a mismatching launcher or too few devices is an error, never a
+    silent 1-GPU run labelled otherwise"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+    import torch
+
+    if torch.cuda.device_count() < 8:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, cwd=ROOT)
+        assert out.returncode == 2 and "device(s) are visible" in out.stderr
+
+
+def _line(out):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line"
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_every_key_of_the_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--scenes", "2", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "0", "--second-leg-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    d = _line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the headline workload is the one the metric names: 6 levels
+    assert "6-level" in d["metric"] and "6-level" in d["config"]["workload"] and "1248x384" in d["config"]["workload"]
+    five = d["config"]["reference_five_level"]
+    assert "5-level" in five["workload"] and five["value"] > 0 and 0 < five["roofline"]["frac"] < 1
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -49,5 +71,21 @@ def test_bench_line_carries_every_key_of_the_contract():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["form"] == "sse-restatement" and c["cores"] == 1 and c["value"] > 0
+    ate = c["ate_vs_cpu_ref"]
+    assert ate["frames"] >= 2 and ate["good_flags_equal"] and 0.99 <= ate["ate_ratio_gpu_over_cpu"] <= 1.01
+    ac = c["all_cores"]
+    assert ac["cores"] >= 2 and ac["value"] > 0 and ac["cpu_model"]
     assert d["value"] > 0 and abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """two ranks on the one device of the test box (gloo plumbing; the RCCL ring-key leg needs one device per rank)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device-override", "0", "--dist-backend", "gloo",
+                          "--batch", "8", "--scenes", "2", "--steps", "2", "--warmup", "1", "--no-second-leg"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["config"]["replicas"] == 2 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

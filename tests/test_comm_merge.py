@@ -1,0 +1,147 @@
+"""Cross-shard merge of the sharded ring-key DB behind the C ABI (csrc/comm_capi.hip; SURVEY.md section 8e;
+the k-NN of search_place.h:29-33 over an index split `ordinal mod G`).
+
+One GPU is enough: G "ranks" run as threads, each with its own context and shard on the same device, and the collective of
+dsm_ringdb_merge_topk_with is a barrier-synchronised exchange through host memory -- the merge KERNELS and their round
+logic are exactly what dsm_ringdb_merge_topk runs over RCCL.  The RCCL binding itself is exercised with a communicator of
+one rank (RCCL refuses two ranks on one device); N > 1 ranks over xGMI run in bench.py --gpus N, which checks the merged
+result against the unsharded answer on every rank."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from direct_stereo_slam_amd.ringdb import Comm, RingKeyDB
+from direct_stereo_slam_amd.tracker import Context
+from test_oracle_ringkey import ring_keys
+
+pytestmark = pytest.mark.gpu
+
+
+class HostExchange:
+    """all-reduce(min) / all-gather among G threads through host memory"""
+
+    def __init__(self, G):
+        self.G, self.barrier, self.slots = G, threading.Barrier(G), [None] * G
+
+    def allreduce_min(self, rank):
+        def fn(buf, count, stream):
+            torch.cuda.synchronize()
+            h = torch.empty(count, dtype=torch.int64)
+            _memcpy(h.data_ptr(), buf, 8 * count, "d2h")
+            self.slots[rank] = h
+            self.barrier.wait()
+            m = torch.stack(self.slots).min(0).values.contiguous()  # packed candidates are non-negative: int64 order = uint64 order
+            self.barrier.wait()
+            _memcpy(buf, m.data_ptr(), 8 * count, "h2d")
+        return fn
+
+    def allgather(self, rank):
+        def fn(send, recv, count, stream):
+            torch.cuda.synchronize()
+            h = torch.empty(count, dtype=torch.int64)
+            _memcpy(h.data_ptr(), send, 8 * count, "d2h")
+            self.slots[rank] = h
+            self.barrier.wait()
+            allv = torch.cat(self.slots).contiguous()
+            self.barrier.wait()
+            _memcpy(recv, allv.data_ptr(), 8 * count * self.G, "h2d")
+        return fn
+
+
+_HIP = None
+
+
+def _hip():
+    """the HIP runtime this process already uses (the copy torch / the product library mapped), not a second one"""
+    global _HIP
+    if _HIP is None:
+        import ctypes as C
+
+        paths = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l]
+        _HIP = C.CDLL(paths[0] if paths else "libamdhip64.so")
+    return _HIP
+
+
+def _memcpy(dst, src, nbytes, kind):
+    import ctypes as C
+
+    hip = _hip()
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), nbytes, 2 if kind == "d2h" else 1)
+    assert rc == 0, rc
+
+
+def _data(n=5000, nq=40, seed=7):
+    keys = ring_keys(n, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    q = (keys[rng.integers(n, size=nq)] + rng.normal(0, 0.02, (nq, 20))).astype(np.float32)
+    q[-1] = 5.0  # a query with no candidate under the threshold: NO_CANDIDATE rows must survive the merge
+    return keys, q
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+@pytest.mark.parametrize("algo", ["allreduce_min", "allgather"])
+def test_merge_kernels_over_G_ranks_equal_the_unsharded_scan(built, G, algo):
+    keys, q = _data()
+    ctx0 = Context(0)
+    full = RingKeyDB(ctx0, capacity=len(keys) + 16)
+    full.add_points(keys)
+    want = full.knn_packed_host(q)
+    ex = HostExchange(G)
+    got, errs = [None] * G, []
+
+    def rank_main(r):
+        try:
+            ctx = Context(0)
+            db = RingKeyDB(ctx, capacity=len(keys) // G + 16, shard_rank=r, shard_count=G)
+            db.add_points(keys)
+            local = torch.from_numpy(db.knn_packed_host(q)).cuda()
+            db.merge_topk_with(local.data_ptr(), len(q), G, allreduce_min=ex.allreduce_min(r), allgather=ex.allgather(r), algo=algo)
+            ctx.sync()
+            got[r] = local.cpu().numpy()
+            db.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            ex.barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for r in range(G):
+        assert np.array_equal(got[r], want), f"rank {r}"
+    full.close()
+    ctx0.close()
+
+
+def test_rccl_binding_with_one_rank(built, ctx):
+    """librccl is loaded by the library itself; a one-rank communicator runs the k all-reduce rounds / the all-gather"""
+    keys, q = _data(n=2000, nq=16)
+    comm = Comm(ctx, Comm.unique_id(), 0, 1)
+    db = RingKeyDB(ctx, capacity=len(keys) + 16)
+    db.add_points(keys)
+    want = db.knn_packed_host(q)
+    for algo in ("allreduce_min", "allgather"):
+        local = torch.from_numpy(want.copy()).cuda()
+        db.merge_topk_device(comm, local.data_ptr(), len(q), algo)
+        ctx.sync()
+        assert np.array_equal(local.cpu().numpy(), want)
+    db.close()
+    comm.close()
+
+
+def test_sharded_query_then_enqueue_needs_a_communicator(built, ctx):
+    from direct_stereo_slam_amd._lib import DsmError
+
+    db = RingKeyDB(ctx, shard_rank=0, shard_count=2)
+    db.add_points(ring_keys(50, seed=1))
+    with pytest.raises(DsmError, match="communicator"):
+        db.search_ringkey(np.zeros(20, np.float32))
+    comm = Comm(ctx, Comm.unique_id(), 0, 1)
+    with pytest.raises(DsmError, match="shard"):
+        db.attach_comm(comm)  # rank / size of the communicator must equal the shard's
+    comm.close()
+    db.close()

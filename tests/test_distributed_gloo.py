@@ -1,7 +1,10 @@
-"""CPU, world_size 2, gloo: the cross-shard merge of the ring-key DB (the only collective on the
-path).  The per-shard k-NN is produced here by a numpy brute force with the oracle's distance
-function, so that the test needs no GPU; on the GPU box the same merge runs over RCCL with the
-kernel's output (bench.py --gpus N)."""
+"""world_size 2, gloo: the cross-shard merge of the ring-key DB (the only collective on the path).
+
+Without a GPU (`-m "not gpu"`): the per-shard k-NN is a numpy brute force with the oracle's distance function and the merge
+is the torch restatement of the round algorithm (ringdb.merge_topk_allreduce_min).
+With a GPU (`-m gpu`): two gloo processes share the device; each scans ITS shard with the HIP kernel
+(dsm_ringdb_knn_packed_host) and the merge is the C ABI's own (dsm_ringdb_merge_topk_with: the kernels RCCL drives in
+dsm_ringdb_merge_topk) with gloo as the transport.  N ranks over RCCL / xGMI: bench.py --gpus N."""
 import os
 import socket
 import sys
@@ -57,12 +60,72 @@ def worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_allreduce_min_merge_world2(built):
+def _run(fn):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(fn, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_allreduce_min_merge_world2(built):
+    _run(worker)
+
+
+def gpu_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from direct_stereo_slam_amd.ringdb import RingKeyDB
+    from direct_stereo_slam_amd.tracker import Context
+    from test_comm_merge import _memcpy
+    from test_oracle_ringkey import ring_keys
+
+    keys = ring_keys(3000, seed=5)
+    rng = np.random.default_rng(2)
+    q = (keys[rng.integers(3000, size=24)] + rng.normal(0, 0.02, (24, 20))).astype(np.float32)
+    ctx = Context(0)
+    db = RingKeyDB(ctx, capacity=len(keys) // world + 16, shard_rank=rank, shard_count=world)  # ordinal mod G shard
+    db.add_points(keys)
+
+    def allreduce_min(buf, count, stream):
+        torch.cuda.synchronize()
+        h = torch.empty(count, dtype=torch.int64)
+        _memcpy(h.data_ptr(), buf, 8 * count, "d2h")
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        _memcpy(buf, h.data_ptr(), 8 * count, "h2d")
+
+    def allgather(send, recv, count, stream):
+        torch.cuda.synchronize()
+        h = torch.empty(count, dtype=torch.int64)
+        _memcpy(h.data_ptr(), send, 8 * count, "d2h")
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        allv = torch.cat(parts).contiguous()
+        _memcpy(recv, allv.data_ptr(), 8 * count * world, "h2d")
+
+    ok = True
+    full = RingKeyDB(ctx, capacity=len(keys) + 16)
+    full.add_points(keys)
+    want = full.knn_packed_host(q)
+    for algo in ("allreduce_min", "allgather"):
+        local = torch.from_numpy(db.knn_packed_host(q)).cuda()  # the HIP kernel's scan of this shard
+        db.merge_topk_with(local.data_ptr(), len(q), world, allreduce_min=allreduce_min, allgather=allgather, algo=algo)
+        ctx.sync()
+        ok = ok and bool((local.cpu().numpy() == want).all())
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_abi_merge_of_kernel_shards_over_gloo_world2(built):
+    _run(gpu_worker)
