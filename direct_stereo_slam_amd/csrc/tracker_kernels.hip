@@ -120,16 +120,22 @@ struct EvalConsts {
 // device-scope accesses (write-through / L2-coherent), so no cache-wide write-back or invalidate is
 // ever needed for them.
 //
-// Ordering between workgroups (arrival tickets, queue items): the producer's stores must be PERFORMED at device scope
-// before the device-scope atomic that announces them -- a release fence at AGENT scope (s_waitcnt vmcnt(0) + L2
-// write-back of anything not yet written through); a workgroup-scope fence emits neither and leaves the announcing
-// atomic free to overtake the stores.  The consumer pairs it with an agent-scope acquire after it has seen the
-// announcement.
-// Measured on MI355X (work-queue form, 256 dense frames): the pair costs nothing against the old workgroup-scope
-// fence (33.1 k vs 32.7-33.0 k frames/s) -- the release finds nothing to write back (partials, state and items are
-// written through), and the acquire's cache invalidate hits lines that are streamed once anyway.
-__device__ __forceinline__ void xwg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-__device__ __forceinline__ void xwg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// Ordering between workgroups (arrival tickets, queue items).  Everything one workgroup writes for another inside a
+// launch -- chunk partials, the LMState, queue items -- is written with device-scope (sc1, write-through) stores and read
+// with device-scope loads, which the non-coherent cache levels do not serve from stale lines.  What the producer still
+// owes is that those stores have been PERFORMED before the device-scope atomic that announces them: s_waitcnt vmcnt(0)
+// between the two (a workgroup-scope fence alone emits no wait, and the announcing atomic could overtake the stores).
+// The textbook form, an agent-scope release fence, emits the same wait plus an L2 write-back (buffer_wbl2 sc1) that has
+// nothing to write back here and costs a factor of three on the work-queue kernel (measured on MI355X, 256 dense frames:
+// 10.9-11.8 k frames/s with agent-scope release / release+acquire fences against 32.7-33.1 k with this form); an
+// agent-scope acquire on the consumer side would invalidate the L2 under the streaming evaluations for the same reason.
+__device__ __forceinline__ void xwg_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // compiler + LDS ordering
+  __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the written-through stores have been acknowledged
+}
+__device__ __forceinline__ void xwg_acquire() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // later (device-scope) loads are not moved above the announcement
+}
 __device__ __forceinline__ void store_partial(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
