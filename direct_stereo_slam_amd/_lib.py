@@ -56,6 +56,15 @@ class Stats(C.Structure):
     ]
 
 
+class LoopJob(C.Structure):
+    _fields_ = [
+        ("n_kf", C.c_int), ("kf_ids", c_int_p), ("kf_pose_wc", c_double_p), ("cur_cw", c_double_p),
+        ("n_pts", C.c_int), ("pt_kf_id", c_int_p), ("pt_xyz", c_double_p),
+        ("kf_keep", c_int_p), ("n_out", c_int_p), ("sel_idx", c_int_p), ("pts_spherical", c_double_p),
+        ("ringkey", c_float_p), ("sig_idx", c_int_p), ("sig_val", c_double_p), ("n_sig", c_int_p), ("tfm_pca_rig", c_double_p),
+    ]
+
+
 # every symbol include/dsm_hotpath.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 _pp_f = C.POINTER(c_float_p)
@@ -124,6 +133,7 @@ SYMBOLS = {
     "dsm_ringdb_attach_comm": (C.c_int, [_vp, _vp]),
     "dsm_scancontext_generate": (C.c_int, [c_double_p, C.c_int, C.c_double, C.c_int, C.c_int, c_float_p, c_int_p, c_double_p, c_int_p, c_double_p]),
     "dsm_generate_spherical_points": (C.c_int, [C.c_int, c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p]),
+    "dsm_loop_descriptors_batch": (C.c_int, [_vp, C.c_int, C.POINTER(LoopJob), C.c_double, C.c_int, C.c_int]),
     "dsm_make_coarse_depth_l0": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, _pp_f, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
     "dsm_sc_distance": (C.c_float, [c_int_p, c_double_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
     "dsm_search_sc": (C.c_int, [c_int_p, c_double_p, C.c_int, C.c_int, c_int_p, _pp_i, _pp_d, c_int_p, C.c_int, c_int_p, c_float_p]),

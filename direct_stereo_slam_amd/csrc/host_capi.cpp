@@ -53,7 +53,9 @@ int dsm_search_sc(const int *sig_idx, const double *sig_val, int n_sig, int n_ca
 #include <cstring>
 #include <vector>
 
-namespace {
+#include "loopdet_internal.hpp"
+
+namespace dsm {
 
 // symmetric 3x3 eigen-decomposition (cyclic Jacobi, double), eigenvalues ascending as
 // Eigen::SelfAdjointEigenSolver returns them (:43-47); columns of V are the eigenvectors
@@ -110,7 +112,8 @@ void eig3_sym(const double A_in[9], double evals[3], double V[9]) {
   memcpy(V, Vs, sizeof Vs);
 }
 
-} // namespace
+} // namespace dsm
+using dsm::eig3_sym;
 
 extern "C" {
 
@@ -180,7 +183,8 @@ int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int n
 // ---------------------------------------------------------------------------------------------
 // generate_spherical_points, src/loop_closure/loop_detection/generate_spherical_points.h:27-85 (flat-array form)
 // ---------------------------------------------------------------------------------------------
-namespace {
+} // extern "C"
+namespace dsm {
 // Sophus SO3::exp as a rotation matrix (Rodrigues; the series below 1e-10 as Sophus does for the quaternion)
 void so3_exp_matrix(const double w[3], double R[9]) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -228,7 +232,20 @@ double rotation_angle(const double R[9]) {
   if (std::fabs(q[3]) < 1e-10) return M_PI;
   return std::fabs(2.0 * std::atan(n / q[3]));
 }
-} // namespace
+
+// generate_spherical_points.h:33-41: keyframes whose orientation differs from the current one by more than 0.5 rad are trimmed
+void trim_keyframes(int n_kf, const double *kf_pose_wc, const double *cur_cw, int *kf_keep) {
+  for (int k = 0; k < n_kf; k++) {
+    double Rk[9], Rd[9];
+    so3_exp_matrix(kf_pose_wc + 6 * k + 3, Rk);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Rd[i * 3 + j] = cur_cw[i * 4 + 0] * Rk[0 * 3 + j] + cur_cw[i * 4 + 1] * Rk[1 * 3 + j] + cur_cw[i * 4 + 2] * Rk[2 * 3 + j];
+    kf_keep[k] = rotation_angle(Rd) > 0.5 ? 0 : 1;
+  }
+}
+} // namespace dsm
+using dsm::trim_keyframes;
+extern "C" {
 
 int dsm_generate_spherical_points(int n_kf, const int *kf_ids, const double *kf_pose_wc, const double *cur_cw, double lidar_range,
                                   int n_pts, const int *pt_kf_id, const double *pt_xyz, int *kf_keep, int *n_out, int *sel_idx,
@@ -238,14 +255,8 @@ int dsm_generate_spherical_points(int n_kf, const int *kf_ids, const double *kf_
     return DSM_ERR_INVALID;
   // :33-41 keyframes whose orientation differs from the current one by more than 0.5 rad are trimmed
   std::vector<std::pair<int, int>> keep_ids; // (id, kept)
-  for (int k = 0; k < n_kf; k++) {
-    double Rk[9], Rd[9];
-    so3_exp_matrix(kf_pose_wc + 6 * k + 3, Rk);
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) Rd[i * 3 + j] = cur_cw[i * 4 + 0] * Rk[0 * 3 + j] + cur_cw[i * 4 + 1] * Rk[1 * 3 + j] + cur_cw[i * 4 + 2] * Rk[2 * 3 + j];
-    kf_keep[k] = rotation_angle(Rd) > 0.5 ? 0 : 1;
-    keep_ids.push_back(std::make_pair(kf_ids[k], kf_keep[k]));
-  }
+  trim_keyframes(n_kf, kf_pose_wc, cur_cw, kf_keep);
+  for (int k = 0; k < n_kf; k++) keep_ids.push_back(std::make_pair(kf_ids[k], kf_keep[k]));
   std::sort(keep_ids.begin(), keep_ids.end());
   auto kept = [&](int id) {
     auto it = std::lower_bound(keep_ids.begin(), keep_ids.end(), std::make_pair(id, 0));

@@ -334,6 +334,35 @@ int dsm_generate_spherical_points(int n_kf, const int *kf_ids, const double *kf_
                                   double lidar_range, int n_pts, const int *pt_kf_id, const double *pt_xyz, int *kf_keep,
                                   int *n_out, int *sel_idx, double *pts_spherical);
 
+/* DEVICE form of the pair generate_spherical_points + ScanContext::generate (the two calls a marginalised keyframe makes on its
+ * way to the ring-key search: LoopHandler.cpp:186-187 and ScanContext.cpp:78-141 via LoopHandler.cpp:240-245), batched over
+ * n_jobs keyframes -- one per concurrent sequence sharing the GPU (BASELINE configs[4]).  Per job the inputs are those of
+ * dsm_generate_spherical_points; outputs: kf_keep, *n_out, sel_idx, pts_spherical as there, and -- when ringkey is not NULL --
+ * ringkey[num_r], the sparse signature (sig_idx / sig_val, capacity num_s*num_r, *n_sig entries) and tfm_pca_rig[16] as
+ * dsm_scancontext_generate returns them for pts_spherical.  The voxel "highest point" filter runs as two atomic-min passes
+ * over a dense voxel grid plus an ordered compaction, the polar binning as atomic max per bin (csrc/loopdet_kernels.hip); the
+ * keyframe trim (a handful of keyframes) and the 3x3 eigen-decomposition stay on the host.  Same results as the two host
+ * entry points (bit for bit wherever device and host libm agree on atan2).  lidar_range up to 100 m (dense grid). */
+typedef struct dsm_loop_job {
+  int n_kf;
+  const int *kf_ids;
+  const double *kf_pose_wc;   /* n_kf x 6 */
+  const double *cur_cw;       /* row-major 3x4 */
+  int n_pts;
+  const int *pt_kf_id;
+  const double *pt_xyz;       /* n_pts x 3 */
+  int *kf_keep;               /* out: n_kf */
+  int *n_out;                 /* out */
+  int *sel_idx;               /* out: capacity n_pts */
+  double *pts_spherical;      /* out: capacity n_pts x 3 */
+  float *ringkey;             /* out: num_r floats, or NULL to stop after the point filter */
+  int *sig_idx;               /* out: capacity num_s*num_r */
+  double *sig_val;            /* out: capacity num_s*num_r */
+  int *n_sig;                 /* out */
+  double *tfm_pca_rig;        /* out: row-major 4x4 */
+} dsm_loop_job;
+int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r);
+
 /* replaces TrackerAndScaler::makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) for callers that hold
  * the active points as flat arrays: (pu,pv) = centerProjectedTo[0..1], pidepth = centerProjectedTo[2],
  * pweight = sqrtf(1e-3/(HdiF+1e-12)) (:155-158).  ref_dIp[lvl]: the keyframe's (I,dx,dy) pyramid.

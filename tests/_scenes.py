@@ -14,11 +14,15 @@ SIZES = {
     # the other BASELINE.json configs' working sizes (crop keeps fx, fy and shifts cx, cy by half the removed border):
     "kitti04": (1216, 368, 0, 5),  # configs[0]: cams/kitti/4_12/camera0.txt:1-4 (1226x370 cropped)
     "malaga": (1024, 768, 0, 5),   # configs[2]: cams/malaga/camera0.txt:1-4
+    "kitti6": (1248, 384, 0, 6),   # S2: the metric's own configuration, 1241x376 padded to a multiple of 32, six levels
+    "hd6": (1920, 1080, 0, 6),     # S3 / configs[3]: 1920x1080, six floor-halved levels (1920x1080 ... 60x33), full size
 }
 # (fx, fy, cx, cy) at the working size and the stereo baseline for sizes that are not KITTI-00
 CAMERAS = {
     "kitti04": ((707.0912, 707.0912, 601.8873 - (1226 - 1216) / 2.0, 183.1104 - (370 - 368) / 2.0), -0.5372),
     "malaga": ((795.11588, 795.11588, 517.12973, 395.59665), -0.119471),  # cams/malaga/T_stereo.yaml:4-7
+    "kitti6": ((718.856, 718.856, 607.1928 + (1248 - 1241) / 2.0, 185.2157 + (384 - 376) / 2.0), -0.5372),
+    "hd6": ((718.856 * 1920.0 / 1241.0, 718.856 * 1920.0 / 1241.0, 959.5, 539.5), -0.5372),  # KITTI's field of view
 }
 
 

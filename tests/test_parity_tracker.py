@@ -86,6 +86,39 @@ def test_eval_parity_kitti_full_size(ctx):
     assert_eval_pose_equal(orc, trk, 0, sc.gt_pose, sc.gt_aff, 20.0)
 
 
+@pytest.mark.parametrize("size,seed", [("kitti6", 0x5EED0000), ("hd6", 0x5EED0001)])
+def test_eval_and_track_parity_six_level_configs_full_size(ctx, size, seed):
+    """The metric's own configuration (S2: 1248x384, six levels) and BASELINE.json configs[3] at FULL size (S3: 1920x1080,
+    six floor-halved levels, 2,057,696 template points at level 0): fused evaluation vs oracle at the finest, a middle and
+    the coarsest level (levels 4-5 of S3 have odd sizes: 120x67, 60x33), then the full LM of track and optimize_scale with
+    the six-entry iteration table -- same evaluation counts per level as the oracle."""
+    sc = make_scene(size, seed=seed, noise=2.0)
+    assert sc.nl == 6
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    assert len(sc.tpl[0][0]) == (sc.w - 4) * (sc.h - 4) and len(sc.tpl[0][5]) == ((sc.w >> 5) - 4) * ((sc.h >> 5) - 4)
+    for lvl in (0, 3, 5):
+        assert_eval_pose_equal(orc, trk, lvl, S.IDENTITY_POSE, [0.0, 0.0], 20.0)
+        assert_eval_pose_equal(orc, trk, lvl, sc.gt_pose, sc.gt_aff, 20.0)
+        assert_eval_scale_equal(orc, trk, lvl, 1.0, 20.0)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    good_g, pose_g, aff_g, last_g = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    assert good_g == good_o
+    np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
+    assert list(ctx.stats().evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
+    err_o, s_o = orc.optimize_scale(1.0, sc.nl - 1)
+    err_g, s_g = trk.optimizeScale(1.0, sc.nl - 1)
+    assert abs(s_g - s_o) < 1e-4
+    # err = sqrt(E / N) of the last accepted level-0 evaluation.  The reference (and the oracle) accumulate E sequentially in
+    # float (quirk Q1), good to n * 2^-24 -- 12 % of E in the worst case at 2 M points -- so the device's value is held
+    # against the EXACT sum of the oracle's per-point float terms at the final scale instead (2e-5), and the oracle's own
+    # float sum only against its rounding bound
+    rs = orc.calc_res_scale(0, s_o, 20.0)
+    assert rs[5] < 0.6  # the level ran at the base cut-off (no cut-off repeat)
+    err_exact = np.sqrt(orc.last_energy_f64() / rs[1])
+    assert abs(err_g - err_exact) < 2e-5 * err_exact
+    assert abs(err_o - err_exact) < 0.5 * rs[1] * 2.0 ** -24 * err_exact
+
+
 @pytest.mark.parametrize("size", ["kitti04", "malaga"])
 def test_eval_and_track_parity_other_baseline_shapes(ctx, size):
     """BASELINE.json configs[0] (KITTI 04, 1216x368) and configs[2] (Malaga, 1024x768) working sizes with their own
