@@ -70,6 +70,7 @@ def parse():
                     help="dsm_params.work_queue: 0 (default here) launch-per-step form -- its dominant kernel, the level-0 evaluation, is "
                          "timed per launch for the roofline; 1 the library's automatic rule (batches >= 32); 2 the whole call as one "
                          "launch of persistent workgroups (its roofline is the whole-call figure)")
+    ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="upper bound of the frames timed on the CPU baseline (rank 0, N=1); the leg stops after --cpu-seconds")
@@ -211,6 +212,8 @@ def build_workload(args, ctx, config):
     params.work_queue = args.queue
     if args.fuse is not None:
         params.fuse_lm = args.fuse
+    if args.speculate is not None:
+        params.speculate = args.speculate
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0

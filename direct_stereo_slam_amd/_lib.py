@@ -36,6 +36,7 @@ class Params(C.Structure):
         ("persistent_coarse", C.c_int),
         ("fuse_lm", C.c_int),
         ("work_queue", C.c_int),
+        ("speculate", C.c_int),
     ]
 
 

@@ -215,6 +215,7 @@ void dsm_params_default(dsm_params *p) {
   p->persistent_coarse = 0;
   p->fuse_lm = 1;
   p->work_queue = 1;
+  p->speculate = 1;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -850,7 +851,7 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
       return invalid("batch: all trackers must share image size and levels");
     int rc = check_ready(t, mode);
     if (rc) return rc;
-    const int need = max_chunks_upto(t->w * t->h) * kPartialStride;
+    const int need = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
     if (need > ps) ps = need;
   }
   int rc = ensure_batch_capacity(ctx, n, ps);
@@ -939,15 +940,22 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   // launches (their workgroups exit on the first instruction); problems that need more simply stay
   // at their level and are continued by the next pass.  Results do not depend on the schedule.
   int worst[DSM_MAX_LEVELS], grid_x[DSM_MAX_LEVELS];
+  bool spec[DSM_MAX_LEVELS];
   for (int L = 0; L < nlevels; L++) {
-    int max_chunks = 1, max_it = 0;
+    int max_chunks = 1, max_it = 0, max_n = 0;
     for (int i = 0; i < n; i++) {
       const int c = num_chunks(ts[i]->desc.lv[L].n);
       if (c > max_chunks) max_chunks = c;
+      if (ts[i]->desc.lv[L].n > max_n) max_n = ts[i]->desc.lv[L].n;
       if (ts[i]->params.max_iterations[L] > max_it) max_it = ts[i]->params.max_iterations[L];
     }
-    grid_x[L] = round8(max_chunks);
+    grid_x[L] = max_chunks < 8 ? max_chunks : round8(max_chunks);
     worst[L] = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
+    // Speculative second candidate (dsm_device.hpp): doubles the evaluation work of a step to save the launches of
+    // rejected steps.  It pays where a launch is latency- and not bandwidth-bound and rejections come in runs: the
+    // small levels (a few thousand points).  Measured (S2 dense, launch form): 64 frames +12 %, 512 frames +-0 %, one
+    // frame -1 % when applied to every level (the fine levels end on their first rejection), DESIGN.md section 4.3.
+    spec[L] = P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192);
   }
   int *sched = ctx->sched[mode];
   int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
@@ -1004,12 +1012,12 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
           const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n <= 8));
           launch_eval(st, mode, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
                       ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride,
-                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0);
+                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0, spec[L]);
           if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
           if (!fused)
             launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
                       ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr,
-                      ctx->d_status + 2 * g0);
+                      ctx->d_status + 2 * g0, spec[L]);
         }
       }
       ctx->stats.launches[L] += steps;
@@ -1088,7 +1096,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       return DSM_ERR_STATE;
     }
     for (int l = 0; l < nlevels; l++) {
-      if ((int)S.evals[l] > need[l]) need[l] = (int)S.evals[l];
+      if ((int)S.rounds[l] > need[l]) need[l] = (int)S.rounds[l]; // launches this problem needed at the level
       ctx->stats.evals[l] += S.evals[l];
       // compulsory bytes of one evaluation: the template once + the target image once, or, for a sparse template,
       // the four 12-byte taps of every point if that is less

@@ -97,7 +97,18 @@ struct alignas(16) LMState {
   double min_res[DSM_MAX_LEVELS];
   double flow[3];
   long long evals[DSM_MAX_LEVELS];
+  long long rounds[DSM_MAX_LEVELS]; // LM steps taken at each level = evaluation launches it needed (with a speculative
+                                    // candidate consumed a step covers two evaluations)
   EvalIn in;
+  // Speculative second candidate (dsm_params.speculate): next to the proposal being evaluated, the proposal that WOULD follow
+  // if this one is rejected (same H, b and current pose; lambda four times larger, :583-585) is evaluated in the same launch.
+  // A rejection -- half of all steps on the coarse levels -- then finds its successor's residual already computed and the LM
+  // step consumes both: same evaluations, same decisions, same counts as the sequential loop, fewer launches in a row.
+  int spec_valid, spec_pad0;
+  float spec_scale_cand, spec_inc_f;
+  double spec_inc_norm;
+  double spec_cand[7], spec_aff_cand[2];
+  EvalIn spec_in;
 };
 
 // Output of a single fused evaluation (dsm_tracker_calc_res_pose / _scale)

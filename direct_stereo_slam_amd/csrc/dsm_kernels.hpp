@@ -46,10 +46,10 @@ struct StartInfo { // host -> device, one per problem
 // mode: 0 = pose (calcResPose + calcGSSSEPose), 1 = scale (calcResScale + calcGSSSEScale)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out);
+                 int partial_stride, int *tickets, int *status_out, bool spec = false);
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
-               SingleOut *single_out, int *status_out);
+               SingleOut *single_out, int *status_out, bool spec = false);
 
 // work-queue kernel (queue_kernel): header of the device-side queue, zeroed before every launch; counters on their
 // own 128-byte lines.  Items: (index + 1) << 32 | problem << kQueueChunkBits | chunk.

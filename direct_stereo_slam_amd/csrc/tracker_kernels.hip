@@ -596,8 +596,9 @@ __device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &
 
 // Builds the inputs of the next evaluation and (store) writes them to the problem state: called by lane 0
 // alone, or by a whole wave with wave-uniform arguments and store = (lane == 0).
+// spec: the inputs go to the speculative slot (S.spec_in) instead of S.in.
 __device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
-                              float scale, float cutoff, bool store = true) {
+                              float scale, float cutoff, bool store = true, bool spec = false) {
   EvalIn e;
   if (mode == 1)
     make_eval_scale(T, e, lvl, scale, cutoff);
@@ -605,7 +606,12 @@ __device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, i
     make_eval_points3d(T, e, lvl, pose, aff, cutoff);
   else
     make_eval_pose(T, e, lvl, pose, aff, cutoff);
-  if (store) S.in = e;
+  if (store) {
+    if (spec)
+      S.spec_in = e;
+    else
+      S.in = e;
+  }
 }
 
 // lane 0 only
@@ -614,6 +620,7 @@ __device__ __forceinline__ void begin_level(const TrackerDev &T, LMState &S, int
   S.phase = PH_INIT;
   S.iteration = 0;
   S.level_cutoff_repeat = 1.0f;
+  S.spec_valid = 0;
   const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
   make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
 }
@@ -771,8 +778,8 @@ __device__ __forceinline__ void finish_track(const TrackerDev &T, LMState &S) {
 }
 
 // whole wave: solve + propose for the pose problem (:505-554).  h = H(r,c) of this lane,
-// bneg = -b(r) replicated along the row.
-__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane) {
+// bneg = -b(r) replicated along the row.  spec: the proposal is the speculative one (S.spec_*).
+__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane, bool spec = false) {
   const int r = lane >> 3, c = lane & 7;
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   double a = h;
@@ -827,18 +834,26 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, do
 #pragma unroll
   for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
   if (lane == 0) {
+    if (spec) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
-    S.aff_cand[0] = aff_cand[0];
-    S.aff_cand[1] = aff_cand[1];
-    S.inc_norm = sqrt(nrm);
-    S.phase = PH_ITER;
+      for (int i = 0; i < 7; i++) S.spec_cand[i] = cand[i];
+      S.spec_aff_cand[0] = aff_cand[0];
+      S.spec_aff_cand[1] = aff_cand[1];
+      S.spec_inc_norm = sqrt(nrm);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
+      S.aff_cand[0] = aff_cand[0];
+      S.aff_cand[1] = aff_cand[1];
+      S.inc_norm = sqrt(nrm);
+      S.phase = PH_ITER;
+    }
   }
-  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0);
+  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0, spec);
 }
 
 // lane 0 only: :897-913
-__device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, float lambda) {
+__device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, float lambda, bool spec = false) {
   float Hl = S.Hs;
   Hl *= (1 + lambda);
   float inc = -S.bs / Hl;
@@ -847,10 +862,16 @@ __device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, f
   if (lambda < lim) extrapFac = sqrtf(sqrtf(lim / lambda));
   inc *= extrapFac;
   if (!__builtin_isfinite(inc) || __builtin_fabsf(inc) > S.scale_cur) inc = 0.0f;
-  S.inc_f = inc;
-  S.scale_cand = S.scale_cur + inc;
-  S.phase = PH_ITER;
-  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, S.scale_cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat);
+  const float cand = S.scale_cur + inc;
+  if (spec) {
+    S.spec_inc_f = inc;
+    S.spec_scale_cand = cand;
+  } else {
+    S.inc_f = inc;
+    S.scale_cand = cand;
+    S.phase = PH_ITER;
+  }
+  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, true, spec);
 }
 
 // lane 0 only
@@ -883,11 +904,21 @@ __device__ __forceinline__ void end_level(const TrackerDev &T, LMState &S) {
 }
 
 // LDS workspace of the partial reduction / LM step (lm_kernel and coarse_kernel)
-struct LmShared {
+struct RedBuf { // fixed-order reduction of one evaluation's chunk partials
   double psum[19][kNumSlots];
   long long pisum[19][4];
   double sums[kNumSlots];
   long long isums[4];
+};
+// second reduction buffer and the wave 0 <-> wave 1 hand-shake of a step that handles a speculative candidate
+struct LmSpecShared {
+  RedBuf red;
+  int cmd;      // wave 0 -> wave 1: 0 wait, 1 stage the speculative proposal with `lambda`, 2 nothing to do
+  int done;     // wave 1 -> wave 0
+  float lambda;
+};
+struct LmShared {
+  RedBuf red;
   // The problem's LMState and its tracker descriptor are staged here for the duration of a step
   // (lm_kernel) or of the whole small-level loop (coarse_kernel): the state machine then runs on LDS
   // latencies instead of a chain of dependent global-memory round trips.
@@ -931,7 +962,7 @@ __device__ __forceinline__ void store16_coherent(void *p, const uint4 &v) {
 // workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
 // g, g+19, g+38, ...: every load is a 16-byte read and up to kRedBatch of them are in flight per
 // thread.  `P` may point to global memory (lm_kernel) or LDS (coarse_kernel): same order, same sums.
-__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, LmShared &sh) {
+__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, RedBuf &sh) {
   constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
   const int q = tid % kQuads, g = tid / kQuads;
   if (g < kGroups) {
@@ -963,7 +994,7 @@ __device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, 
 }
 
 // wave 0, after a workgroup barrier: the 19 group sums are added in group order by the slot's lane
-__device__ __forceinline__ void reduce_partials_final(int lane, LmShared &sh) {
+__device__ __forceinline__ void reduce_partials_final(int lane, RedBuf &sh) {
   if (lane < kSlotNTerms) {
     double s = sh.psum[0][lane];
 #pragma unroll
@@ -980,11 +1011,18 @@ __device__ __forceinline__ void reduce_partials_final(int lane, LmShared &sh) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// value of an LDS word that another wave of the workgroup writes
+__device__ __forceinline__ int lds_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // One step of the LM state machine by wave 0 (all 64 lanes; lane 0 writes the state).
-__device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane) {
+// sp != nullptr: the launch also evaluated the speculative candidates (where S.spec_valid) -- their reduced sums are in
+// sp->red -- and new proposals may stage one; wave 1 of the workgroup runs lm_spec_wave1 beside this function.
+__device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane,
+                                              LmSpecShared *sp = nullptr) {
   const bool pose_like = mode != 1;
-  const double *sums = sh.sums;
-  const long long *isums = sh.isums;
+  const double *sums = sh.red.sums;
+  const long long *isums = sh.red.isums;
   double rs[6];
   build_rs(sums, isums, rs);
   const int n_warped = (int)isums[2];
@@ -994,9 +1032,15 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   const int max_it = T.p.max_iterations[lvl];
   const float lim = T.p.lambda_extrapolation_limit;
   const int phase = S.phase;
+  const bool had_spec = sp && S.spec_valid; // wave-uniform; read before lane 0 clears it
   bool level_done = false, do_propose = false;
   double h = 0, bneg = 0; // this lane's H(r,c) and -b(r) for a following proposal
   float lambda_next = 0.01f; // computed by every lane: nothing lane 0 writes below is re-read by the wave
+  int iteration = 0;
+  if (lane == 0) {
+    S.rounds[lvl]++;
+    S.spec_valid = 0;
+  }
   if (phase == PH_INIT) {
     if (rs[5] > 0.6 && S.level_cutoff_repeat < 50) { // :477-485 / :875-883
       if (lane == 0) {
@@ -1028,9 +1072,10 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
         do_propose = true;
     }
   } else {
-    const bool accept = (rs[0] / rs[1]) < (S.res_old[0] / S.res_old[1]); // :559 / :915
+    const double old_ratio = S.res_old[0] / S.res_old[1];
+    const bool accept = (rs[0] / rs[1]) < old_ratio; // :559 / :915
     const bool small = pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
-    const int iteration = S.iteration + 1;
+    iteration = S.iteration + 1;
     {
       const float l_old = S.lambda;
       float l4 = l_old * 4;
@@ -1062,34 +1107,116 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
           S.scale_cur = S.scale_cand;
         }
       }
+    }
+    if (small || iteration >= max_it) {
+      level_done = true;
+    } else if (!accept && had_spec) {
+      // The proposal the loop makes next -- same H, b and current pose, lambda = lambda_next -- is the speculative candidate:
+      // it was evaluated in this launch.  Consume it as the loop's next iteration (:505-590 once more).
+      const double *sums2 = sp->red.sums;
+      const long long *isums2 = sp->red.isums;
+      double rs2[6];
+      build_rs(sums2, isums2, rs2);
+      const int n4b = ((int)isums2[2] + 3) & ~3;
+      const bool accept2 = (rs2[0] / rs2[1]) < old_ratio; // res_old is unchanged by the rejection
+      const bool small2 = pose_like ? !(S.spec_inc_norm > 1e-3) : !(S.spec_inc_f > 1e-3);
+      iteration += 1;
+      {
+        const float l_old = lambda_next;
+        float l4 = l_old * 4;
+        if (l4 < lim) l4 = lim;
+        lambda_next = accept2 ? l_old * 0.5f : l4;
+      }
+      if (pose_like && accept2) {
+        h = build_H_elem(T.p, sums2, n4b, r, c);
+        bneg = -build_b_elem(T.p, sums2, n4b, r);
+        S.H[lane] = h;
+        if (c == 0) S.b[r] = -bneg;
+      }
+      if (lane == 0) {
+        S.evals[lvl]++;
+        if (accept2) {
+          for (int i = 0; i < 6; i++) S.res_old[i] = rs2[i];
+          if (pose_like) {
+            for (int i = 0; i < 7; i++) S.cur[i] = S.spec_cand[i];
+            S.aff_cur[0] = S.spec_aff_cand[0];
+            S.aff_cur[1] = S.spec_aff_cand[1];
+          } else {
+            S.Hs = (float)sums2[0] * (1.0f / n4b);
+            S.bs = (float)sums2[1] * (1.0f / n4b);
+            S.scale_cur = S.spec_scale_cand;
+          }
+        }
+      }
+      if (small2 || iteration >= max_it)
+        level_done = true;
+      else
+        do_propose = true;
+    } else {
+      do_propose = true;
+    }
+    if (lane == 0) {
       S.lambda = lambda_next;
       S.iteration = iteration;
     }
-    if (small || iteration >= max_it)
-      level_done = true;
-    else
-      do_propose = true;
   }
-  // make lane 0's state writes (lambda, cur, ...) visible to the whole wave before proposing
+  // make lane 0's state writes (lambda, cur, ...) visible to the whole wave (and to wave 1) before proposing
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // the speculative proposal: what the loop proposes after rejecting the main one -- lambda four times larger (:583-585);
+  // it exists only if the loop would go on after that rejection (one more iteration allowed; the main step not "too small")
+  const bool want_spec = sp && do_propose && iteration + 1 < max_it;
+  if (sp && lane == 0) {
+    float l4 = lambda_next * 4;
+    if (l4 < lim) l4 = lim;
+    sp->lambda = l4;
+    lds_flag_set(&sp->cmd, want_spec ? 1 : 2);
+  }
   if (do_propose) {
     if (pose_like)
       propose_pose(T, S, h, bneg, lambda_next, lane);
     else if (lane == 0)
       propose_scale(T, S, lambda_next);
   }
+  if (want_spec) {
+    while (lds_flag(&sp->done) == 0) __builtin_amdgcn_s_sleep(1);
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const bool main_small = pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // the loop breaks after the main step
+      S.spec_valid = main_small ? 0 : 1;
+    }
+  }
   if (lane == 0 && level_done) end_level(T, S);
+}
+
+// wave 1 beside lm_step_wave0: stages the speculative proposal when wave 0 asks for it
+__device__ __forceinline__ void lm_spec_wave1(int mode, const TrackerDev &T, LMState &S, LmSpecShared &sp, int lane) {
+  int cmd;
+  while ((cmd = lds_flag(&sp.cmd)) == 0) __builtin_amdgcn_s_sleep(1);
+  if (cmd != 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const float lambda = sp.lambda;
+  if (mode != 1) {
+    const int r = lane >> 3;
+    propose_pose(T, S, S.H[lane], -S.b[r], lambda, lane, true);
+  } else if (lane == 0) {
+    propose_scale(T, S, lambda, true);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) lds_flag_set(&sp.done, 1);
 }
 
 // One LM step by a workgroup of >= 256 threads on the problem's partials: state and tracker descriptor
 // staged through LDS, fixed-order reduction, wave 0 advances the state machine and writes the state
 // back.  Shared by lm_kernel (LM_OP_STEP) and by the last-arriving workgroup of a fused eval kernel.
 // All threads of the workgroup must call it; S must be at this level (status RUNNING, lvl, mode).
+// sp != nullptr: speculative candidates (their partials sit spec_off floats behind the main ones).
 template <bool COH = false>
 __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const TrackerDev *Tg, LMState &S,
-                                              const float *partials_prob, LmShared &sh, int tid, int *status_out) {
+                                              const float *partials_prob, LmShared &sh, int tid, int *status_out,
+                                              LmSpecShared *sp = nullptr, int spec_off = 0) {
   constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
   static_assert(kS16 <= kThreads && kT16 <= kThreads, "one 16-byte block per thread");
   // one round trip: state block, tracker descriptor and the chunk partials together
@@ -1098,14 +1225,20 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
   // the pending evaluation was built for this level
   const int n_lvl = COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
-  reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh);
+  reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh.red);
+  if (sp) { // (garbage where no speculative candidate was evaluated: never looked at then)
+    reduce_partials_groups(partials_prob + spec_off, num_chunks(n_lvl), tid, sp->red);
+    if (tid == 0) sp->cmd = 0, sp->done = 0;
+  }
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
   if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
   __syncthreads();
+  if (sp && tid >= 64 && tid < 128) lm_spec_wave1(mode, sh.trk, sh.st, *sp, tid - 64);
   if (tid >= 64) return; // wave 0 carries on
   const int lane = tid;
-  reduce_partials_final(lane, sh);
-  lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane);
+  reduce_partials_final(lane, sh.red);
+  if (sp) reduce_partials_final(lane, sp->red);
+  lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane, sp);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1134,21 +1267,28 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
                                                         int partial_stride, int lvl, int *__restrict__ tickets,
-                                                        int *__restrict__ status_out) {
-  const int prob = blockIdx.y;
+                                                        int *__restrict__ status_out, int spec_nprob) {
+  // spec_nprob > 0: grid rows [spec_nprob, 2 spec_nprob) evaluate the problems' speculative candidates (where staged)
+  const bool cand = spec_nprob > 0 && (int)blockIdx.y >= spec_nprob;
+  const int prob = cand ? blockIdx.y - spec_nprob : blockIdx.y;
   // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
   const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
   if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
-  const DSM_GLOBAL EvalIn &in = S.in;
+  const bool have_eval = !cand || S.spec_valid != 0;
+  if (!FUSED && !have_eval) return;
+  const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
   const int n = in.n;
   const int P = pts_per_thread(n);
   const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
   // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
-  // contiguous band of the template (and therefore of the target rows it gathers from).
+  // contiguous band of the template (and therefore of the target rows it gathers from).  Levels of fewer than 8 chunks get
+  // exactly as many workgroups as chunks (a launch over hundreds of problems is bound by the workgroup dispatch rate there:
+  // rounding 2 chunks up to 8 made the coarsest level's launches 2.5x longer).
   const int per_xcd = gridDim.x >> 3;
-  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int chunk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
   float *partials_prob = partials + (size_t)prob * partial_stride;
-  if (chunk < nchunks) {
+  const int spec_off = partial_stride >> 1; // the speculative candidate's partials: second half of the problem's block
+  if (chunk < nchunks && have_eval) {
     EvalConsts c;
     c.pts = in.pts, c.img = in.img, c.n = n, c.w = in.w, c.h = in.h;
     c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
@@ -1157,7 +1297,7 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
     __shared__ float red[16][kNumSlots];
-    eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (size_t)chunk * kPartialStride);
+    eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
     if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
   } else if (!FUSED) {
     return;
@@ -1167,44 +1307,46 @@ __global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const 
     __syncthreads();
     if (threadIdx.x == 0) {
       const int t = atomicAdd(&tickets[prob], 1);
-      last = t == (int)gridDim.x - 1;
+      last = t == (int)gridDim.x * (spec_nprob > 0 ? 2 : 1) - 1; // both candidates' rows arrive at the same counter
       if (last) tickets[prob] = 0; // for the next launch
     }
     __syncthreads();
     if (!last) return;
     xwg_acquire(); // the other workgroups' partials were announced by their tickets
     __shared__ LmShared sh;
+    __shared__ LmSpecShared sps;
     lm_step_block(MODE, lvl, prob, trackers[prob], const_cast<LMState &>(states[prob]), partials_prob, sh, threadIdx.x,
-                  status_out);
+                  status_out, spec_nprob > 0 ? &sps : nullptr, spec_off);
   }
 }
 
 template <int MODE>
 static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
-                           float *partials, int partial_stride, int *tickets, int *status_out) {
+                           float *partials, int partial_stride, int *tickets, int *status_out, int spec_nprob) {
   if (tickets) { // fused LM step (never level 0: its kernel stays a pure evaluation)
     hipLaunchKernelGGL((eval_kernel<MODE, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out);
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
   } else if (lvl == 0)
     hipLaunchKernelGGL((eval_kernel<MODE, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out);
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
   else
     hipLaunchKernelGGL((eval_kernel<MODE, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out);
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
 }
 
 // tickets != nullptr (levels >= 1 only): the kernel also performs the LM step (no lm_kernel launch needed)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out) {
-  dim3 grid(grid_x, nprob);
+                 int partial_stride, int *tickets, int *status_out, bool spec) {
+  dim3 grid(grid_x, spec ? 2 * nprob : nprob);
+  const int spec_nprob = spec ? nprob : 0;
   if (lvl == 0) tickets = nullptr;
   if (mode == 0)
-    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
   else if (mode == 2)
-    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
   else
-    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out);
+    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
 }
 
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
@@ -1213,7 +1355,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
                                                         const float *__restrict__ partials, int partial_stride,
                                                         const StartInfo *__restrict__ start,
                                                         SingleOut *__restrict__ single_out,
-                                                        int *__restrict__ status_out) {
+                                                        int *__restrict__ status_out, int spec) {
   const int prob = blockIdx.x;
   const bool pose_like = mode != 1; // 0: frame tracking, 2: loop-closure pose -- same 8-DoF LM; 1: stereo scale
   const int tid = threadIdx.x;
@@ -1221,6 +1363,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   const TrackerDev &T = *trackers[prob];
   LMState &S = states[prob];
   __shared__ LmShared sh;
+  __shared__ LmSpecShared sps;
 
   if (op == LM_OP_START) {
     if (tid == 0) {
@@ -1240,7 +1383,9 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
         S.last_inners[i] = 0;
         S.min_res[i] = I.min_res[i];
         S.evals[i] = 0;
+        S.rounds[i] = 0;
       }
+      S.spec_valid = 0;
       S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
       S.status = ST_RUNNING;
       begin_level(T, S, I.coarsest);
@@ -1257,6 +1402,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
       S.is_scale = mode;
       S.status = ST_RUNNING;
       S.lvl = I.lvl;
+      S.spec_valid = 0;
       make_eval_any(T, S, mode, I.lvl, I.pose, I.aff, I.scale, I.cutoff);
     }
     return;
@@ -1272,17 +1418,18 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
     return;
   }
   if (op == LM_OP_STEP) {
-    lm_step_block(mode, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, status_out);
+    lm_step_block(mode, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, status_out,
+                  spec ? &sps : nullptr, partial_stride >> 1);
     return;
   }
 
   // LM_OP_SINGLE_FINISH: reduced sums -> rs, H, b of one evaluation (dsm_tracker_calc_res_*)
-  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(S.in.n), tid, sh);
+  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(S.in.n), tid, sh.red);
   __syncthreads();
   if (tid >= 64) return;
-  reduce_partials_final(lane, sh);
-  const double *sums = sh.sums;
-  const long long *isums = sh.isums;
+  reduce_partials_final(lane, sh.red);
+  const double *sums = sh.red.sums;
+  const long long *isums = sh.red.isums;
   double rs[6];
   build_rs(sums, isums, rs);
   const int n_warped = (int)isums[2];
@@ -1373,10 +1520,10 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
         eval_chunk<MODE, false>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
       __syncthreads(); // red[] is reused by the next round
     }
-    reduce_partials_groups(&part[0][0], nch, tid, sh);
+    reduce_partials_groups(&part[0][0], nch, tid, sh.red);
     __syncthreads();
     if (tid < 64) {
-      reduce_partials_final(tid, sh);
+      reduce_partials_final(tid, sh.red);
       lm_step_wave0(MODE, lvl, sh.trk, sh.st, sh, tid);
     }
     __syncthreads(); // the state (status, level, next evaluation inputs) is read by all waves
@@ -1589,9 +1736,9 @@ void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const Tracker
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
-               SingleOut *single_out, int *status_out) {
+               SingleOut *single_out, int *status_out, bool spec) {
   hipLaunchKernelGGL(lm_kernel, dim3(nprob), dim3(kLmThreads), 0, s, mode, op, lvl, trackers, states, partials,
-                     partial_stride, start, single_out, status_out);
+                     partial_stride, start, single_out, status_out, spec ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -83,6 +83,14 @@ typedef struct dsm_params {
                                          of at least 32 problems with at most 32768 finest-level chunks in all (beyond
                                          that the lock-step launches are faster), 2 always.  Scheduling only -- results
                                          are bit-identical. */
+  int speculate;                      /* launch-per-step form: next to the LM proposal being evaluated, the proposal that
+                                         FOLLOWS IF IT IS REJECTED (same H, b, pose; lambda x 4, TrackerAndScaler.cpp:583-585)
+                                         is evaluated in the same launch, so a rejected step -- about half of all steps on
+                                         the coarse levels -- costs no launch of its own.  Same evaluations, decisions and
+                                         per-level evaluation counts as the sequential loop; the speculative evaluation of
+                                         an ACCEPTED step is discarded (not counted).  0 never, 1 (default) on levels of at most
+                                         8192 template points (where launches are latency-bound and rejections come in runs),
+                                         2 on every level.  Scheduling only -- results are bit-identical. */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */

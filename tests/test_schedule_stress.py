@@ -9,11 +9,11 @@ from _scenes import S, hip_tracker, make_scene
 pytestmark = pytest.mark.gpu
 
 
-def _run(ctx, scs, fuse, ns, coarse, queue=0):
+def _run(ctx, scs, fuse, ns, coarse, queue=0, spec=0):
     from direct_stereo_slam_amd.tracker import default_params
 
     p = default_params()
-    p.fuse_lm, p.persistent_coarse, p.work_queue = fuse, coarse, queue
+    p.fuse_lm, p.persistent_coarse, p.work_queue, p.speculate = fuse, coarse, queue, spec
     ctx.set_streams(ns)
     out = []
     for parity in (0, 1):  # two batches of equal image size
@@ -32,10 +32,35 @@ def test_every_schedule_gives_identical_results(ctx):
     try:
         ref = _run(ctx, scs, 0, 1, 0)
         for it in range(12):
-            for fuse, ns, coarse, queue in ((2, 1, 0, 0), (2, 2, 0, 0), (1, 3, 0, 0), (0, 2, 4096, 0), (2, 2, 2048, 0), (0, 1, 0, 2), (1, 2, 0, 2)):
-                got = _run(ctx, scs, fuse, ns, coarse, queue)
+            for fuse, ns, coarse, queue, spec in ((2, 1, 0, 0, 0), (2, 2, 0, 0, 0), (1, 3, 0, 0, 0), (0, 2, 4096, 0, 0), (2, 2, 2048, 0, 0),
+                                                  (0, 1, 0, 2, 0), (1, 2, 0, 2, 0),
+                                                  # speculative second candidate: two-kernel form, fused form, with the other switches
+                                                  (0, 1, 0, 0, 2), (2, 2, 0, 0, 2), (1, 3, 0, 0, 1), (0, 2, 4096, 0, 2), (1, 2, 0, 2, 2)):
+                got = _run(ctx, scs, fuse, ns, coarse, queue, spec)
                 for g, r in zip(got, ref):
                     for a, b in zip(g, r):
-                        assert np.array_equal(a, b, equal_nan=True), (it, fuse, ns, coarse, queue)
+                        assert np.array_equal(a, b, equal_nan=True), (it, fuse, ns, coarse, queue, spec)
     finally:
         ctx.set_streams(1)
+
+
+def test_speculation_keeps_the_evaluation_counts_and_saves_launches(ctx):
+    """dsm_params.speculate: same per-level evaluation counts as the sequential loop (= the oracle's), fewer launches"""
+    from _scenes import oracle_tracker
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene("medium", seed=31)
+    orc = oracle_tracker(sc)
+    orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    want = orc.eval_counts()[0][:sc.nl]
+    launches = {}
+    for spec in (0, 2):
+        p = default_params()
+        p.speculate, p.fuse_lm = spec, 0
+        trk = hip_tracker(ctx, sc, p)
+        for _ in range(3):  # let the launch schedule settle
+            trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        st = ctx.stats()
+        assert list(st.evals)[:sc.nl] == want
+        launches[spec] = sum(st.launches)
+    assert launches[2] < launches[0]
