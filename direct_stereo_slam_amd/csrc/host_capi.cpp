@@ -3,8 +3,20 @@
 // Plain C++; no device code.
 #include "../../include/dsm_hotpath.h"
 #include <algorithm>
+#include <cstdio>
 
 extern "C" {
+
+// LoopHandler::savePose, LoopHandler.cpp:59-80: one line per loop frame, "incoming_id x y z", std::setprecision(6) on a default
+// (%g-style) stream -- the dslam.txt / sodso.txt trajectory files the evaluation scripts of the reference read
+int dsm_write_trajectory(const char *path, int n, const int *incoming_ids, const double *t_wc) {
+  if (!path || n < 0 || (n && (!incoming_ids || !t_wc))) return DSM_ERR_INVALID;
+  FILE *f = fopen(path, "w");
+  if (!f) return DSM_ERR_STATE;
+  for (int i = 0; i < n; i++)
+    fprintf(f, "%d %.6g %.6g %.6g\n", incoming_ids[i], t_wc[3 * i], t_wc[3 * i + 1], t_wc[3 * i + 2]);
+  return fclose(f) == 0 ? DSM_OK : DSM_ERR_STATE;
+}
 
 // inner loop of search_sc, search_place.h:67-79: float accumulator, double products
 float dsm_sc_distance(const int *a_idx, const double *a_val, int na, const int *b_idx, const double *b_val, int nb,

@@ -249,3 +249,11 @@ def loop_descriptors_batch(ctx, jobs, lidar_range, num_s=60, num_r=20, scanconte
             r.update(ringkey=o["ringkey"], sig_idx=o["sig_idx"][:ns].copy(), sig_val=o["sig_val"][:ns].copy(), tfm_pca_rig=o["tfm"].reshape(4, 4))
         res.append(r)
     return res
+
+
+def write_trajectory(path, incoming_ids, t_wc):
+    """dslam.txt / sodso.txt writer of LoopHandler::savePose (LoopHandler.cpp:59-80) through the C ABI"""
+    ids = np.ascontiguousarray(incoming_ids, np.int32)
+    t = np.ascontiguousarray(t_wc, np.float64).reshape(-1, 3)
+    assert len(ids) == len(t)
+    check(_lib.load().dsm_write_trajectory(str(path).encode(), len(ids), ids.ctypes.data_as(c_int_p), t.ctypes.data_as(_lib.c_double_p)))

@@ -390,6 +390,11 @@ int dsm_search_sc(const int *sig_idx, const double *sig_val, int n_sig, int n_ca
                   const int *cand_ids, const int *const *cand_idx, const double *const *cand_val,
                   const int *cand_n, int sc_width, int *res_idx, float *res_diff);
 
+/* replaces the file output of LoopHandler::savePose (LoopHandler.cpp:59-80): writes n lines "incoming_id x y z" with six
+ * significant digits (std::setprecision(6)) -- the dslam.txt (optimised poses, tfm_w_c.translation()) and sodso.txt
+ * (trans_w_c_orig) trajectory surface of the reference.  t_wc: n x 3 doubles. */
+int dsm_write_trajectory(const char *path, int n, const int *incoming_ids, const double *t_wc);
+
 #ifdef __cplusplus
 }
 #endif

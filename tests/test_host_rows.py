@@ -142,3 +142,19 @@ def test_generate_spherical_points_matches_oracle(built):
     # degenerate inputs
     k0, s0, p0 = generate_spherical_points(kf_ids[:0], poses[:0], cur_cw, rng_m, pt_kf[:0], xyz[:0])
     assert len(k0) == 0 and len(s0) == 0 and p0.shape == (0, 3)
+
+
+def test_trajectory_writer_matches_savepose_format(built, tmp_path):
+    """LoopHandler::savePose (LoopHandler.cpp:59-80): `incoming_id x y z`, operator<< of doubles at setprecision(6)"""
+    from direct_stereo_slam_amd.ringdb import write_trajectory
+
+    rng = np.random.default_rng(3)
+    ids = np.array([0, 3, 4, 9, 1000, 123456])
+    t = np.vstack([rng.normal(0, 100, (4, 3)), [[1e-7, -2.5e6, 0.0]], [[1.0, 2.0, 3.0]]])
+    f = tmp_path / "dslam.txt"
+    write_trajectory(f, ids, t)
+    lines = f.read_text().splitlines()
+    assert len(lines) == len(ids)
+    for line, i, p in zip(lines, ids, t):
+        assert line == f"{i} {p[0]:.6g} {p[1]:.6g} {p[2]:.6g}"  # a default C++ stream prints %g-style with 6 significant digits
+    assert lines[-1] == "123456 1 2 3" and lines[-2].split()[1:] == ["1e-07", "-2.5e+06", "0"]

@@ -168,7 +168,7 @@ def test_replay_trajectory_matches_cpu_reference(ctx):
     # trajectory surface of the reference (dslam.txt, 6 significant digits): same ids, coordinates within 0.5 mm
     lo, lg = write_dslam(traj_o).splitlines(), write_dslam(traj_g).splitlines()
     assert len(lo) == len(lg) == len(path)
-    for a, b in zip(lo, lg):
+    for a, b in zip(lo, lg):  # (the C ABI writer of the same format: dsm_write_trajectory, tests/test_host_rows.py)
         np.testing.assert_allclose([float(x) for x in a.split()[1:]], [float(x) for x in b.split()[1:]], atol=5e-4)
 
 
