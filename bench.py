@@ -631,7 +631,8 @@ def bench_tracking(args):
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": workload_label(args, wl, m["n0"]), "replicas": world,
+        "config": {"workload": workload_label(args, wl, m["n0"]), "name": wl["config"], "w": wl["w"], "h": wl["h"], "levels": wl["nl"], "n0": m["n0"],
+                   "replicas": world,
                    "inputs": "host images uploaded and pyramids built inside the timed region (secondary figure)" if args.with_upload else "resident in HBM",
                    **m["detail"]},
         "roofline": m["roofline"],

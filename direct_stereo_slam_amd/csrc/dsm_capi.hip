@@ -1177,6 +1177,31 @@ int dsm_optimize_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, fl
   return DSM_OK;
 }
 
+// The untrapped branch of FrontEnd::optimizeScale (FrontEnd.cpp:995-1003): optimizeScale from every initial guess, keep the
+// smallest positive error (the first one on ties).  The guesses are independent problems on the same template and right
+// image: ONE batched call instead of eight sequential ones.
+int dsm_tracker_optimize_scale_guesses(dsm_tracker *t, int n_guesses, const float *scale_guesses, int coarsest_lvl, float *scale_out,
+                                       float *err_out, float *scales_all, float *errs_all) {
+  if (!t || n_guesses < 1 || !scale_guesses || !scale_out || !err_out) return invalid("dsm_tracker_optimize_scale_guesses: bad argument");
+  std::vector<dsm_tracker *> ts((size_t)n_guesses, t);
+  std::vector<float> sc(scale_guesses, scale_guesses + n_guesses), er((size_t)n_guesses, 0.f);
+  const int rc = dsm_optimize_scale_batch(t->ctx, n_guesses, ts.data(), sc.data(), coarsest_lvl, er.data());
+  if (rc) return rc;
+  float new_scale = 1.0f, scale_error = -1.0f; // :991-992
+  for (int i = 0; i < n_guesses; i++) {
+    const float cur_error = er[i];
+    if (cur_error > 0 && (scale_error < 0 || scale_error > cur_error)) { // :998-1001 (NaN compares false: rejected)
+      scale_error = cur_error;
+      new_scale = sc[i];
+    }
+    if (scales_all) scales_all[i] = sc[i];
+    if (errs_all) errs_all[i] = er[i];
+  }
+  *scale_out = new_scale;
+  *err_out = scale_error;
+  return DSM_OK;
+}
+
 int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl, float *err_out) {
   if (!t) return invalid("null tracker");
   dsm_tracker *ts[1] = {t};

@@ -121,6 +121,16 @@ public:
     return err;
   }
 
+  // the untrapped branch of FrontEnd::optimizeScale (FrontEnd.cpp:995-1003) as ONE batched call: optimizeScale from every
+  // initial guess, the smallest positive error wins (the first on ties); returns scale_error, new_scale by reference
+  float optimizeScaleGuesses(const FrameView &fh1, const std::vector<float> &scale_guess, float &new_scale, int coarsestLvl) {
+    upload(fh1, DSM_SLOT_NEW_RIGHT);
+    float err = -1.0f;
+    check(dsm_tracker_optimize_scale_guesses(t_, (int)scale_guess.size(), scale_guess.data(), coarsestLvl, &new_scale, &err, nullptr, nullptr),
+          "optimizeScaleGuesses");
+    return err;
+  }
+
   dsm_tracker *handle() { return t_; }
 
   // act as pure output (TrackerAndScaler.h:59-64)

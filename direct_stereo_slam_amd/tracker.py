@@ -287,6 +287,15 @@ class TrackerAndScaler:
         check(self.L.dsm_tracker_optimize_scale(self.h, C.byref(s), coarsestLvl, C.byref(err)))
         return err.value, s.value
 
+    def optimizeScaleGuesses(self, guesses, coarsestLvl):
+        """the untrapped branch of FrontEnd::optimizeScale (FrontEnd.cpp:995-1003) as one batched call: returns
+        (scale_error, new_scale, all_errors, all_scales)"""
+        g = np.ascontiguousarray(guesses, np.float32)
+        s, e = C.c_float(), C.c_float()
+        sa, ea = np.zeros(len(g), np.float32), np.zeros(len(g), np.float32)
+        check(self.L.dsm_tracker_optimize_scale_guesses(self.h, len(g), _fp(g), coarsestLvl, C.byref(s), C.byref(e), _fp(sa), _fp(ea)))
+        return e.value, s.value, ea, sa
+
     def reduction_geometry(self, lvl, n):
         t, p, c = C.c_int(), C.c_int(), C.c_int()
         check(self.L.dsm_reduction_geometry(self.h, lvl, n, C.byref(t), C.byref(p), C.byref(c)))

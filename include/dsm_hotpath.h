@@ -223,6 +223,12 @@ int dsm_tracker_track(dsm_tracker *t, double pose_io[7], double aff_io[2], int c
                       int *good);
 /* replaces TrackerAndScaler::optimizeScale (TrackerAndScaler.cpp:854-964); err_out = return value */
 int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl, float *err_out);
+/* replaces the untrapped branch of FrontEnd::optimizeScale (FrontEnd.cpp:995-1003): optimizeScale from each of n_guesses
+ * initial scales (the reference's list: 0.1, 1, 5, 10, 15, 25, 30, 50) as ONE batched call on the tracker's template and right
+ * frame; *scale_out / *err_out = the result with the smallest positive error (the first one on ties; 1.0 / -1 when none is
+ * positive), scales_all / errs_all (may be NULL) = every guess's result in order. */
+int dsm_tracker_optimize_scale_guesses(dsm_tracker *t, int n_guesses, const float *scale_guesses, int coarsest_lvl,
+                                       float *scale_out, float *err_out, float *scales_all, float *errs_all);
 
 /* Batched forms: n independent trackers of one context advance in lock-step launches
  * (SURVEY.md section 7 "throughput mode").  Arrays are n x 7 / n x 2 / n x DSM_MAX_LEVELS / n x 3. */

@@ -558,3 +558,24 @@ def test_upload_image_from_pinned_memory(ctx):
     buf[...] = -1.0  # must not affect the pyramid being built
     for lvl in range(sc.nl):
         np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
+
+
+def test_scale_guess_list_as_one_batch_equals_the_sequential_loop(ctx):
+    """FrontEnd::optimizeScale, untrapped branch (FrontEnd.cpp:995-1003): the eight initial guesses as ONE batched call on the
+    same tracker vs the reference's sequential loop on the oracle -- same winner, same scale and error"""
+    for idepth_scale in (1.0, 7.0):  # template depths off by a factor: the winner is no longer the guess 1
+        sc = make_scene("small", seed=41, idepth_scale=idepth_scale)
+        orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+        guesses = [0.1, 1, 5, 10, 15, 25, 30, 50]
+        new_scale, scale_error, all_o = 1.0, -1.0, []
+        for g in guesses:
+            err, s = orc.optimize_scale(g, sc.nl - 1)
+            all_o.append((err, s))
+            if err > 0 and (scale_error < 0 or scale_error > err):
+                scale_error, new_scale = err, s
+        err_g, s_g, errs, scales = trk.optimizeScaleGuesses(guesses, sc.nl - 1)
+        for (eo, so), eg, sg in zip(all_o, errs, scales):
+            assert abs(sg - so) < 1e-4 * max(1.0, abs(so)) and (abs(eg - eo) < 1e-3 * eo or (np.isnan(eo) and np.isnan(eg)))
+        assert abs(s_g - new_scale) < 1e-4 * max(1.0, new_scale) and abs(err_g - scale_error) < 1e-3 * scale_error
+        # (which guess wins is decided by the last bits when several guesses reach the same minimum -- here 5, 10 and 15 end at
+        # the same scale with errors equal to 1e-6; the winner's scale and error are what FrontEnd uses)

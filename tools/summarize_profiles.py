@@ -9,9 +9,9 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(root, "profiles")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")  # on a gpurun box only gpurun_out/ travels back
 os.makedirs(dst, exist_ok=True)
-L0 = "eval_kernel<0, 0, true, false>"  # level-0 pose evaluation (MODE 0, AOS3, LVL0, not fused)
+L0 = "eval_kernel<0, true, false>"  # level-0 pose evaluation (MODE 0, LVL0, not fused)
 
 
 def last_json(path):
@@ -23,7 +23,8 @@ def last_json(path):
 
 bench = last_json(os.path.join(src, "bench_default.json"))
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
-for name in ("bench_b1", "bench_ringkey", "membw"):
+for name in ("bench_b1", "bench_b1_S1", "bench_ringkey", "bench_ringkey_q1", "membw", "bench_cfg_S3", "bench_cfg_sparse", "bench_queue", "bench_queue_b256",
+             "bench_b256", "bench_b1024", "bench_evals_only", "bench_with_upload_u8_pinned_overlap"):
     f = os.path.join(src, name + ".log")
     if os.path.exists(f):
         json.dump(last_json(f), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
@@ -69,7 +70,7 @@ if trace:
     B = cfg["frames_in_flight_per_gpu"]
     bytes_eval = bench["roofline"]["bytes_per_launch"] * bench["roofline"]["launches"] / l0["evals"]
     summary = {
-        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu --no-six-level",
+        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu --no-second-leg",
         "kernel": "dsm::" + L0,
         "dispatches": len(d), "dispatches_with_work": len(work),
         "avg_ns_dispatches_with_work": sum(work) / max(1, len(work)),
@@ -109,8 +110,7 @@ if fetch is not None:
     pl0 = [k for k in pb["config"]["pose_eval_kernels_by_level"] if k["lvl"] == 0][0]
     steps = pb["steps"] + pb["warmup"] + 1
     n_evals = pl0["evals"] * steps
-    n0 = int(pb["config"]["workload"].split("n0=")[1].split(",")[0])
-    w, h = 1232, 368
+    n0, w, h = pb["config"]["n0"], pb["config"]["w"], pb["config"]["h"]
     alg = n_evals * (16 * n0 + 12 * w * h)
     raw_fetch = fetch * 1024.0  # FETCH_SIZE / WRITE_SIZE count kilobytes
     # MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced
@@ -118,8 +118,8 @@ if fetch is not None:
     corrected = raw_fetch + 0.5 * n_evals * 16 * n0
     wr = (write or 0.0) * 1024.0
     out = {
-        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-six-level --steps 2 --warmup 1",
-        "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
+        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-second-leg --steps 2 --warmup 1",
+        "config": pb["config"]["name"], "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; tap gathers (12-byte texels) taken as reported",
         "hbm_read_bytes_corrected": corrected, "hbm_bytes_corrected": corrected + wr,
