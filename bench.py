@@ -70,6 +70,7 @@ def parse():
                     help="dsm_params.work_queue: 0 (default here) launch-per-step form -- its dominant kernel, the level-0 evaluation, is "
                          "timed per launch for the roofline; 1 the library's automatic rule (batches >= 32); 2 the whole call as one "
                          "launch of persistent workgroups (its roofline is the whole-call figure)")
+    ap.add_argument("--separate-calls", action="store_true", help="dsm_track_batch then dsm_optimize_scale_batch instead of the one dsm_track_and_scale_batch call per step")
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
@@ -264,7 +265,7 @@ def build_workload(args, ctx, config):
         if b < args.cpu_frames:
             host.append((tpl, new, right))
     return dict(config=config, w=w, h=h, nl=nl, K=K, T=T, trackers=trackers, gts=np.array(gts), host=host, params=params,
-                images=images, single_uploads=args.single_uploads, overlap=args.overlap, primed=False)
+                images=images, single_uploads=args.single_uploads, overlap=args.overlap, primed=False, separate_calls=args.separate_calls)
 
 
 def one_step(ctx, wl, kf_idx, with_upload=False):
@@ -292,11 +293,18 @@ def one_step(ctx, wl, kf_idx, with_upload=False):
             trks = list(wl["trackers"]) + [wl["trackers"][i] for i in kf_idx]
             ctx.upload_images(trks, [0] * B + [1] * len(kf_idx), [wl["images"][i][0] for i in range(B)] + [wl["images"][i][1] for i in kf_idx])
     poses0 = np.tile(S.IDENTITY_POSE, (B, 1))
-    good, poses, affs, last, flow = ctx.track_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1)
-    st_track = ctx.stats()
     kf = [wl["trackers"][i] for i in kf_idx]
-    err, sc = ctx.optimize_scale_batch(kf, np.ones(len(kf)), wl["nl"] - 1)
-    st_scale = ctx.stats()
+    if wl.get("separate_calls") or wl["params"].work_queue >= 1:
+        # two calls (the work-queue form is one kernel per call and mode)
+        good, poses, affs, last, flow = ctx.track_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1)
+        st_track = ctx.stats()
+        err, sc = ctx.optimize_scale_batch(kf, np.ones(len(kf)), wl["nl"] - 1)
+        st_scale = ctx.stats()
+    else:
+        # one call: the keyframes' scale optimisations are independent of the frames' tracking and run beside it
+        good, poses, affs, last, flow, err, sc = ctx.track_and_scale_batch(wl["trackers"], poses0, np.zeros((B, 2)), wl["nl"] - 1, kf, np.ones(len(kf)))
+        st_track, st_scale = ctx.stats(), ctx.stats2()
+        st_scale.total_ms = 0.0  # (one call: its time is the tracking segment's total)
     return good, poses, err, sc, st_track, st_scale
 
 
@@ -555,7 +563,17 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
         dev = "cuda" if _BACKEND == "nccl" else "cpu"
         uid = uid.to(dev)
         dist.broadcast(uid, 0)
-        comm = Comm(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+        ok, why = 1, ""
+        try:
+            comm = Comm(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, repr(e)
+        # all ranks go on, or none: a rank that left the leg alone would leave the others waiting in a collective
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            db.close()
+            return {"error": "communicator creation failed on at least one rank" + (": " + why if why else "")}
     dq = torch.from_numpy(qs).cuda()
     out = torch.empty((args.rk_q, 3), dtype=torch.int64, device="cuda")
     res = {}

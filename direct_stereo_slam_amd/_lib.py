@@ -109,6 +109,9 @@ SYMBOLS = {
     "dsm_tracker_track": (C.c_int, [_vp, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
     "dsm_tracker_optimize_scale": (C.c_int, [_vp, c_float_p, C.c_int, c_float_p]),
     "dsm_tracker_optimize_scale_guesses": (C.c_int, [_vp, C.c_int, c_float_p, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "dsm_track_and_scale_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p,
+                                           C.c_int, C.POINTER(_vp), c_float_p, c_float_p]),
+    "dsm_context_get_stats2": (C.c_int, [_vp, C.POINTER(Stats)]),
     "dsm_track_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_double_p, c_double_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
     "dsm_optimize_scale_batch": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_float_p, C.c_int, c_float_p]),
     "dsm_tracker_ref_frame_id": (C.c_int, [_vp]),

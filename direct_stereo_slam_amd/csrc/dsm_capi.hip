@@ -266,6 +266,8 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipFree(ctx->d_stage);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->join_events) hipEventDestroy(ev);
+  if (ctx->companion_stream) hipStreamDestroy(ctx->companion_stream);
+  if (ctx->companion_event) hipEventDestroy(ctx->companion_event);
   for (hipStream_t st : ctx->extra_streams) hipStreamDestroy(st);
   hipEventDestroy(ctx->fork_event);
   hipEventDestroy(ctx->copy_event);
@@ -840,26 +842,27 @@ static int check_ready(dsm_tracker *t, int mode) {
   return DSM_OK;
 }
 
-static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode) {
-  if (!ctx || n <= 0 || !ts) return invalid("batch: bad argument");
+// ts: n trackers of a call in mode `mode`, followed by n2 trackers of the companion segment in mode `mode2`
+static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode, int n2 = 0, int mode2 = 1) {
+  if (!ctx || n <= 0 || n2 < 0 || !ts) return invalid("batch: bad argument");
   DSM_HIP(hipSetDevice(ctx->device));
   int ps = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < n + n2; i++) {
     dsm_tracker *t = ts[i];
     if (!t || t->ctx != ctx) return invalid("batch: tracker does not belong to this context");
     if (t->w != ts[0]->w || t->h != ts[0]->h || t->nlevels != ts[0]->nlevels)
       return invalid("batch: all trackers must share image size and levels");
-    int rc = check_ready(t, mode);
+    int rc = check_ready(t, i < n ? mode : mode2);
     if (rc) return rc;
     const int need = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
     if (need > ps) ps = need;
   }
-  int rc = ensure_batch_capacity(ctx, n, ps);
+  int rc = ensure_batch_capacity(ctx, n + n2, ps);
   if (rc) return rc;
-  rc = sync_descs(ctx, ts, n);
+  rc = sync_descs(ctx, ts, n + n2);
   if (rc) return rc;
-  for (int i = 0; i < n; i++) ctx->h_tracker_ptrs[i] = ts[i]->d_desc;
-  DSM_HIP(hipMemcpyAsync(ctx->d_tracker_ptrs, ctx->h_tracker_ptrs, sizeof(TrackerDev *) * n, hipMemcpyHostToDevice, ctx->stream));
+  for (int i = 0; i < n + n2; i++) ctx->h_tracker_ptrs[i] = ts[i]->d_desc;
+  DSM_HIP(hipMemcpyAsync(ctx->d_tracker_ptrs, ctx->h_tracker_ptrs, sizeof(TrackerDev *) * (n + n2), hipMemcpyHostToDevice, ctx->stream));
   return DSM_OK;
 }
 
@@ -872,23 +875,32 @@ static hipEvent_t get_event(dsm_context *ctx, size_t idx) {
   return ctx->ev_pool[idx];
 }
 
-// runs the device LM state machine for a batch (mode 0 = trackNewestCoarse, 1 = optimizeScale)
-static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode, int coarsest) {
+// runs the device LM state machine for a batch (mode 0 = trackNewestCoarse, 1 = optimizeScale, 2 = loop-closure pose).
+// n2 > 0: problems [n, n + n2) form a COMPANION segment in mode2 (dsm_track_and_scale_batch: the keyframes' scale
+// optimisations next to the frames' tracking).  The two segments are independent problems; the companion's launches go to a
+// stream of their own, so its latency-bound chains of small launches run under the main segment's kernels instead of after
+// them.  Launch-per-step form only.  Statistics of the companion: ctx->stats2.
+static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode, int coarsest, int n2 = 0, int mode2 = 1) {
   const int nlevels = ts[0]->nlevels;
   if (coarsest < 0 || coarsest >= nlevels) return invalid("coarsest level out of range"); // :457 / :856
   const dsm_params &P = ts[0]->params;
+  const int N = n + n2;
   memset(&ctx->stats, 0, sizeof ctx->stats);
+  memset(&ctx->stats2, 0, sizeof ctx->stats2);
   DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
-  DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo) * n, hipMemcpyHostToDevice, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo) * N, hipMemcpyHostToDevice, ctx->stream));
   launch_lm(ctx->stream, mode, LM_OP_START, coarsest, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, ctx->d_status);
+  if (n2 > 0)
+    launch_lm(ctx->stream, mode2, LM_OP_START, coarsest, n2, ctx->d_tracker_ptrs + n, ctx->d_states + n,
+              ctx->d_partials + (size_t)n * ctx->partial_stride, ctx->partial_stride, ctx->d_start + n, nullptr, ctx->d_status + 2 * n);
   // Work-queue form: one launch of persistent workgroups for the whole call (queue_kernel).  Scheduling only:
   // results are bit-identical to the launch-per-step form below.
   // Default rule (measured): the queue form wins while the batch is large enough to fill the
   // persistent workgroups and small enough that its per-item cost (a few microseconds per chunk) does not add up --
   // up to about 32 k finest-level chunks per call (256 dense KITTI frames; thousands of sparse ones).
-  bool use_queue = P.work_queue >= 2;
-  if (P.work_queue == 1 && n >= 32) {
+  bool use_queue = P.work_queue >= 2 && n2 == 0;
+  if (P.work_queue == 1 && n >= 32 && n2 == 0) {
     long long chunks0 = 0;
     for (int i = 0; i < n; i++) chunks0 += num_chunks(ts[i]->desc.lv[0].n);
     use_queue = chunks0 <= 32768;
@@ -943,7 +955,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   bool spec[DSM_MAX_LEVELS];
   for (int L = 0; L < nlevels; L++) {
     int max_chunks = 1, max_it = 0, max_n = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < N; i++) {
       const int c = num_chunks(ts[i]->desc.lv[L].n);
       if (c > max_chunks) max_chunks = c;
       if (ts[i]->desc.lv[L].n > max_n) max_n = ts[i]->desc.lv[L].n;
@@ -957,7 +969,11 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     // frame -1 % when applied to every level (the fine levels end on their first rejection), DESIGN.md section 4.3.
     spec[L] = P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192);
   }
-  int *sched = ctx->sched[mode];
+  int *sched = ctx->sched[mode], *sched2 = ctx->sched[mode2];
+  if (n2 > 0 && !ctx->companion_stream) {
+    DSM_HIP(hipStreamCreateWithFlags(&ctx->companion_stream, hipStreamNonBlocking));
+    DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
+  }
   int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
   if (ng > n) ng = n;
   while ((int)ctx->extra_streams.size() < ng - 1) {
@@ -968,8 +984,8 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     ctx->join_events.push_back(ev);
   }
-  int top = coarsest;
-  if (!use_queue && P.persistent_coarse > 0) {
+  int top = coarsest, top2 = n2 > 0 ? coarsest : -1;
+  if (!use_queue && P.persistent_coarse > 0 && n2 == 0) {
     // Small levels: the whole LM loop in one launch per problem (coarse_kernel).  It hands a problem
     // back (still RUNNING) at the first level with more than coarse_max_points() template points.
     const int max_pts = P.persistent_coarse < coarse_max_points() ? P.persistent_coarse : coarse_max_points();
@@ -984,15 +1000,35 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         }
   }
   for (int pass = 0; !use_queue; pass++) {
-    if (ng > 1) { // fork: the extra streams start after everything enqueued on the main stream so far
+    if (ng > 1 || top2 >= 0) { // fork: the extra streams start after everything enqueued on the main stream so far
       DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
       for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
+      if (top2 >= 0) DSM_HIP(hipStreamWaitEvent(ctx->companion_stream, ctx->fork_event, 0));
     }
-    for (int L = top; L >= 0; L--) {
+    for (int L = top > top2 ? top : top2; L >= 0; L--) {
       int steps = P.adaptive_schedule ? sched[L] << (pass > 3 ? 3 : pass) : worst[L];
       if (steps > worst[L]) steps = worst[L];
       if (steps < 1) steps = 1;
-      for (int k = 0; k < steps; k++) {
+      if (L > top) steps = 0;
+      int steps2 = 0;
+      if (L <= top2) {
+        steps2 = P.adaptive_schedule ? sched2[L] << (pass > 3 ? 3 : pass) : worst[L];
+        if (steps2 > worst[L]) steps2 = worst[L];
+        if (steps2 < 1) steps2 = 1;
+      }
+      for (int k = 0; k < steps2 || k < steps; k++) {
+        if (k < steps2) { // the companion segment: one (evaluate, step) pair on its own stream
+          hipStream_t cs = ctx->companion_stream;
+          const bool fused2 = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n2 <= 8));
+          launch_eval(cs, mode2, L, grid_x[L], n2, ctx->d_tracker_ptrs + n, ctx->d_states + n,
+                      ctx->d_partials + (size_t)n * ctx->partial_stride, ctx->partial_stride, fused2 ? ctx->d_tickets + n : nullptr,
+                      ctx->d_status + 2 * n, spec[L]);
+          if (!fused2)
+            launch_lm(cs, mode2, LM_OP_STEP, L, n2, ctx->d_tracker_ptrs + n, ctx->d_states + n,
+                      ctx->d_partials + (size_t)n * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr, ctx->d_status + 2 * n,
+                      spec[L]);
+        }
+        if (k >= steps) continue;
         // Stream groups: the batch is split into `ng` contiguous groups, each with its own HIP stream.
         // A group's lm_kernel (one small workgroup per problem) and its small-level eval kernels leave
         // most of the chip idle; another group's kernels fill it.  Per-problem results are unchanged.
@@ -1021,25 +1057,32 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         }
       }
       ctx->stats.launches[L] += steps;
+      ctx->stats2.launches[L] += steps2;
     }
     DSM_HIP(hipGetLastError()); // launch-configuration errors of the kernels enqueued above
     for (int g = 1; g < ng; g++) { // join
       DSM_HIP(hipEventRecord(ctx->join_events[g - 1], ctx->extra_streams[g - 1]));
       DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->join_events[g - 1], 0));
     }
-    DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (top2 >= 0) {
+      DSM_HIP(hipEventRecord(ctx->companion_event, ctx->companion_stream));
+      DSM_HIP(hipStreamWaitEvent(ctx->stream, ctx->companion_event, 0));
+    }
+    DSM_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * 2 * N, hipMemcpyDeviceToHost, ctx->stream));
     DSM_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stats.polls++;
-    top = -1;
+    top = top2 = -1;
     for (int i = 0; i < n; i++)
       if (ctx->h_status[2 * i] == ST_RUNNING && ctx->h_status[2 * i + 1] > top) top = ctx->h_status[2 * i + 1];
-    if (top < 0) break;
+    for (int i = n; i < N; i++)
+      if (ctx->h_status[2 * i] == ST_RUNNING && ctx->h_status[2 * i + 1] > top2) top2 = ctx->h_status[2 * i + 1];
+    if (top < 0 && top2 < 0) break;
     if (pass > 64) {
       set_error("internal: LM state machine did not terminate within the launch bound");
       return DSM_ERR_STATE;
     }
   }
-  DSM_HIP(hipMemcpyAsync(ctx->h_states, ctx->d_states, sizeof(LMState) * n, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(ctx->h_states, ctx->d_states, sizeof(LMState) * N, hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   if (use_queue) {
@@ -1088,20 +1131,23 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       ctx->stats.eval_kernel_union_ms[l] = busy;
     }
   }
-  int need[DSM_MAX_LEVELS] = {0};
-  for (int i = 0; i < n; i++) {
+  int need[DSM_MAX_LEVELS] = {0}, need2[DSM_MAX_LEVELS] = {0};
+  ctx->stats2.total_ms = ms;
+  for (int i = 0; i < N; i++) {
     const LMState &S = ctx->h_states[i];
     if (S.status == ST_RUNNING) {
       set_error("internal: LM state machine did not terminate within the launch bound");
       return DSM_ERR_STATE;
     }
+    dsm_stats &st = i < n ? ctx->stats : ctx->stats2;
+    int *nd = i < n ? need : need2;
     for (int l = 0; l < nlevels; l++) {
-      if ((int)S.rounds[l] > need[l]) need[l] = (int)S.rounds[l]; // launches this problem needed at the level
-      ctx->stats.evals[l] += S.evals[l];
+      if ((int)S.rounds[l] > nd[l]) nd[l] = (int)S.rounds[l]; // launches this problem needed at the level
+      st.evals[l] += S.evals[l];
       // compulsory bytes of one evaluation: the template once + the target image once, or, for a sparse template,
       // the four 12-byte taps of every point if that is less
       const long long nl = ts[i]->desc.lv[l].n, img = 12ll * (ts[i]->w >> l) * (ts[i]->h >> l);
-      ctx->stats.algorithmic_bytes += S.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
+      st.algorithmic_bytes += S.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
     }
   }
   // next call's schedule: what this batch needed plus one, decaying slowly towards it
@@ -1109,6 +1155,10 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     const int want = need[l] + 1;
     const int decayed = sched[l] - (sched[l] + 7) / 8;
     sched[l] = want > decayed ? want : decayed;
+    if (n2 > 0) {
+      const int want2 = need2[l] + 1, decayed2 = sched2[l] - (sched2[l] + 7) / 8;
+      sched2[l] = want2 > decayed2 ? want2 : decayed2;
+    }
   }
   return DSM_OK;
 }
@@ -1174,6 +1224,63 @@ int dsm_optimize_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, fl
     scale_io[i] = S.scale_cur;                               // :954
     if (err_out) err_out[i] = (float)S.last_residuals[0];    // :963
   }
+  return DSM_OK;
+}
+
+// One step of many sequences: the frames' trackNewestCoarse AND the keyframes' optimizeScale in one call.  The scale problems
+// are independent of the track problems (they read the keyframe tracker's template and its right frame, FrontEnd.cpp:992-998;
+// the track problems read the same kind of template and the left frame), so their launches run on a stream of their own
+// under the tracking kernels.  Same results as dsm_track_batch followed by dsm_optimize_scale_batch, bit for bit.
+int dsm_track_and_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, double *pose_io, double *aff_io, int coarsest_lvl,
+                              const double *min_res_for_abort, double *last_residuals, double *flow_out, int *good, int n_scale,
+                              dsm_tracker *const *ts_scale, float *scale_io, float *err_out) {
+  if (!pose_io || !aff_io || n < 1) return invalid("dsm_track_and_scale_batch: null pose/aff");
+  if (n_scale < 0 || (n_scale && (!ts_scale || !scale_io))) return invalid("dsm_track_and_scale_batch: bad scale arguments");
+  std::vector<dsm_tracker *> all(ts, ts + n);
+  all.insert(all.end(), ts_scale, ts_scale + n_scale);
+  int rc = prepare_batch(ctx, n, all.data(), 0, n_scale, 1);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    StartInfo &I = ctx->h_start[i];
+    memset(&I, 0, sizeof I);
+    memcpy(I.pose, pose_io + 7 * i, sizeof I.pose);
+    memcpy(I.aff, aff_io + 2 * i, sizeof I.aff);
+    for (int l = 0; l < DSM_MAX_LEVELS; l++)
+      I.min_res[l] = min_res_for_abort ? min_res_for_abort[DSM_MAX_LEVELS * i + l] : std::numeric_limits<double>::quiet_NaN();
+    I.scale = 1.0f;
+    I.coarsest = coarsest_lvl;
+  }
+  for (int i = 0; i < n_scale; i++) {
+    StartInfo &I = ctx->h_start[n + i];
+    memset(&I, 0, sizeof I);
+    I.pose[3] = 1.0;
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) I.min_res[l] = std::numeric_limits<double>::quiet_NaN();
+    I.scale = scale_io[i];
+    I.coarsest = coarsest_lvl;
+  }
+  rc = run_lm_batch(ctx, n, all.data(), 0, coarsest_lvl, n_scale, 1);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    const LMState &S = ctx->h_states[i];
+    if (S.status == ST_GOOD || S.status == ST_BAD_AFFINE) { // as dsm_track_batch
+      memcpy(pose_io + 7 * i, S.cur, sizeof(double) * 7);
+      memcpy(aff_io + 2 * i, S.aff_cur, sizeof(double) * 2);
+    }
+    if (last_residuals) memcpy(last_residuals + DSM_MAX_LEVELS * i, S.last_residuals, sizeof(double) * DSM_MAX_LEVELS);
+    if (flow_out) memcpy(flow_out + 3 * i, S.flow, sizeof(double) * 3);
+    if (good) good[i] = S.status == ST_GOOD ? 1 : 0;
+  }
+  for (int i = 0; i < n_scale; i++) {
+    const LMState &S = ctx->h_states[n + i];
+    scale_io[i] = S.scale_cur;                             // :954
+    if (err_out) err_out[i] = (float)S.last_residuals[0];  // :963
+  }
+  return DSM_OK;
+}
+
+int dsm_context_get_stats2(dsm_context *ctx, dsm_stats *out) {
+  if (!ctx || !out) return invalid("dsm_context_get_stats2: null argument");
+  *out = ctx->stats2;
   return DSM_OK;
 }
 

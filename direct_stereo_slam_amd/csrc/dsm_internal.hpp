@@ -28,6 +28,8 @@ struct dsm_context {
   std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> join_events;
   hipEvent_t fork_event = nullptr;
+  hipStream_t companion_stream = nullptr; // the companion segment of dsm_track_and_scale_batch
+  hipEvent_t companion_event = nullptr;
   hipEvent_t copy_event = nullptr; // end of a host->device hand-over (dsm_tracker_upload_image)
   // descriptor updates of a batch in one copy (sync_descs): [n descriptors][n destination pointers], pinned + device
   unsigned char *h_desc_stage = nullptr, *d_desc_stage = nullptr;
@@ -72,6 +74,7 @@ struct dsm_context {
   // stats / timing
   bool timing = false;
   dsm_stats stats{};
+  dsm_stats stats2{}; // companion segment of the last dsm_track_and_scale_batch
   std::vector<hipEvent_t> ev_pool;
   hipEvent_t ev_total[2] = {nullptr, nullptr};
 };

@@ -99,6 +99,12 @@ class Context:
         check(self.L.dsm_context_get_stats(self.h, C.byref(s)))
         return s
 
+    def stats2(self):
+        """statistics of the scale segment of the last track_and_scale_batch"""
+        s = Stats()
+        check(self.L.dsm_context_get_stats2(self.h, C.byref(s)))
+        return s
+
     def read_bandwidth(self, nbytes=1 << 30, iters=10):
         """measurement aid: read-only streaming bandwidth in GB/s"""
         g = C.c_double()
@@ -170,6 +176,22 @@ class Context:
         hs = (C.c_void_p * n)(*[t.h for t in trackers])
         sl = np.ascontiguousarray(slots, np.int32)
         check(self.L.dsm_frames_advance(self.h, n, hs, sl.ctypes.data_as(c_int_p)))
+
+    def track_and_scale_batch(self, trackers, poses, affs, coarsest, scale_trackers, scales, min_res=None):
+        """dsm_track_and_scale_batch: the frames' tracking and the keyframes' scale optimisation in one call (the scale
+        problems run on their own stream under the tracking kernels); returns track_batch's tuple + (err, scales)"""
+        n, n2 = len(trackers), len(scale_trackers)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        hs2 = (C.c_void_p * max(1, n2))(*[t.h for t in scale_trackers])
+        poses = np.ascontiguousarray(poses, np.float64).reshape(n, 7).copy()
+        affs = np.ascontiguousarray(affs, np.float64).reshape(n, 2).copy()
+        mr = None if min_res is None else np.ascontiguousarray(min_res, np.float64).reshape(n, MAX_LEVELS)
+        last, flow, good = np.zeros((n, MAX_LEVELS)), np.zeros((n, 3)), np.zeros(n, np.int32)
+        sc = np.ascontiguousarray(scales, np.float32).reshape(n2).copy()
+        err = np.zeros(max(1, n2), np.float32)
+        check(self.L.dsm_track_and_scale_batch(self.h, n, hs, _dp(poses), _dp(affs), coarsest, None if mr is None else _dp(mr), _dp(last),
+                                               _dp(flow), good.ctypes.data_as(c_int_p), n2, hs2, _fp(sc) if n2 else None, _fp(err)))
+        return good.astype(bool), poses, affs, last, flow, err[:n2], sc
 
     def optimize_scale_batch(self, trackers, scales, coarsest):
         n = len(trackers)

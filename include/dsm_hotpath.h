@@ -229,6 +229,15 @@ int dsm_tracker_optimize_scale(dsm_tracker *t, float *scale_io, int coarsest_lvl
  * positive), scales_all / errs_all (may be NULL) = every guess's result in order. */
 int dsm_tracker_optimize_scale_guesses(dsm_tracker *t, int n_guesses, const float *scale_guesses, int coarsest_lvl,
                                        float *scale_out, float *err_out, float *scales_all, float *errs_all);
+/* One step of many sequences in ONE call: trackNewestCoarse for the n trackers of `trackers` (arguments as dsm_track_batch) and
+ * optimizeScale for the n_scale trackers of `scale_trackers` (arguments as dsm_optimize_scale_batch; a tracker may appear in
+ * both lists -- a keyframe's tracker is tracked against AND scale-optimised, FrontEnd.cpp:204-206,992-998).  The two sets are
+ * independent problems; the scale problems' launches run on a stream of their own under the tracking kernels.  Results are
+ * bit-identical to the two separate calls.  Statistics: dsm_context_get_stats (tracking) / dsm_context_get_stats2 (scale). */
+int dsm_track_and_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *trackers, double *pose_io, double *aff_io, int coarsest_lvl,
+                              const double *min_res_for_abort, double *last_residuals, double *flow_out, int *good, int n_scale,
+                              dsm_tracker *const *scale_trackers, float *scale_io, float *err_out);
+int dsm_context_get_stats2(dsm_context *ctx, dsm_stats *out);
 
 /* Batched forms: n independent trackers of one context advance in lock-step launches
  * (SURVEY.md section 7 "throughput mode").  Arrays are n x 7 / n x 2 / n x DSM_MAX_LEVELS / n x 3. */

@@ -64,3 +64,33 @@ def test_speculation_keeps_the_evaluation_counts_and_saves_launches(ctx):
         assert list(st.evals)[:sc.nl] == want
         launches[spec] = sum(st.launches)
     assert launches[2] < launches[0]
+
+
+def test_track_and_scale_in_one_call_equals_the_two_calls(ctx):
+    """dsm_track_and_scale_batch: the scale problems run as a companion segment on their own stream; bit-identical results"""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    scs = [make_scene("small", seed=300 + i, template="dense" if i % 2 else "sparse", n0=3000) for i in range(10)]
+    p = default_params()
+    p.work_queue = 0
+    trks = [hip_tracker(ctx, sc, p) for sc in scs]
+    n, nl = len(trks), scs[0].nl
+    kf = trks[::3]
+    try:
+        for ns in (1, 2):
+            ctx.set_streams(ns)
+            for _ in range(4):
+                r = ctx.track_batch(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+                ev_t = list(ctx.stats().evals)
+                e, s = ctx.optimize_scale_batch(kf, np.full(len(kf), 1.3), nl - 1)
+                ev_s = list(ctx.stats().evals)
+                c = ctx.track_and_scale_batch(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1, kf, np.full(len(kf), 1.3))
+                for a, b in zip(r, c[:5]):
+                    assert np.array_equal(a, b, equal_nan=True)
+                assert np.array_equal(e, c[5], equal_nan=True) and np.array_equal(s, c[6])
+                assert list(ctx.stats().evals) == ev_t and list(ctx.stats2().evals) == ev_s
+        # no keyframe in the step: the call degenerates to dsm_track_batch
+        c0 = ctx.track_and_scale_batch(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1, [], [])
+        assert np.array_equal(c0[1], r[1]) and len(c0[5]) == 0
+    finally:
+        ctx.set_streams(1)
