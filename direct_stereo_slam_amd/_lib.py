@@ -136,6 +136,7 @@ SYMBOLS = {
     "dsm_ringdb_merge_topk": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     "dsm_ringdb_merge_topk_with": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, ALLREDUCE_MIN_FN, ALLGATHER_FN, _vp]),
     "dsm_ringdb_attach_comm": (C.c_int, [_vp, _vp]),
+    "dsm_ringdb_attach_transport": (C.c_int, [_vp, C.c_int, ALLREDUCE_MIN_FN, ALLGATHER_FN, _vp]),
     "dsm_scancontext_generate": (C.c_int, [c_double_p, C.c_int, C.c_double, C.c_int, C.c_int, c_float_p, c_int_p, c_double_p, c_int_p, c_double_p]),
     "dsm_generate_spherical_points": (C.c_int, [C.c_int, c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p]),
     "dsm_loop_descriptors_batch": (C.c_int, [_vp, C.c_int, C.POINTER(LoopJob), C.c_double, C.c_int, C.c_int]),

@@ -251,10 +251,22 @@ int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm) {
   return DSM_OK;
 }
 
+int dsm_ringdb_attach_transport(dsm_ringdb *db, int nranks, dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather, void *user) {
+  if (!db) return invalid("dsm_ringdb_attach_transport: null database");
+  if (allreduce_min && nranks != db->shard_count) return invalid("dsm_ringdb_attach_transport: nranks must equal the database's shard count");
+  db->tr_allreduce = allreduce_min;
+  db->tr_allgather = allgather;
+  db->tr_user = user;
+  db->tr_nranks = allreduce_min ? nranks : 0;
+  return DSM_OK;
+}
+
 } // extern "C"
 
 // used by dsm_ringdb_query_then_enqueue on sharded handles (ringdb_capi.hip)
 int dsm::ringdb_merge_attached(dsm_ringdb *db, void *d_packed, int nq) {
+  if (!db->comm && db->tr_allreduce)
+    return dsm_ringdb_merge_topk_with(db, d_packed, nq, DSM_MERGE_ALLREDUCE_MIN, db->tr_nranks, db->tr_allreduce, db->tr_allgather, db->tr_user);
   if (!db->comm) {
     set_error("sharded ring-key DB: attach a communicator first (dsm_ringdb_attach_comm) -- every rank then calls "
               "dsm_ringdb_query_then_enqueue collectively with the same key");

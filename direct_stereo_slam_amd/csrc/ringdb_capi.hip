@@ -204,7 +204,7 @@ int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_ou
   // Sharded handle: a COLLECTIVE call -- every rank passes the same key, scans its shard, the candidates are merged
   // through the attached communicator (RCCL all-reduce(min)), and every rank returns the same candidate list and
   // enqueues the key (each shard keeps the ordinals that are its own).
-  if (db->shard_count != 1 && !db->comm) {
+  if (db->shard_count != 1 && !db->comm && !db->tr_allreduce) {
     set_error("dsm_ringdb_query_then_enqueue on a sharded DB needs a communicator (dsm_ringdb_attach_comm); "
               "without one use knn_packed + your own merge + enqueue");
     return DSM_ERR_STATE;

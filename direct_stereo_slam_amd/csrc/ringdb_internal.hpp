@@ -25,6 +25,11 @@ struct dsm_ringdb {
   unsigned long long *d_merge = nullptr;
   size_t merge_words = 0;
   struct dsm_comm *comm = nullptr; // borrowed
+  // ... or a caller-supplied transport (dsm_ringdb_attach_transport)
+  dsm_allreduce_min_u64_fn tr_allreduce = nullptr;
+  dsm_allgather_u64_fn tr_allgather = nullptr;
+  void *tr_user = nullptr;
+  int tr_nranks = 0;
 };
 
 namespace dsm {

@@ -125,6 +125,27 @@ class RingKeyDB:
         check(self.L.dsm_ringdb_attach_comm(self.h, comm.h if comm is not None else None))
         self._comm = comm
 
+    def attach_transport(self, nranks, allreduce_min):
+        """sharded handle: search_ringkey becomes a collective over a caller-supplied all-reduce(min)
+        (allreduce_min(d_buf_ptr, count, stream_ptr) on a device buffer of unsigned 64-bit words); None detaches"""
+        if allreduce_min is None:
+            check(self.L.dsm_ringdb_attach_transport(self.h, 0, C.cast(None, ALLREDUCE_MIN_FN), C.cast(None, ALLGATHER_FN), None))
+            self._tr = None
+            return
+
+        def _ar(user, buf, count, stream):
+            try:
+                allreduce_min(buf, count, stream)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return -1
+
+        self._tr = ALLREDUCE_MIN_FN(_ar)  # keep the callback alive as long as it is attached
+        check(self.L.dsm_ringdb_attach_transport(self.h, nranks, self._tr, C.cast(None, ALLGATHER_FN), None))
+
     def merge_topk_device(self, comm, d_packed_ptr, nq, algo="allreduce_min"):
         """cross-shard merge of the nq x k packed candidates at the raw device pointer, in place (dsm_ringdb_merge_topk);
         asynchronous on the context stream"""

@@ -335,6 +335,9 @@ int dsm_ringdb_merge_topk_with(dsm_ringdb *db, void *d_packed, int nq, int algo,
 /* attach (or, with NULL, detach) the communicator dsm_ringdb_query_then_enqueue uses on a sharded handle; borrowed:
  * destroy the database or detach before destroying the communicator */
 int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm);
+/* the same with a caller-supplied transport instead of an RCCL communicator (allreduce_min NULL detaches) */
+int dsm_ringdb_attach_transport(dsm_ringdb *db, int nranks, dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather,
+                                void *user);
 
 /* replaces ScanContext::generate (src/loop_closure/loop_detection/ScanContext.cpp:78-141, with
  * align_points_PCA :19-66).  Host side by design: a few 10^3 points per

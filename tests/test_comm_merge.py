@@ -145,3 +145,41 @@ def test_sharded_query_then_enqueue_needs_a_communicator(built, ctx):
         db.attach_comm(comm)  # rank / size of the communicator must equal the shard's
     comm.close()
     db.close()
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_sharded_search_ringkey_is_a_drop_in_for_the_unsharded_one(built, G):
+    """search_ringkey (search_place.h:25-57) on a sharded index: every rank calls dsm_ringdb_query_then_enqueue with the same
+    key -- scan of its shard, cross-shard merge, delay queue -- and gets the candidate list the unsharded index returns,
+    query after query while the index grows through the delay queue (margin 5 here) and its dummy slot"""
+    keys = ring_keys(160, seed=11)
+    keys[40:60] = keys[:20] + np.float32(0.01)  # revisits: candidates under the threshold
+    keys[100:130] = keys[30:60]
+    ctx0 = Context(0)
+    ref_db = RingKeyDB(ctx0, margin=5, capacity=64)
+    want = [ref_db.search_ringkey(k) for k in keys]
+    assert any(len(w) for w in want)
+    ex = HostExchange(G)
+    got, errs = [None] * G, []
+
+    def rank_main(r):
+        try:
+            ctx = Context(0)
+            db = RingKeyDB(ctx, margin=5, capacity=64, shard_rank=r, shard_count=G)
+            db.attach_transport(G, ex.allreduce_min(r))
+            got[r] = [db.search_ringkey(k) for k in keys]
+            assert db.size() == ref_db.size()
+            db.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            ex.barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for r in range(G):
+        assert got[r] == want, f"rank {r}"
+    ref_db.close()
+    ctx0.close()
