@@ -231,14 +231,14 @@ int dsm_context_create(int device_ordinal, dsm_context **out) {
   DSM_HIP(hipSetDevice(device_ordinal));
   dsm_context *ctx = new dsm_context();
   ctx->device = device_ordinal;
-  DSM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  DSM_HIP(hipEventCreate(&ctx->ev_total[0]));
-  DSM_HIP(hipEventCreate(&ctx->ev_total[1]));
-  DSM_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
-  DSM_HIP(hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming));
-  if (const char *e = getenv("DSM_ASYNC_COPY_BLOCKS")) {
-    const int v = atoi(e);
-    if (v > 0) ctx->async_copy_blocks = v;
+  hipError_t ce = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (ce == hipSuccess) ce = hipEventCreate(&ctx->ev_total[0]);
+  if (ce == hipSuccess) ce = hipEventCreate(&ctx->ev_total[1]);
+  if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming);
+  if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ctx->copy_event, hipEventDisableTiming);
+  if (ce != hipSuccess) { // give back what was created
+    dsm_context_destroy(ctx);
+    DSM_HIP(ce);
   }
   *out = ctx;
   return DSM_OK;
@@ -247,7 +247,7 @@ int dsm_context_create(int device_ordinal, dsm_context **out) {
 int dsm_context_destroy(dsm_context *ctx) {
   if (!ctx) return DSM_OK;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
   hipFree(ctx->d_tracker_ptrs);
   hipHostFree(ctx->h_tracker_ptrs);
   hipFree(ctx->d_states);
@@ -269,8 +269,8 @@ int dsm_context_destroy(dsm_context *ctx) {
   if (ctx->companion_stream) hipStreamDestroy(ctx->companion_stream);
   if (ctx->companion_event) hipEventDestroy(ctx->companion_event);
   for (hipStream_t st : ctx->extra_streams) hipStreamDestroy(st);
-  hipEventDestroy(ctx->fork_event);
-  hipEventDestroy(ctx->copy_event);
+  if (ctx->fork_event) hipEventDestroy(ctx->fork_event);
+  if (ctx->copy_event) hipEventDestroy(ctx->copy_event);
   for (hipEvent_t ev : ctx->upload_events) hipEventDestroy(ev);
   if (ctx->desc_event) hipEventDestroy(ctx->desc_event);
   hipFree(ctx->d_desc_stage);
@@ -284,9 +284,9 @@ int dsm_context_destroy(dsm_context *ctx) {
   }
   hipFree(ctx->d_pyr_jobs);
   hipHostFree(ctx->h_pyr_jobs);
-  hipEventDestroy(ctx->ev_total[0]);
-  hipEventDestroy(ctx->ev_total[1]);
-  hipStreamDestroy(ctx->stream);
+  for (hipEvent_t ev : ctx->ev_total)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return DSM_OK;
 }

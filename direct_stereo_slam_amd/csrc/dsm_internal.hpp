@@ -43,7 +43,7 @@ struct dsm_context {
   hipStream_t upload_stream = nullptr;
   hipEvent_t upload_copies_event = nullptr, upload_done_event = nullptr;
   bool upload_pending = false;
-  int async_copy_blocks = 48;  // DSM_ASYNC_COPY_BLOCKS (developer knob)
+  int async_copy_blocks = 48;  // workgroups of the host-read kernel of the asynchronous hand-over (measured: DESIGN.md section 2)
   std::vector<hipEvent_t> upload_events;
   dsm::PyrJob *d_pyr_jobs = nullptr, *h_pyr_jobs = nullptr; // h: pinned
   int pyr_jobs_cap = 0;
