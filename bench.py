@@ -350,7 +350,8 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
     ctx.set_timing(False)
     stt, sts = out_t[4], out_t[5]
     n0 = len(wl["trackers"][0].get_template(0)[0])
-    bytes_eval0 = 16 * n0 + min(12 * wl["w"] * wl["h"], 48 * n0)  # sparse templates do not touch the whole image
+    bytes_eval0 = 16 * n0 + min(12 * wl["w"] * wl["h"], 48 * n0)  # the reference's data (16 B template entries, 12 B (I, dx, dy) texels); sparse templates do not touch the whole image
+    layout_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 48 * n0)  # what this implementation keeps in HBM for the same evaluation: the intensity plane only (gradients are formed from neighbouring intensities)
     l0_ms = stt.eval_kernel_union_ms[0]
     l0_launches, l0_dispatches, l0_evals = stt.launches[0], stt.eval_dispatches[0], stt.evals[0]
     achieved = (l0_evals * bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
@@ -359,6 +360,7 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
                 "traffic": ratio * l0_evals * bytes_eval0 / max(1, l0_launches) if ratio is not None else None,
                 "traffic_source": f"{src}: stored rocprofv3 --pmc summary of this command, scaled to this run's bytes per launch (not re-measured here)" if src else None,
                 "kernel": "eval_kernel<pose, LVL0>", "bytes_per_eval": int(bytes_eval0),
+                "layout_bytes_per_eval": int(layout_eval0), "achieved_on_layout_bytes": achieved * layout_eval0 / bytes_eval0,
                 "bytes_per_launch": l0_evals * bytes_eval0 / max(1, l0_launches),
                 "avg_launch_us": 1e3 * stt.eval_kernel_ms[0] / max(1, l0_dispatches), "launches": int(l0_launches),
                 "dispatches": int(l0_dispatches), "stream_groups": args.streams,

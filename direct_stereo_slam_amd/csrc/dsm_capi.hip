@@ -28,6 +28,11 @@ static int invalid(const char *msg) {
   return DSM_ERR_INVALID;
 }
 
+// One intensity plane of a w x h level.  Lanes whose point is not usable fetch their twelve taps around texel (2, 2)
+// instead (rows 1-4, columns 1-4): four rows and a few texels of slack keep that inside the allocation on levels
+// smaller than 5 x 5, where no point is usable anyway.
+static size_t plane_bytes(int w, int h) { return sizeof(float) * ((size_t)w * h + 4 * (size_t)w + 16); }
+
 int ensure_stage(dsm_context *ctx, size_t floats) {
   if (floats <= ctx->stage_floats) return DSM_OK;
   if (ctx->d_stage) DSM_HIP(hipFree(ctx->d_stage));
@@ -361,7 +366,6 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
   D.p.lambda_extrapolation_limit = t->params.lambda_extrapolation_limit;
   for (int l = 0; l < DSM_MAX_LEVELS; l++) D.p.max_iterations[l] = t->params.max_iterations[l];
   se3_from_matrix(T_f1_f0, D.T10);
-  const int ts = kTexel;
   for (int l = 0; l < nlevels; l++) { // TrackerAndScaler.cpp:52-64
     const int wl = w >> l, hl = h >> l;
     D.lv[l].w = wl;
@@ -369,8 +373,8 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
     DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)wl * hl));
     t->pts_cap[l] = wl * hl;
     for (int s = 0; s < 2; s++) {
-      DSM_HIP(hipMalloc(&t->d_img[s][l], sizeof(float) * ts * (size_t)wl * hl));
-      DSM_HIP(hipMemsetAsync(t->d_img[s][l], 0, sizeof(float) * ts * (size_t)wl * hl, ctx->stream));
+      DSM_HIP(hipMalloc(&t->d_img[s][l], plane_bytes(wl, hl)));
+      DSM_HIP(hipMemsetAsync(t->d_img[s][l], 0, plane_bytes(wl, hl), ctx->stream));
       D.lv[l].img[s] = t->d_img[s][l];
     }
     D.lv[l].pts = t->d_pts[l];
@@ -557,11 +561,25 @@ int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, 
   if (!t || !dIp || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_frame: bad argument");
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
+  // The device keeps channel 0 only; channels 1 and 2 must be what FrameHessian::makeImages derives
+  // from it -- which is all the reference ever passes -- and that is checked, not assumed.
+  const size_t npx0 = (size_t)t->w * t->h;
+  int rc = ensure_stage(ctx, 3 * npx0 + 4);
+  if (rc) return rc;
+  int *d_bad = (int *)(ctx->d_stage + 3 * npx0);
+  DSM_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
   for (int l = 0; l < t->nlevels; l++) {
-    const size_t npx = (size_t)(t->w >> l) * (t->h >> l);
-    DSM_HIP(hipMemcpyAsync(t->d_img[slot][l], dIp[l], npx * 12, hipMemcpyHostToDevice, ctx->stream));
+    const int wl = t->w >> l, hl = t->h >> l;
+    DSM_HIP(hipMemcpyAsync(ctx->d_stage, dIp[l], (size_t)wl * hl * 12, hipMemcpyHostToDevice, ctx->stream));
+    launch_dip_import(ctx->stream, wl, hl, ctx->d_stage, t->d_img[slot][l], d_bad);
   }
+  int bad = 0;
+  DSM_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
+  if (bad) {
+    t->have_frame[slot] = false;
+    return invalid("dsm_tracker_upload_frame: the gradient channels are not the central differences of channel 0 (makeImages)");
+  }
   t->desc.exposure[slot] = ab_exposure;
   t->have_frame[slot] = true;
   t->desc_dirty = true;
@@ -594,12 +612,11 @@ static int upload_target(dsm_tracker *t, int slot, float **raw, float **img) {
   const size_t npx0 = (size_t)t->w * t->h;
   const int s = slot & 1;
   const bool back = slot >= 2;
-  const int ts = kTexel;
   if (back) {
     for (int l = 0; l < t->nlevels; l++)
       if (!t->d_img_back[s][l]) {
-        const size_t npx = (size_t)(t->w >> l) * (t->h >> l);
-        DSM_HIP(hipMalloc(&t->d_img_back[s][l], sizeof(float) * ts * npx));
+        DSM_HIP(hipMalloc(&t->d_img_back[s][l], plane_bytes(t->w >> l, t->h >> l)));
+        DSM_HIP(hipMemsetAsync(t->d_img_back[s][l], 0, plane_bytes(t->w >> l, t->h >> l), t->ctx->stream));
       }
     if (!t->d_raw_back[s]) DSM_HIP(hipMalloc(&t->d_raw_back[s], npx0 * sizeof(float)));
   } else if (!t->d_raw[s]) {
@@ -815,8 +832,12 @@ int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out) {
   if (!t || !dIp_out || slot < 0 || slot > 1 || lvl < 0 || lvl >= t->nlevels) return invalid("dsm_tracker_get_frame: bad argument");
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
-  const size_t npx = (size_t)(t->w >> lvl) * (t->h >> lvl);
-  DSM_HIP(hipMemcpyAsync(dIp_out, t->d_img[slot][lvl], npx * 12, hipMemcpyDeviceToHost, ctx->stream));
+  const int wl = t->w >> lvl, hl = t->h >> lvl;
+  const size_t npx = (size_t)wl * hl;
+  int rc = ensure_stage(ctx, 3 * npx);
+  if (rc) return rc;
+  launch_dip_export(ctx->stream, wl, hl, t->d_img[slot][lvl], ctx->d_stage);
+  DSM_HIP(hipMemcpyAsync(dIp_out, ctx->d_stage, npx * 12, hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
   return DSM_OK;
 }

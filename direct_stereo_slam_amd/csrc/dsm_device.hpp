@@ -24,11 +24,11 @@ constexpr int kSlotE = 45, kSlotFlowT = 46, kSlotFlowRT = 47, kSlotFlowNum = 48;
 constexpr int kSlotNTerms = 49, kSlotNSat = 50, kSlotNWarped = 51;
 constexpr int kNumSlots = 52;
 
-constexpr int kTexel = 3;         // floats per target texel (I, dx, dy)
+constexpr int kTexel = 1;         // floats per target texel: the intensity; gradients are formed from neighbours (taps_interp)
 
 struct LevelDev {
   const float4 *pts;   // n template points
-  const float *img[2]; // slot 0 = new left frame, slot 1 = right frame; kTexel floats per texel
+  const float *img[2]; // slot 0 = new left frame, slot 1 = right frame: intensity planes
   int n, w, h, pad;
   float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
   float Ki[9];              // inverse of K at this level (float, :135-140)

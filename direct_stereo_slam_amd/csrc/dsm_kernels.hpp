@@ -79,8 +79,12 @@ void launch_interleave_template(hipStream_t s, int n, const float *u, const floa
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
                                   float *c);
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
-// makeImages (upstream DSO): level 0 from the float image, level l from level l-1
+// makeImages (upstream DSO): the intensity plane of level 0 from the float image, of level l from level l-1
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img);
+// the reference's (I, dx, dy) texels out of / into an intensity plane; import counts texels whose gradient channels are
+// not makeImages' central differences of channel 0 into *d_bad
+void launch_dip_export(hipStream_t s, int w, int h, const float *plane, float *out3);
+void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad);
 // one image of a batched hand-over (dsm_upload_images): staged level-0 pixels (float or u8) and the pyramid levels
 struct PyrJob {
   const void *raw;

@@ -182,7 +182,7 @@ size_t make_coarse_depth_workspace_floats(int w, int h, int nlevels, int npts) {
 }
 
 // ws: workspace of make_coarse_depth_workspace_floats() floats.  d_pt: [pu | pv | pidepth | pweight] (npts each), already
-// on the device at the start of ws.  ref[l]: the keyframe's pyramid level l (texel_floats = 3 or 4).  pts[l]: float4
+// on the device at the start of ws.  ref[l]: the keyframe's pyramid level l (texel_floats = kTexel: the intensity plane).  pts[l]: float4
 // template buffers.  d_n: nlevels + 1 ints on the device: n per level, then the out-of-bounds flag.
 void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, int npts, float *ws, const float *const *ref,
                               int texel_floats, float4 *const *pts, int *d_n) {

@@ -50,46 +50,75 @@ __device__ __forceinline__ int row16_sum(int v) {
 
 // clang vector types: loads through address_space(1) pointers compile on the host pass too
 typedef float fvec4 __attribute__((ext_vector_type(4)));
-typedef float fvec3u __attribute__((ext_vector_type(3), aligned(4))); // 12-byte texel, dword aligned
+typedef float fvec4u __attribute__((ext_vector_type(4), aligned(4))); // four / two neighbouring texels, dword aligned
+typedef float fvec2u __attribute__((ext_vector_type(2), aligned(4)));
 #define DSM_GLOBAL __attribute__((address_space(1)))
 
 // getInterpolatedElement33 (upstream DSO), call sites TrackerAndScaler.cpp:790,1106, split in two
-// so that the four tap loads of one point can be in flight while the previous point is consumed.
+// so that the tap loads of one point can be in flight while the previous point is consumed.
+//
+// The target lives in HBM as its intensities only (4 bytes per texel).  The reference's texel is
+// (I, dx, dy) with dx = 0.5 (I[x+1] - I[x-1]), dy = 0.5 (I[y+1] - I[y-1]) (upstream DSO FrameHessian::makeImages), so the
+// interpolated gradients follow from a 4 x 4 neighbourhood of intensities of which only 12 values are needed:
+//   rows y, y+1: columns x-1 .. x+2 (two 16-byte loads),  rows y-1, y+2: columns x, x+1 (two 8-byte loads)
+// -- as many vector-memory instructions and registers as four 12-byte texels, one third of the image bytes.
 struct Taps {
-  float t00[3], t10[3], t01[3], t11[3];
-  float dx, dy; // fractional position
+  float r1[4], r2[4]; // rows y, y+1: columns x-1 .. x+2
+  float r0[2], r3[2]; // rows y-1, y+2: columns x, x+1
+  float dx, dy;       // fractional position
 };
 
-__device__ __forceinline__ void taps_load(const DSM_GLOBAL float *img, float x, float y, int w, Taps &T) {
+// The four row bases of a target plane (wave-uniform, kept in SGPRs): every tap load of a point then shares ONE 32-bit
+// vector offset (global_load with saddr + voffset, no 64-bit vector address arithmetic).
+struct TapBases {
+  const DSM_GLOBAL char *r0, *r1, *r2, *r3;
+};
+__device__ __forceinline__ TapBases tap_bases(const DSM_GLOBAL float *img, int w) {
+  const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
+  const long pitch = 4l * w;
+  return TapBases{cb - pitch, cb - 4, cb + pitch - 4, cb + 2 * pitch};
+}
+__device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
   const int iy = (int)y;
   // x - (float)(int)x for x >= 0 is exact and equals v_fract_f32(x) (= x - floor(x))
   T.dx = __builtin_amdgcn_fractf(x);
   T.dy = __builtin_amdgcn_fractf(y);
-  const unsigned base = (unsigned)(ix + iy * w);
-  // 32-bit byte offsets from the (scalar) image base: global_load with saddr + voffset, no
-  // 64-bit vector address arithmetic.  (Shift-add / 24-bit forms of these multiplies were measured: no gain.)
-  const unsigned off0 = 12u * base, off1 = off0 + 12u * (unsigned)w;
-  const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
-  const fvec3u a = *(const DSM_GLOBAL fvec3u *)(cb + off0);
-  const fvec3u b = *(const DSM_GLOBAL fvec3u *)(cb + off0 + 12u);
-  const fvec3u c = *(const DSM_GLOBAL fvec3u *)(cb + off1);
-  const fvec3u d = *(const DSM_GLOBAL fvec3u *)(cb + off1 + 12u);
-  T.t00[0] = a.x, T.t00[1] = a.y, T.t00[2] = a.z;
-  T.t10[0] = b.x, T.t10[1] = b.y, T.t10[2] = b.z;
-  T.t01[0] = c.x, T.t01[1] = c.y, T.t01[2] = c.z;
-  T.t11[0] = d.x, T.t11[1] = d.y, T.t11[2] = d.z;
+  // (Shift-add / 24-bit forms of this multiply were measured: no gain.)
+  const unsigned off = 4u * (unsigned)(ix + iy * w);
+  const fvec4u a = *(const DSM_GLOBAL fvec4u *)(B.r1 + off); // (x-1 .. x+2, y)
+  const fvec4u b = *(const DSM_GLOBAL fvec4u *)(B.r2 + off); // (x-1 .. x+2, y+1)
+  const fvec2u c = *(const DSM_GLOBAL fvec2u *)(B.r0 + off); // (x, x+1; y-1)
+  const fvec2u d = *(const DSM_GLOBAL fvec2u *)(B.r3 + off); // (x, x+1; y+2)
+  T.r1[0] = a.x, T.r1[1] = a.y, T.r1[2] = a.z, T.r1[3] = a.w;
+  T.r2[0] = b.x, T.r2[1] = b.y, T.r2[2] = b.z, T.r2[3] = b.w;
+  T.r0[0] = c.x, T.r0[1] = c.y;
+  T.r3[0] = d.x, T.r3[1] = d.y;
 }
 
-// h0 (the intensity) decides in/out, Huber and cut-off: exact reference operation order.  h1/h2
-// (the gradients) only enter the Jacobian sums, which are compared to float tolerance: FMA allowed.
-__device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &h1, float &h2) {
+// h0 (the intensity) decides in/out, Huber and cut-off: exact reference operation order.  g1 / g2 are TWICE the
+// interpolated gradients (the 0.5 of the central difference is a power of two: it commutes with every rounding of the
+// chain and is folded into the focal length by the caller); they only enter the Jacobian sums, which are compared to
+// float tolerance: FMA allowed.  makeImages replaces a non-finite gradient by zero; some tap difference is non-finite
+// exactly when the interpolated value is (the weights are finite), which the caller tests per wave: EXACT = the rare
+// path that applies the replacement tap by tap.
+template <bool EXACT>
+__device__ __forceinline__ void taps_gradients(const Taps &T, float w00, float w10, float w01, float w11, float &g1, float &g2) {
+  auto fix = [](float d) { return EXACT ? (__builtin_isfinite(d) ? d : 0.0f) : d; };
+  const float d00 = fix(T.r1[2] - T.r1[0]), d10 = fix(T.r1[3] - T.r1[1]);
+  const float d01 = fix(T.r2[2] - T.r2[0]), d11 = fix(T.r2[3] - T.r2[1]);
+  const float e00 = fix(T.r2[1] - T.r0[0]), e10 = fix(T.r2[2] - T.r0[1]);
+  const float e01 = fix(T.r3[0] - T.r1[1]), e11 = fix(T.r3[1] - T.r1[2]);
+  g1 = __builtin_fmaf(w00, d00, __builtin_fmaf(w10, d10, __builtin_fmaf(w01, d01, w11 * d11)));
+  g2 = __builtin_fmaf(w00, e00, __builtin_fmaf(w10, e10, __builtin_fmaf(w01, e01, w11 * e11)));
+}
+template <bool EXACT>
+__device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1, float &g2) {
   const float dx = T.dx, dy = T.dy;
   const float dxdy = dx * dy;
   const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-  h0 = ((w11 * T.t11[0] + w01 * T.t01[0]) + w10 * T.t10[0]) + w00 * T.t00[0];
-  h1 = __builtin_fmaf(w00, T.t00[1], __builtin_fmaf(w10, T.t10[1], __builtin_fmaf(w01, T.t01[1], w11 * T.t11[1])));
-  h2 = __builtin_fmaf(w00, T.t00[2], __builtin_fmaf(w10, T.t10[2], __builtin_fmaf(w01, T.t01[2], w11 * T.t11[2])));
+  h0 = ((w11 * T.r2[2] + w01 * T.r2[1]) + w10 * T.r1[2]) + w00 * T.r1[1];
+  taps_gradients<EXACT>(T, w00, w10, w01, w11, g1, g2);
 }
 
 // per-point state carried from the warp stage to the consume stage
@@ -172,9 +201,10 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
     const float cutoff = c.cutoff, max_energy = c.max_energy;
     const float huber = c.huber;
     const float fxl = c.fx, fyl = c.fy, cxl = c.cx, cyl = c.cy;
+    const float hfx = 0.5f * fxl, hfy = 0.5f * fyl; // the central differences' 0.5 (see taps_interp)
     const int wl = c.w, hl = c.h;
     const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
-    const DSM_GLOBAL float *img = (const DSM_GLOBAL float *)c.img;
+    const TapBases img = tap_bases((const DSM_GLOBAL float *)c.img, wl);
     const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)c.pts;
     // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
     const float sc = c.scale;
@@ -239,8 +269,15 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       taps_load(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
-      float h0, h1, h2;
-      taps_interp(T, h0, h1, h2);
+      float h0, g1, g2;
+      taps_interp<false>(T, h0, g1, g2);
+      // makeImages' "non-finite gradient -> 0", the rare path: the taps are fetched again (so that the common path
+      // does not keep twelve registers alive for it) and the replacement is applied tap by tap
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(W.inb && !(__builtin_isfinite(g1) && __builtin_isfinite(g2))) != 0ull, 0)) {
+        Taps Tx;
+        taps_load(img, W.inb ? fxl * W.u + cxl : 2.5f, W.inb ? fyl * W.v + cyl : 2.5f, wl, Tx);
+        taps_interp<true>(Tx, h0, g1, g2);
+      }
       const float refColor = W.refColor;
       const bool fin = W.inb && __builtin_isfinite(h0); // :791
       const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
@@ -265,7 +302,7 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
         const unsigned m = use ? 0xFFFFFFFFu : 0u;
         auto keep = [m](float f) { return __uint_as_float(__float_as_uint(f) & m); };
         const float u = keep(W.u), v = keep(W.v), nid = keep(W.new_idepth);
-        const float dx = keep(h1 * fxl), dy = keep(h2 * fyl);
+        const float dx = keep(g1 * hfx), dy = keep(g2 * hfy); // dxInterp = hitColor[1] * fx (:814), 0.5 folded
         float J[9];
         J[0] = nid * dx;
         J[1] = nid * dy;
@@ -292,7 +329,7 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
         const float rx1 = ((M0 * x + M1 * y) + M2) / id;
         const float rx2 = ((M3 * x + M4 * y) + M5) / id;
         const float rx3 = ((M6 * x + M7 * y) + M8) / id;
-        const float dxfx = h1 * fxl, dyfy = h2 * fyl;
+        const float dxfx = g1 * hfx, dyfy = g2 * hfy;
         const float deno_sqrt = sc * rx3 + t2;
         const float deno = 1.0f / (deno_sqrt * deno_sqrt);
         const float xno = rx1 * t2 - rx3 * t0;
@@ -1262,8 +1299,11 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
 // rewritten) also runs the LM step -- no separate lm_kernel launch for this evaluation.  The step
 // reads the same partials in the same order: results are bit-identical to the two-kernel form.
 // ------------------------------------------------------------------------------------------
+// The plain form (levels >= 1 of the launch-per-step schedule) is held to 96 VGPRs = five waves per SIMD, which is worth
+// more there than the two or three registers the allocator would otherwise take (no spills); the level-0 and fused forms
+// need 104-109 and run four.
 template <int MODE, bool LVL0, bool FUSED>
-__global__ __launch_bounds__(kThreads) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 || FUSED || MODE == 1) ? 4 : 5))) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
                                                         int partial_stride, int lvl, int *__restrict__ tickets,
@@ -1783,59 +1823,89 @@ void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale) {
 
 // ------------------------------------------------------------------------------------------
 // makeImages (upstream DSO FrameHessian::makeImages; call sites FrontEnd.cpp:605,680)
-// texels are the reference's AoS (I, dx, dy): stride kTexel = 3 floats
+// The device keeps the INTENSITY plane of every level only; the reference's (I, dx, dy) texels are formed where they are
+// consumed (taps_interp) or handed back (dip_export_kernel).
 // ------------------------------------------------------------------------------------------
-// One launch per pyramid level: gradients of level l (central differences on the flat index, borders zero -- upstream
-// DSO FrameHessian::makeImages) and the intensities of level l+1 (2x2 mean, 0.25 * (a + b + c + d)) both read
-// only the intensities of level l.  src: those intensities with element stride `ss` (1: the raw level-0 image,
-// kTexel: the I channel of out_l itself for l >= 1).
+// One launch per pyramid level l: the intensities of level l+1 are the 2x2 means 0.25 * (a + b + c + d) of level l.
+// Level 0 also converts the camera image (float or "mono8" bytes, exactly) into the level-0 plane.
 template <typename SRC>
-__device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__restrict__ src, int ss, float *__restrict__ out_l,
+__device__ __forceinline__ void pyr_level_body(int wl, int hl, const SRC *__restrict__ src, float *__restrict__ out_l,
                                                float *__restrict__ out_next, int first, int step) {
-  constexpr int TS = kTexel;
-  const int npx = wl * hl, wn = wl >> 1, hn = hl >> 1;
-  const int lo = wl, hi = wl * (hl - 1);
+  const int wn = wl >> 1, hn = hl >> 1;
+  const int npx = out_l ? wl * hl : wn * hn;
   for (int idx = first; idx < npx; idx += step) {
-    float dx = 0.f, dy = 0.f;
-    if (idx >= lo && idx < hi) {
-      dx = 0.5f * ((float)src[ss * (idx + 1)] - (float)src[ss * (idx - 1)]);
-      dy = 0.5f * ((float)src[ss * (idx + wl)] - (float)src[ss * (idx - wl)]);
-      if (!__builtin_isfinite(dx)) dx = 0;
-      if (!__builtin_isfinite(dy)) dy = 0;
-    }
-    if (ss == 1) {
-      out_l[TS * idx] = (float)src[idx];
-    }
-    out_l[TS * idx + 1] = dx;
-    out_l[TS * idx + 2] = dy;
+    if (out_l) out_l[idx] = (float)src[idx];
     if (out_next && idx < wn * hn) {
       const int x = idx % wn, y = idx / wn;
       const int b = 2 * x + 2 * y * wl;
-      out_next[TS * idx] =
-          0.25f * ((float)src[ss * b] + (float)src[ss * (b + 1)] + (float)src[ss * (b + wl)] + (float)src[ss * (b + 1 + wl)]);
+      out_next[idx] = 0.25f * ((float)src[b] + (float)src[b + 1] + (float)src[b + wl] + (float)src[b + 1 + wl]);
     }
   }
 }
-__global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, int ss, float *__restrict__ out_l,
+// out_l != nullptr: level 0 (src = the camera image); else src = the plane of level l
+__global__ void pyr_level_fused_kernel(int wl, int hl, const float *__restrict__ src, float *__restrict__ out_l,
                                        float *__restrict__ out_next) {
-  pyr_level_body<float>(wl, hl, src, ss, out_l, out_next, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  pyr_level_body<float>(wl, hl, src, out_l, out_next, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 // the same for a batch of images (dsm_upload_images): blockIdx.y = image; U8: the level-0 source holds camera bytes
 // (main.cpp:216-217 "mono8"), converted exactly
 template <bool U8>
 __global__ void pyr_level_batched_kernel(int l, int nlevels, int wl, int hl, const PyrJob *__restrict__ jobs) {
   const PyrJob &j = jobs[blockIdx.y];
-  float *out_l = j.img[l];
   float *out_next = l + 1 < nlevels ? j.img[l + 1] : nullptr;
   const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
   if (l == 0) {
     if (U8)
-      pyr_level_body<unsigned char>(wl, hl, (const unsigned char *)j.raw, 1, out_l, out_next, first, step);
+      pyr_level_body<unsigned char>(wl, hl, (const unsigned char *)j.raw, j.img[0], out_next, first, step);
     else
-      pyr_level_body<float>(wl, hl, (const float *)j.raw, 1, out_l, out_next, first, step);
+      pyr_level_body<float>(wl, hl, (const float *)j.raw, j.img[0], out_next, first, step);
   } else {
-    pyr_level_body<float>(wl, hl, out_l, kTexel, out_l, out_next, first, step);
+    pyr_level_body<float>(wl, hl, j.img[l], nullptr, out_next, first, step);
   }
+}
+// The reference's texels from / against an intensity plane.  Gradients: central differences on the flat index for
+// idx in [w, w (h - 1)), zero elsewhere and where the difference is not finite (upstream DSO makeImages).
+__device__ __forceinline__ void dip_gradients(const float *__restrict__ I, int w, int h, int idx, float &dx, float &dy) {
+  dx = 0.f, dy = 0.f;
+  if (idx >= w && idx < w * (h - 1)) {
+    dx = 0.5f * (I[idx + 1] - I[idx - 1]);
+    dy = 0.5f * (I[idx + w] - I[idx - w]);
+    if (!__builtin_isfinite(dx)) dx = 0;
+    if (!__builtin_isfinite(dy)) dy = 0;
+  }
+}
+// dsm_tracker_get_frame: plane -> (I, dx, dy)
+__global__ void dip_export_kernel(int w, int h, const float *__restrict__ I, float *__restrict__ out3) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < w * h; idx += gridDim.x * blockDim.x) {
+    float dx, dy;
+    dip_gradients(I, w, h, idx, dx, dy);
+    out3[3 * idx] = I[idx];
+    out3[3 * idx + 1] = dx;
+    out3[3 * idx + 2] = dy;
+  }
+}
+// dsm_tracker_upload_frame, step 1: (I, dx, dy) -> plane
+__global__ void dip_import_kernel(int npx, const float *__restrict__ in3, float *__restrict__ I) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npx; idx += gridDim.x * blockDim.x) I[idx] = in3[3 * idx];
+}
+// step 2: the caller's gradient channels must be what makeImages derives from channel 0 (they are not stored): count
+// the texels of the rows makeImages fills whose dx or dy differs bitwise
+__global__ void dip_verify_kernel(int w, int h, const float *__restrict__ in3, const float *__restrict__ I, int *__restrict__ bad) {
+  int mine = 0;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < w * h; idx += gridDim.x * blockDim.x) {
+    if (idx < w || idx >= w * (h - 1)) continue; // rows makeImages leaves untouched are never read by the tracker
+    float dx, dy;
+    dip_gradients(I, w, h, idx, dx, dy);
+    mine += (__float_as_uint(dx) != __float_as_uint(in3[3 * idx + 1])) || (__float_as_uint(dy) != __float_as_uint(in3[3 * idx + 2]));
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+void launch_dip_export(hipStream_t s, int w, int h, const float *plane, float *out3) {
+  hipLaunchKernelGGL(dip_export_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w, h, plane, out3);
+}
+void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad) {
+  hipLaunchKernelGGL(dip_import_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w * h, in3, plane);
+  hipLaunchKernelGGL(dip_verify_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w, h, in3, plane, d_bad);
 }
 // descriptors of many trackers in one copy + one launch (after a batched hand-over every tracker's exposure changed)
 __global__ void desc_scatter_kernel(const TrackerDev *__restrict__ src, TrackerDev *const *__restrict__ dst) {
@@ -1873,18 +1943,20 @@ void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int r
   else
     hipLaunchKernelGGL(host_rows_copy_kernel<unsigned char>, grid, dim3(256), 0, s, d_jobs, njobs, row_units, rows, pitch);
 }
-// raw: the level-0 float image; img[l]: the AoS pyramid levels
+// raw: the level-0 float image; img[l]: the intensity planes of the pyramid levels
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img) {
   for (int l = 0; l < nlevels; l++) {
     const int wl = w >> l, hl = h >> l;
-    hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(wl * hl)), dim3(256), 0, s, wl, hl, l == 0 ? raw : img[l], l == 0 ? 1 : kTexel, img[l],
-                       l + 1 < nlevels ? img[l + 1] : nullptr);
+    if (l > 0 && l + 1 >= nlevels) break; // the coarsest level has nothing to produce
+    hipLaunchKernelGGL(pyr_level_fused_kernel, dim3(grid_for(l == 0 ? wl * hl : (wl >> 1) * (hl >> 1))), dim3(256), 0, s, wl, hl,
+                       l == 0 ? raw : img[l], l == 0 ? img[0] : nullptr, l + 1 < nlevels ? img[l + 1] : nullptr);
   }
 }
 void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, bool u8) {
   for (int l = 0; l < nlevels; l++) {
     const int wl = w >> l, hl = h >> l;
-    const dim3 grid(grid_for(wl * hl), njobs);
+    if (l > 0 && l + 1 >= nlevels) break;
+    const dim3 grid(grid_for(l == 0 ? wl * hl : (wl >> 1) * (hl >> 1)), njobs);
     if (u8)
       hipLaunchKernelGGL(pyr_level_batched_kernel<true>, grid, dim3(256), 0, s, l, nlevels, wl, hl, d_jobs);
     else

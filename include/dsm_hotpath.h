@@ -169,10 +169,15 @@ int dsm_tracker_get_template(dsm_tracker *t, int lvl, int *n, float *pc_u, float
 
 enum { DSM_SLOT_NEW_LEFT = 0, DSM_SLOT_NEW_RIGHT = 1 };
 /* replaces the consumption of FrameHessian::dIp[lvl] (TrackerAndScaler.cpp:709,1016):
- * dIp[lvl] is the reference's AoS Eigen::Vector3f (I,dx,dy) array of w_l*h_l texels. */
+ * dIp[lvl] is the reference's AoS Eigen::Vector3f (I,dx,dy) array of w_l*h_l texels.  The device keeps channel 0 only
+ * and forms the gradients where they are interpolated, from the neighbouring intensities, exactly as
+ * FrameHessian::makeImages (upstream DSO) defines them -- dx = 0.5 (I[idx+1] - I[idx-1]), dy = 0.5 (I[idx+w] - I[idx-w]),
+ * zero where not finite -- which is the only way the reference ever fills channels 1 and 2.  The call verifies that
+ * (bitwise, rows 1 .. h_l-2; makeImages leaves the first and last row unset and the tracker never reads them) and
+ * returns DSM_ERR_INVALID for texels that were built any other way. */
 int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, float ab_exposure);
-/* "next" row N1: build the (I,dx,dy) pyramid on the device from the level-0 float image
- * (upstream DSO FrameHessian::makeImages, call sites FrontEnd.cpp:605,680). */
+/* "next" row N1: build the pyramid on the device from the level-0 float image (upstream DSO FrameHessian::makeImages,
+ * call sites FrontEnd.cpp:605,680): the intensity plane of every level; see dsm_tracker_upload_frame. */
 int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure);
 /* the same hand-over for many frames in ONE call (the frames of a batched track / scale call): host->device copies
  * back to back on a copy stream, pyramids of a group of images built under the copies of the next group, five batched
@@ -202,7 +207,8 @@ int dsm_frames_advance(dsm_context *ctx, int n, dsm_tracker *const *trackers, co
  * counterpart -- the reference keeps its images in ordinary host memory */
 int dsm_host_alloc(size_t bytes, void **out);
 int dsm_host_free(void *p);
-/* read back one pyramid level (AoS float3) */
+/* read back one pyramid level as the reference's AoS (I,dx,dy) texels (gradients as makeImages forms them, zero in the
+ * first and last row) */
 int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out);
 
 /* replaces calcResPose + calcGSSSEPose as ONE fused evaluation (TrackerAndScaler.cpp:699-852, 640-697).

@@ -62,6 +62,26 @@ def make_scene(size="small", seed=3, noise=1.0, template="dense", idepth_scale=1
     return sc
 
 
+def regrad(level):
+    """Gradient channels of one pyramid level [h, w, 3] rebuilt from channel 0 exactly as FrameHessian::makeImages (upstream
+    DSO) forms them: central differences on the flat index for idx in [w, w (h - 1)), zero elsewhere and where the
+    difference is not finite.  Tests that edit intensities after make_images call this so that the (I, dx, dy) texels
+    stay what the reference would have built -- dsm_tracker_upload_frame checks that they are."""
+    h, w, _ = level.shape
+    out = np.zeros_like(level)
+    I = level[..., 0].reshape(-1).astype(np.float32)
+    out[..., 0] = level[..., 0]
+    idx = np.arange(w, w * (h - 1))
+    with np.errstate(invalid="ignore", over="ignore"):
+        dx = np.float32(0.5) * (I[idx + 1] - I[idx - 1])
+        dy = np.float32(0.5) * (I[idx + w] - I[idx - w])
+    dx[~np.isfinite(dx)] = 0
+    dy[~np.isfinite(dy)] = 0
+    out.reshape(-1, 3)[idx, 1] = dx
+    out.reshape(-1, 3)[idx, 2] = dy
+    return out
+
+
 def oracle_tracker(sc, params=None):
     orc = O.OracleTracker(sc.w, sc.h, sc.nl, sc.T, sc.K, params)
     orc.make_k(*sc.K)

@@ -4,7 +4,7 @@ reference's row-major order, so the templates must be identical arrays, not just
 import numpy as np
 import pytest
 
-from _scenes import O, S, hip_tracker, make_scene
+from _scenes import O, S, hip_tracker, make_scene, regrad
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +33,7 @@ def test_set_ref_from_points_matches_oracle(ctx, size, npts):
     pu, pv, pid, pw = _points(sc, 81, npts)
     ref = [p.copy() for p in sc.ref_p]
     ref[0][min(40, sc.h - 5), min(50, sc.w - 5), 0] = np.nan  # non-finite reference colour is dropped (:302)
+    ref[0] = regrad(ref[0])
     orc = O.OracleTracker(sc.w, sc.h, sc.nl, sc.T, sc.K)
     orc.make_k(*sc.K)
     exp = orc.make_coarse_depth_l0(pu, pv, pid, pw, ref)

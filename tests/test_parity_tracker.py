@@ -14,7 +14,7 @@ import pytest
 from direct_stereo_slam_amd import synth as S
 from oracle import oracle as O
 
-from _scenes import hip_tracker, make_scene, oracle_tracker
+from _scenes import hip_tracker, make_scene, oracle_tracker, regrad
 
 pytestmark = pytest.mark.gpu
 
@@ -149,6 +149,7 @@ def test_edge_cases(ctx):
     # non-positive inverse depths in the template
     sc.new_p[0][40:44, 100:140, 0] = np.nan
     sc.new_p[0][50, 60:70, 0] = np.inf
+    sc.new_p[0] = regrad(sc.new_p[0])  # makeImages zeroes the non-finite gradients around them
     sc.tpl[2][0][5] = np.nan
     sc.tpl[2][0][6] = -0.1
     sc.tpl[2][0][7] = 0.0
@@ -186,6 +187,30 @@ def test_device_pyramid_matches_make_images(ctx, size):
     sc = make_scene(size, seed=15)
     trk = hip_tracker(ctx, sc)
     trk.upload_image(0, sc.new_img, 1.0)
+    for lvl in range(sc.nl):
+        np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
+
+
+def test_upload_frame_keeps_intensities_and_checks_gradients(ctx):
+    """The device stores channel 0 of the reference's (I, dx, dy) texels only and forms the gradients where they are used:
+    dsm_tracker_upload_frame therefore insists that channels 1 and 2 are makeImages' central differences of channel 0
+    (rows 1 .. h-2; the first and last row are left unset by makeImages and never read), and dsm_tracker_get_frame
+    hands the full texels back"""
+    from direct_stereo_slam_amd._lib import DsmError
+
+    sc = make_scene("small", seed=16)
+    trk = hip_tracker(ctx, sc)
+    for ch in (1, 2):
+        bad = [p.copy() for p in sc.new_p]
+        bad[1][5, 7, ch] = np.nextafter(bad[1][5, 7, ch], np.float32(np.inf))  # one ulp off, one texel
+        with pytest.raises(DsmError, match="central differences"):
+            trk.upload_frame(0, bad)
+    with pytest.raises(DsmError):  # the slot holds no frame after a refused hand-over
+        trk.calcResPose(0, sc.gt_pose, sc.gt_aff, 20.0)
+    ok = [p.copy() for p in sc.new_p]
+    ok[0][0, :, 1:] = 7.0
+    ok[0][-1, :, 1:] = -3.0
+    trk.upload_frame(0, ok)
     for lvl in range(sc.nl):
         np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
 

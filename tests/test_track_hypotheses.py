@@ -6,7 +6,7 @@ import pytest
 from direct_stereo_slam_amd import synth as S
 from oracle import oracle as O
 
-from _scenes import hip_tracker, make_scene, oracle_tracker
+from _scenes import hip_tracker, make_scene, oracle_tracker, regrad
 from test_replay_sequence import mul_pose
 
 pytestmark = pytest.mark.gpu
@@ -64,7 +64,7 @@ def test_batched_hypotheses_match_sequential_reference(ctx, case):
         const_motion, last_rmse0 = S.IDENTITY_POSE.copy(), 0.5
     else:
         sc = make_scene("small", seed=83)
-        sc.new_p = [np.full_like(p, np.nan) for p in sc.new_p]  # a frame with no usable texel: every try fails
+        sc.new_p = [regrad(np.full_like(p, np.nan)) for p in sc.new_p]  # a frame with no usable texel: every try fails
         const_motion, last_rmse0 = S.IDENTITY_POSE.copy(), 1.0
     tries = reference_tries(const_motion)
     assert len(tries) in (83, 109)
