@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidths (two access patterns) and exit")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search alone instead")
     ap.add_argument("--no-ringkey-leg", action="store_true", help="N > 1: skip the sharded ring-key leg of the default line")
+    ap.add_argument("--ringkey-leg-seconds", type=float, default=120.0, help="N > 1: deadline of the sharded ring-key leg; a rank that misses it reports an error in config.ringkey_sharded and the line is printed regardless")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
     return ap.parse_args()
@@ -629,6 +630,31 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
             "shards": world, "merge": "dsm_ringdb_merge_topk (C ABI, librccl)" if world > 1 else "one shard: no merge", **res}
 
 
+def run_with_deadline(fn, seconds, device):
+    """fn() on a worker thread bound to this rank's device; returns (result, still_running).  Exceptions and a missed
+    deadline become {"error": ...}."""
+    import threading
+
+    box = {}
+
+    def target():
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)  # the current device is per thread
+            box["res"] = fn()
+        except BaseException as e:  # noqa: BLE001
+            box["res"] = {"error": repr(e)}
+
+    th = threading.Thread(target=target, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"no result within {seconds:.0f} s (this rank left the leg; the bench line above it is unaffected)"}, True
+    return box["res"], False
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def bench_tracking(args):
     from direct_stereo_slam_amd.tracker import Context
@@ -674,13 +700,15 @@ def bench_tracking(args):
             del wl2
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["reference_five_level"] = {"error": repr(e)}
+    stuck = False
     if world > 1 and not args.no_ringkey_leg and args.device_override < 0:  # (RCCL refuses two ranks on one device)
-        try:
-            res["config"]["ringkey_sharded"] = ringkey_sharded_leg(args, ctx, rank, world)
-        except Exception as e:
-            res["config"]["ringkey_sharded"] = {"error": repr(e)}
+        # A reported extra must never cost the bench line: the leg runs under a deadline (a collective that one rank never
+        # enters would otherwise hold every rank until the driver's own limit), and a rank whose leg is stuck prints and leaves.
+        res["config"]["ringkey_sharded"], stuck = run_with_deadline(lambda: ringkey_sharded_leg(args, ctx, rank, world), args.ringkey_leg_seconds, local)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+    if stuck:
+        os._exit(0)  # the worker thread still sits in a collective: no orderly teardown possible
     if world > 1:
         import torch.distributed as dist
 

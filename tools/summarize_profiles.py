@@ -121,7 +121,9 @@ if fetch is not None:
         "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-second-leg --steps 2 --warmup 1",
         "config": pb["config"]["name"], "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
-        "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; tap gathers (12-byte texels) taken as reported",
+        "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; the tap gathers of the 4-byte-per-texel intensity plane are taken as reported -- calibrated on known byte counts by tools/pmc_calibrate.sh (<tag>_pmc_calibration.json: template stream tallied at 0.50, tap stream at 0.95 of its unique bytes)",
+        "layout_bytes": n_evals * (16 * n0 + 4 * w * h),
+        "hbm_bytes_per_layout_byte_level0_pose_eval": (corrected + wr) / (n_evals * (16 * n0 + 4 * w * h)),
         "hbm_read_bytes_corrected": corrected, "hbm_bytes_corrected": corrected + wr,
         "hbm_bytes_per_algorithmic_byte_level0_pose_eval": (corrected + wr) / alg,
         "raw_fetch_per_algorithmic_byte": raw_fetch / alg,
