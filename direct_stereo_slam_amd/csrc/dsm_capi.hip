@@ -988,7 +988,16 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     // rejected steps.  It pays where a launch is latency- and not bandwidth-bound and rejections come in runs: the
     // small levels (a few thousand points).  Measured (S2 dense, launch form): 64 frames +12 %, 512 frames +-0 %, one
     // frame -1 % when applied to every level (the fine levels end on their first rejection), DESIGN.md section 4.3.
-    spec[L] = P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192);
+    // "Latency-bound" is a property of the launch, not of the level alone: a stream group's launch over G problems of n points
+    // evaluates G * n points, and above about a million of them the doubled work costs more than the saved launches give back
+    // (S2 dense, 512 + 103 problems in two groups, level 3 = 2.3 M points per launch: 51.3-51.8 k frames/s with the second
+    // candidate there, 52.3-52.6 k without; levels 4 and 5, 0.58 M and 0.14 M points, make no measurable difference).
+    {
+      int groups = ctx->n_streams < 1 ? 1 : ctx->n_streams;
+      if (groups > N) groups = N;
+      const long long launch_points = (long long)((N + groups - 1) / groups) * max_n;
+      spec[L] = P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192 && launch_points <= 1000000ll);
+    }
   }
   int *sched = ctx->sched[mode], *sched2 = ctx->sched[mode2];
   if (n2 > 0 && !ctx->companion_stream) {

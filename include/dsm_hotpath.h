@@ -89,7 +89,8 @@ typedef struct dsm_params {
                                          the coarse levels -- costs no launch of its own.  Same evaluations, decisions and
                                          per-level evaluation counts as the sequential loop; the speculative evaluation of
                                          an ACCEPTED step is discarded (not counted).  0 never, 1 (default) on levels of at most
-                                         8192 template points (where launches are latency-bound and rejections come in runs),
+                                         8192 template points whose launches evaluate at most a million points per stream
+                                         group (where launches are latency-bound and rejections come in runs),
                                          2 on every level.  Scheduling only -- results are bit-identical. */
 } dsm_params;
 
