@@ -29,8 +29,8 @@ static int invalid(const char *msg) {
 }
 
 // One intensity plane of a w x h level.  Lanes whose point is not usable fetch their twelve taps around texel (2, 2)
-// instead (rows 1-4, columns 1-4): four rows and a few texels of slack keep that inside the allocation on levels
-// smaller than 5 x 5, where no point is usable anyway.
+// instead (rows 1-4, columns 1-4), always inside the image (dsm_tracker_create wants a coarsest level of at least 8 x 8);
+// the four rows and few texels of slack are belt and braces.
 static size_t plane_bytes(int w, int h) { return sizeof(float) * ((size_t)w * h + 4 * (size_t)w + 16); }
 
 int ensure_stage(dsm_context *ctx, size_t floats) {

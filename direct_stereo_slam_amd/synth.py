@@ -154,11 +154,11 @@ def dense_template(scene, K, w, h, nlevels, ref_pyr, idepth_scale=1.0, R=None, t
     for l in range(nlevels):
         wl, hl = w >> l, h >> l
         idl = scene.idepth(level_K(K, l), wl, hl, R, t) * np.float32(idepth_scale)
-        ys, xs = np.mgrid[2:hl - 2, 2:wl - 2]
+        ys, xs = np.mgrid[2:max(2, hl - 2), 2:max(2, wl - 2)]  # (levels smaller than 5 x 5 have no interior)
         us.append(xs.astype(np.float32).ravel())
         vs.append(ys.astype(np.float32).ravel())
-        ids.append(np.ascontiguousarray(idl[2:hl - 2, 2:wl - 2]).ravel())
-        cs.append(np.ascontiguousarray(ref_pyr[l][2:hl - 2, 2:wl - 2, 0]).ravel())
+        ids.append(np.ascontiguousarray(idl[2:max(2, hl - 2), 2:max(2, wl - 2)]).ravel())
+        cs.append(np.ascontiguousarray(ref_pyr[l][2:max(2, hl - 2), 2:max(2, wl - 2), 0]).ravel())
     return us, vs, ids, cs
 
 

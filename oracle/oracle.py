@@ -164,6 +164,9 @@ class OracleTracker:
 
     def set_ref(self, ref_id, ref_a, ref_b, ref_exposure, pc_u, pc_v, pc_idepth, pc_color):
         n = (C.c_int * self.nlevels)(*[len(a) for a in pc_u])
+        for lvl, a in enumerate(pc_u):  # the reference's per-level arrays hold w_l * h_l entries (TrackerAndScaler.cpp:52-64)
+            if len(a) > (self.w >> lvl) * (self.h >> lvl):
+                raise ValueError(f"level {lvl}: more template points than pixels")
         arrs = [[np.ascontiguousarray(a, np.float32) for a in lst] for lst in (pc_u, pc_v, pc_idepth, pc_color)]
         self.L.orc_tracker_set_ref(self.h_, ref_id, ref_a, ref_b, ref_exposure, n, *[_ptr_array(a) for a in arrs])
 

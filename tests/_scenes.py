@@ -16,6 +16,7 @@ SIZES = {
     "malaga": (1024, 768, 0, 5),   # configs[2]: cams/malaga/camera0.txt:1-4
     "kitti6": (1248, 384, 0, 6),   # S2: the metric's own configuration, 1241x376 padded to a multiple of 32, six levels
     "hd6": (1920, 1080, 0, 6),     # S3 / configs[3]: 1920x1080, six floor-halved levels (1920x1080 ... 60x33), full size
+    "mini4": (64, 64, 3, 4),       # the smallest pyramid the library accepts: an 8 x 8 coarsest level
 }
 # (fx, fy, cx, cy) at the working size and the stereo baseline for sizes that are not KITTI-00
 CAMERAS = {

@@ -191,6 +191,28 @@ def test_device_pyramid_matches_make_images(ctx, size):
         np.testing.assert_array_equal(trk.get_frame(0, lvl), sc.new_p[lvl])
 
 
+def test_smallest_pyramid(ctx):
+    """the library wants a coarsest level of at least 8 x 8 (a tap fetch spans a 4 x 4 neighbourhood inside the
+    2 < u < w - 3 window); at exactly that size -- 16 interior template points, one partly filled wave -- evaluations and the
+    whole LM loop agree with the oracle, and a deeper pyramid of the same image is refused"""
+    from direct_stereo_slam_amd._lib import DsmError
+    from direct_stereo_slam_amd.tracker import TrackerAndScaler
+
+    sc = make_scene("mini4", seed=21)
+    assert sc.new_p[-1].shape[:2] == (8, 8) and len(sc.tpl[0][-1]) == 16
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    for lvl in range(sc.nl):
+        assert_eval_pose_equal(orc, trk, lvl, sc.gt_pose, sc.gt_aff, 20.0)
+        assert_eval_scale_equal(orc, trk, lvl, 1.0, 20.0)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, [0.0, 0.0], sc.nl - 1)
+    good_g, pose_g, aff_g, last_g = trk.trackNewestCoarse(S.IDENTITY_POSE, [0.0, 0.0], sc.nl - 1)
+    assert good_g == good_o
+    np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
+    assert list(ctx.stats().evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
+    with pytest.raises(DsmError, match="too small"):
+        TrackerAndScaler(ctx, sc.w, sc.h, sc.nl + 1, sc.T, sc.K)
+
+
 def test_upload_frame_keeps_intensities_and_checks_gradients(ctx):
     """The device stores channel 0 of the reference's (I, dx, dy) texels only and forms the gradients where they are used:
     dsm_tracker_upload_frame therefore insists that channels 1 and 2 are makeImages' central differences of channel 0
