@@ -355,14 +355,21 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
     layout_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 48 * n0)  # what this implementation keeps in HBM for the same evaluation: the intensity plane only (gradients are formed from neighbouring intensities)
     l0_ms = stt.eval_kernel_union_ms[0]
     l0_launches, l0_dispatches, l0_evals = stt.launches[0], stt.eval_dispatches[0], stt.evals[0]
-    achieved = (l0_evals * bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    # The last evaluation of a level's LM loop runs residual-only when the loop is known to end after it (dsm_stats.
+    # evals_residual_only): calcResPose in full -- which is what SURVEY.md 8(d)'s per-evaluation figure prices: the template
+    # and the (I, dx, dy) texels calcResPose interpolates -- without the calcGSSSEPose the reference runs on it and never
+    # reads.  Counted like every other evaluation; reported next to the total.
+    l0_ro = stt.evals_residual_only[0]
+    l0_bytes = l0_evals * bytes_eval0
+    achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
     ratio, src = pmc_traffic_ratio(wl["config"])
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": ratio * l0_evals * bytes_eval0 / max(1, l0_launches) if ratio is not None else None,
+                "traffic": ratio * l0_bytes / max(1, l0_launches) if ratio is not None else None,
                 "traffic_source": f"{src}: stored rocprofv3 --pmc summary of this command, scaled to this run's bytes per launch (not re-measured here)" if src else None,
                 "kernel": "eval_kernel<pose, LVL0>", "bytes_per_eval": int(bytes_eval0),
                 "layout_bytes_per_eval": int(layout_eval0), "achieved_on_layout_bytes": achieved * layout_eval0 / bytes_eval0,
-                "bytes_per_launch": l0_evals * bytes_eval0 / max(1, l0_launches),
+                "evals": int(l0_evals), "residual_only_evals": int(l0_ro),
+                "bytes_per_launch": l0_bytes / max(1, l0_launches),
                 "avg_launch_us": 1e3 * stt.eval_kernel_ms[0] / max(1, l0_dispatches), "launches": int(l0_launches),
                 "dispatches": int(l0_dispatches), "stream_groups": args.streams,
                 "kernel_busy_us_per_launch": 1e3 * l0_ms / max(1, l0_launches)}
@@ -379,8 +386,8 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
         nl_ = len(wl["trackers"][0].get_template(l)[0])
         by = 16 * nl_ + min(12 * (wl["w"] >> l) * (wl["h"] >> l), 48 * nl_)
         ms = stt.eval_kernel_union_ms[l]
-        per_level.append({"lvl": l, "evals": int(stt.evals[l]), "launches": int(stt.launches[l]), "kernel_ms": round(ms, 4),
-                          "GBps": round(stt.evals[l] * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        per_level.append({"lvl": l, "evals": int(stt.evals[l]), "residual_only": int(stt.evals_residual_only[l]), "launches": int(stt.launches[l]),
+                          "kernel_ms": round(ms, 4), "GBps": round(stt.evals[l] * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     all_bytes = stt.algorithmic_bytes + sts.algorithmic_bytes
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": int(stt.queue_blocks), "adaptive_schedule": not args.no_adaptive,

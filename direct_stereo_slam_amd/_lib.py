@@ -54,6 +54,7 @@ class Stats(C.Structure):
         ("queue_blocks", C.c_int64),
         ("queue_items", C.c_int64),
         ("queue_kernel_ms", C.c_double),
+        ("evals_residual_only", C.c_int64 * MAX_LEVELS),
     ]
 
 

@@ -1174,8 +1174,9 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     for (int l = 0; l < nlevels; l++) {
       if ((int)S.rounds[l] > nd[l]) nd[l] = (int)S.rounds[l]; // launches this problem needed at the level
       st.evals[l] += S.evals[l];
-      // compulsory bytes of one evaluation: the template once + the target image once, or, for a sparse template,
-      // the four 12-byte taps of every point if that is less
+      st.evals_residual_only[l] += S.evals_ro[l];
+      // compulsory bytes of one evaluation (what calcRes* reads): the template once + the target image once,
+      // or, for a sparse template, the four 12-byte taps of every point if that is less
       const long long nl = ts[i]->desc.lv[l].n, img = 12ll * (ts[i]->w >> l) * (ts[i]->h >> l);
       st.algorithmic_bytes += S.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
     }

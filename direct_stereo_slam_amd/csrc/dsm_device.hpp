@@ -29,7 +29,10 @@ constexpr int kTexel = 1;         // floats per target texel: the intensity; gra
 struct LevelDev {
   const float4 *pts;   // n template points
   const float *img[2]; // slot 0 = new left frame, slot 1 = right frame: intensity planes
-  int n, w, h, pad;
+  int n, w, h;
+  int residual_only; // the LM loop ends after this evaluation whatever it yields (:588, the iteration bound): only the
+                     // residual side (calcResPose / calcResScale) is needed -- the normal equations calcGSSSE* would build
+                     // from it are never read by the reference either
   float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
   float Ki[9];              // inverse of K at this level (float, :135-140)
   float fx1, fy1, cx1, cy1; // camera 1 (:89-98)
@@ -61,7 +64,10 @@ struct EvalIn {
   // (scalar) read of this struct instead of chasing tracker -> level -> pointer
   const float4 *pts;
   const float *img;
-  int n, w, h, pad;
+  int n, w, h;
+  int residual_only; // the LM loop ends after this evaluation whatever it yields (:588, the iteration bound): only the
+                     // residual side (calcResPose / calcResScale) is needed -- the normal equations calcGSSSE* would build
+                     // from it are never read by the reference either
   float fx, fy, cx, cy; // intrinsics of the camera the points are projected into (cam0 pose / cam1 scale)
   float Ki[9];          // K^-1 of camera 0 at this level (flow indicators)
   float huber;
@@ -97,6 +103,7 @@ struct alignas(16) LMState {
   double min_res[DSM_MAX_LEVELS];
   double flow[3];
   long long evals[DSM_MAX_LEVELS];
+  long long evals_ro[DSM_MAX_LEVELS]; // ... of which residual-only (EvalIn::residual_only)
   long long rounds[DSM_MAX_LEVELS]; // LM steps taken at each level = evaluation launches it needed (with a speculative
                                     // candidate consumed a step covers two evaluations)
   EvalIn in;

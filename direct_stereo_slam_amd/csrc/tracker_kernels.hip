@@ -78,6 +78,8 @@ __device__ __forceinline__ TapBases tap_bases(const DSM_GLOBAL float *img, int w
   const long pitch = 4l * w;
   return TapBases{cb - pitch, cb - 4, cb + pitch - 4, cb + 2 * pitch};
 }
+// GRAD = false (residual-only evaluations): rows y-1 and y+2 are not fetched (the intensity needs rows y, y+1 only).
+template <bool GRAD = true>
 __device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
   const int iy = (int)y;
@@ -88,12 +90,16 @@ __device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, i
   const unsigned off = 4u * (unsigned)(ix + iy * w);
   const fvec4u a = *(const DSM_GLOBAL fvec4u *)(B.r1 + off); // (x-1 .. x+2, y)
   const fvec4u b = *(const DSM_GLOBAL fvec4u *)(B.r2 + off); // (x-1 .. x+2, y+1)
-  const fvec2u c = *(const DSM_GLOBAL fvec2u *)(B.r0 + off); // (x, x+1; y-1)
-  const fvec2u d = *(const DSM_GLOBAL fvec2u *)(B.r3 + off); // (x, x+1; y+2)
   T.r1[0] = a.x, T.r1[1] = a.y, T.r1[2] = a.z, T.r1[3] = a.w;
   T.r2[0] = b.x, T.r2[1] = b.y, T.r2[2] = b.z, T.r2[3] = b.w;
-  T.r0[0] = c.x, T.r0[1] = c.y;
-  T.r3[0] = d.x, T.r3[1] = d.y;
+  if (GRAD) {
+    const fvec2u c = *(const DSM_GLOBAL fvec2u *)(B.r0 + off); // (x, x+1; y-1)
+    const fvec2u d = *(const DSM_GLOBAL fvec2u *)(B.r3 + off); // (x, x+1; y+2)
+    T.r0[0] = c.x, T.r0[1] = c.y;
+    T.r3[0] = d.x, T.r3[1] = d.y;
+  } else {
+    T.r0[0] = T.r0[1] = T.r3[0] = T.r3[1] = 0.f;
+  }
 }
 
 // h0 (the intensity) decides in/out, Huber and cut-off: exact reference operation order.  g1 / g2 are TWICE the
@@ -112,13 +118,16 @@ __device__ __forceinline__ void taps_gradients(const Taps &T, float w00, float w
   g1 = __builtin_fmaf(w00, d00, __builtin_fmaf(w10, d10, __builtin_fmaf(w01, d01, w11 * d11)));
   g2 = __builtin_fmaf(w00, e00, __builtin_fmaf(w10, e10, __builtin_fmaf(w01, e01, w11 * e11)));
 }
-template <bool EXACT>
+template <bool EXACT, bool GRAD = true>
 __device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1, float &g2) {
   const float dx = T.dx, dy = T.dy;
   const float dxdy = dx * dy;
   const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
   h0 = ((w11 * T.r2[2] + w01 * T.r2[1]) + w10 * T.r1[2]) + w00 * T.r1[1];
-  taps_gradients<EXACT>(T, w00, w10, w01, w11, g1, g2);
+  if (GRAD)
+    taps_gradients<EXACT>(T, w00, w10, w01, w11, g1, g2);
+  else
+    g1 = g2 = 0.f;
 }
 
 // per-point state carried from the warp stage to the consume stage
@@ -142,6 +151,7 @@ struct EvalConsts {
   float M[9];
   float t[3];
   float aff0, aff1, b0, scale, cutoff, max_energy;
+  int residual_only; // EvalIn::residual_only
 };
 
 // Chunk partials are produced by one workgroup and consumed by another (the LM step), possibly on a
@@ -182,9 +192,11 @@ __device__ __forceinline__ fvec4 load_partial4(const float *p) {
 // partial `out` (global memory in eval_kernel, LDS in coarse_kernel).  `red` is this thread group's
 // [16][kNumSlots] LDS scratch.  Contains two workgroup barriers: every thread of the workgroup must
 // call it; thread groups without a chunk pass active = false.
-template <int MODE, bool LVL0>
-__device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                           float *out) {
+// RO = residual-only (EvalIn::residual_only): the residual side alone -- energy, counts, flow indicators; no gradients, no
+// Jacobian, no normal-equation sums (their partial slots are written as zeros), two tap loads per point instead of four.
+template <int MODE, bool LVL0, bool RO>
+__device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
+                                                float *out) {
   const int n = c.n;
   const int P = pts_per_thread(n);
   constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
@@ -266,14 +278,14 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       W.refColor = p.w;
       W.x = x, W.y = y, W.id = id;
       W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-      taps_load(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
+      taps_load<!RO>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, T);
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
       float h0, g1, g2;
-      taps_interp<false>(T, h0, g1, g2);
+      taps_interp<false, !RO>(T, h0, g1, g2);
       // makeImages' "non-finite gradient -> 0", the rare path: the taps are fetched again (so that the common path
       // does not keep twelve registers alive for it) and the replacement is applied tap by tap
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(W.inb && !(__builtin_isfinite(g1) && __builtin_isfinite(g2))) != 0ull, 0)) {
+      if (!RO && __builtin_expect(__builtin_amdgcn_ballot_w64(W.inb && !(__builtin_isfinite(g1) && __builtin_isfinite(g2))) != 0ull, 0)) {
         Taps Tx;
         taps_load(img, W.inb ? fxl * W.u + cxl : 2.5f, W.inb ? fyl * W.v + cyl : 2.5f, wl, Tx);
         taps_interp<true>(Tx, h0, g1, g2);
@@ -296,7 +308,9 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
       n_sat += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && sat));
       n_warped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(use));
       const float wgt = use ? hw : 0.0f;
-      if (MODE != 1) {
+      if (RO) {
+        // nothing else: the sums below feed calcGSSSE*, whose output the ending loop never reads
+      } else if (MODE != 1) {
         // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
         // lanes get all-zero inputs so that they add exact zeros
         const unsigned m = use ? 0xFFFFFFFFu : 0u;
@@ -471,7 +485,7 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
   const bool writer = (lane & 15) == 0;
 #pragma unroll
   for (int i = 0; i < NACC; i++) {
-    const float s = row16_sum(acc[i]);
+    const float s = RO ? 0.0f : row16_sum(acc[i]);
     if (writer) red[row][i] = s;
   }
   {
@@ -503,6 +517,15 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
     for (int r = 0; r < 16; r++) s += __float_as_int(red[r][tid]);
     store_partial(out + tid, __int_as_float(s));
   }
+}
+
+template <int MODE, bool LVL0>
+__device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
+                                           float *out) {
+  if (c.residual_only) // wave-uniform
+    eval_chunk_impl<MODE, LVL0, true>(c, chunk, tid, active, red, out);
+  else
+    eval_chunk_impl<MODE, LVL0, false>(c, chunk, tid, active, red, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -634,8 +657,9 @@ __device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &
 // Builds the inputs of the next evaluation and (store) writes them to the problem state: called by lane 0
 // alone, or by a whole wave with wave-uniform arguments and store = (lane == 0).
 // spec: the inputs go to the speculative slot (S.spec_in) instead of S.in.
+// residual_only: the loop is known to end after this evaluation (see EvalIn).
 __device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
-                              float scale, float cutoff, bool store = true, bool spec = false) {
+                              float scale, float cutoff, bool store = true, bool spec = false, bool residual_only = false) {
   EvalIn e;
   if (mode == 1)
     make_eval_scale(T, e, lvl, scale, cutoff);
@@ -643,6 +667,7 @@ __device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, i
     make_eval_points3d(T, e, lvl, pose, aff, cutoff);
   else
     make_eval_pose(T, e, lvl, pose, aff, cutoff);
+  e.residual_only = residual_only ? 1 : 0;
   if (store) {
     if (spec)
       S.spec_in = e;
@@ -886,7 +911,10 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, do
       S.phase = PH_ITER;
     }
   }
-  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0, spec);
+  // Is this the loop's last evaluation?  The step that consumes it ends the level when the increment is small (:588) or the
+  // iteration bound is reached (:505) -- both known now; the speculative proposal is consumed one iteration later.
+  const bool last = !(sqrt(nrm) > 1e-3) || S.iteration + (spec ? 2 : 1) >= T.p.max_iterations[S.lvl];
+  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0, spec, last);
 }
 
 // lane 0 only: :897-913
@@ -908,7 +936,8 @@ __device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, f
     S.scale_cand = cand;
     S.phase = PH_ITER;
   }
-  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, true, spec);
+  const bool last = !(inc > 1e-3) || S.iteration + (spec ? 2 : 1) >= T.p.max_iterations[S.lvl]; // :937 (signed, Q7) / :897
+  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, true, spec, last);
 }
 
 // lane 0 only
@@ -1132,6 +1161,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
     }
     if (lane == 0) {
       S.evals[lvl]++;
+      S.evals_ro[lvl] += S.in.residual_only;
       if (accept) { // :576-581 / :926-930
         for (int i = 0; i < 6; i++) S.res_old[i] = rs[i];
         if (pose_like) {
@@ -1172,6 +1202,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
       }
       if (lane == 0) {
         S.evals[lvl]++;
+        S.evals_ro[lvl] += S.spec_in.residual_only;
         if (accept2) {
           for (int i = 0; i < 6; i++) S.res_old[i] = rs2[i];
           if (pose_like) {
@@ -1336,6 +1367,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 
     for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
     c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
+    c.residual_only = in.residual_only;
     __shared__ float red[16][kNumSlots];
     eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
     if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
@@ -1423,6 +1455,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
         S.last_inners[i] = 0;
         S.min_res[i] = I.min_res[i];
         S.evals[i] = 0;
+        S.evals_ro[i] = 0;
         S.rounds[i] = 0;
       }
       S.spec_valid = 0;
@@ -1549,6 +1582,7 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
       c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
       c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
       c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
+      c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
     }
     const int nch = num_chunks(c.n);
     for (int c0 = 0; c0 < nch; c0 += kCoarseGroups) {
@@ -1710,6 +1744,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
       c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
       c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
       c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
+      c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
     }
     const int nch = num_chunks(c.n);
     const int nitems = nch > 0 ? nch : 1; // an empty level still needs its LM step

@@ -96,7 +96,8 @@ typedef struct dsm_params {
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
 typedef struct dsm_stats {
-  int64_t evals[DSM_MAX_LEVELS];        /* fused residual+Jacobian evaluations executed, summed over the batch */
+  int64_t evals[DSM_MAX_LEVELS];        /* evaluations executed, summed over the batch: fused residual + Jacobian (calcRes* +
+                                           calcGSSSE*), except the evals_residual_only below */
   int64_t launches[DSM_MAX_LEVELS];     /* eval kernel launches per level */
   int64_t algorithmic_bytes;            /* sum over evals of 16*n_l + min(12*w_l*h_l, 48*n_l)   */
   double eval_kernel_ms[DSM_MAX_LEVELS];/* summed HIP-event durations of the eval kernel dispatches per level (timing enabled) */
@@ -108,6 +109,10 @@ typedef struct dsm_stats {
   int64_t queue_blocks;                 /* work-queue kernel: persistent workgroups launched (0: launch-per-step form) */
   int64_t queue_items;                  /* work-queue kernel: (problem, chunk) items processed */
   double queue_kernel_ms;               /* work-queue kernel: HIP-event duration of the launch (timing enabled) */
+  int64_t evals_residual_only[DSM_MAX_LEVELS]; /* of evals[]: the last evaluation of a level's LM loop when the loop is known
+                                           to end after it (increment below 1e-3, TrackerAndScaler.cpp:588 / :937, or the
+                                           iteration bound): the reference runs calcGSSSE* on it and never reads the result;
+                                           here only calcRes* is executed for it */
 } dsm_stats;
 
 const char *dsm_last_error(void);

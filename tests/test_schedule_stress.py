@@ -66,6 +66,42 @@ def test_speculation_keeps_the_evaluation_counts_and_saves_launches(ctx):
     assert launches[2] < launches[0]
 
 
+def test_last_evaluation_of_a_level_is_residual_only(ctx):
+    """The LM loop of a level ends after the evaluation of a step whose increment is below 1e-3 (TrackerAndScaler.cpp:588,
+    :937) or at the iteration bound: the reference still runs calcGSSSE* on it and never reads the result.  Here that
+    evaluation executes calcRes* alone (EvalIn::residual_only) -- exactly one per level whose loop made a step, counted in
+    dsm_stats.evals_residual_only, in every scheduling form, with the same poses, residuals and evaluation counts"""
+    from _scenes import oracle_tracker
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene("medium", seed=33)
+    orc = oracle_tracker(sc)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    want = orc.eval_counts()[0][:sc.nl]
+    err_o, s_o = orc.optimize_scale(1.0, sc.nl - 1)
+    want_s = orc.eval_counts()[0][:sc.nl]
+    ref = None
+    for fuse, queue, spec, coarse in ((0, 0, 0, 0), (2, 0, 2, 0), (0, 2, 0, 0), (0, 0, 1, 2048)):
+        p = default_params()
+        p.fuse_lm, p.work_queue, p.speculate, p.persistent_coarse = fuse, queue, spec, coarse
+        trk = hip_tracker(ctx, sc, p)
+        good, pose, aff, last = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        st = ctx.stats()
+        assert good == good_o and list(st.evals)[:sc.nl] == want
+        np.testing.assert_allclose(pose, pose_o, atol=1e-4)
+        np.testing.assert_allclose(last[:sc.nl], last_o[:sc.nl], rtol=1e-4)
+        ro = list(st.evals_residual_only)[:sc.nl]
+        assert all(r == (1 if e > 1 else 0) for r, e in zip(ro, want)), (ro, want)  # every level's loop made at least one step
+        if ref is None:
+            ref = (pose, aff, last)
+        else:  # scheduling only
+            assert np.array_equal(pose, ref[0]) and np.array_equal(aff, ref[1]) and np.array_equal(last, ref[2], equal_nan=True)
+        err, s = trk.optimizeScale(1.0, sc.nl - 1)
+        st = ctx.stats()
+        assert list(st.evals)[:sc.nl] == want_s and abs(s - s_o) < 1e-4
+        assert all(r == (1 if e > 1 else 0) for r, e in zip(list(st.evals_residual_only)[:sc.nl], want_s))
+
+
 def test_track_and_scale_in_one_call_equals_the_two_calls(ctx):
     """dsm_track_and_scale_batch: the scale problems run as a companion segment on their own stream; bit-identical results"""
     from direct_stereo_slam_amd.tracker import default_params

@@ -110,6 +110,7 @@ if fetch is not None:
     pl0 = [k for k in pb["config"]["pose_eval_kernels_by_level"] if k["lvl"] == 0][0]
     steps = pb["steps"] + pb["warmup"] + 1
     n_evals = pl0["evals"] * steps
+    n_ro = pl0.get("residual_only", 0) * steps  # of them residual-only (calcResPose without the dead calcGSSSEPose): same figure
     n0, w, h = pb["config"]["n0"], pb["config"]["w"], pb["config"]["h"]
     alg = n_evals * (16 * n0 + 12 * w * h)
     raw_fetch = fetch * 1024.0  # FETCH_SIZE / WRITE_SIZE count kilobytes
@@ -122,6 +123,7 @@ if fetch is not None:
         "config": pb["config"]["name"], "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; the tap gathers of the 4-byte-per-texel intensity plane are taken as reported -- calibrated on known byte counts by tools/pmc_calibrate.sh (<tag>_pmc_calibration.json: template stream tallied at 0.50, tap stream at 0.95 of its unique bytes)",
+        "level0_residual_only_evals": n_ro,
         "layout_bytes": n_evals * (16 * n0 + 4 * w * h),
         "hbm_bytes_per_layout_byte_level0_pose_eval": (corrected + wr) / (n_evals * (16 * n0 + 4 * w * h)),
         "hbm_read_bytes_corrected": corrected, "hbm_bytes_corrected": corrected + wr,
