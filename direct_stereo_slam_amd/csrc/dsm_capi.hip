@@ -972,7 +972,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   // read back ONCE per pass.  Problems that finish a level early idle through the remaining
   // launches (their workgroups exit on the first instruction); problems that need more simply stay
   // at their level and are continued by the next pass.  Results do not depend on the schedule.
-  int worst[DSM_MAX_LEVELS], grid_x[DSM_MAX_LEVELS];
+  int worst[DSM_MAX_LEVELS], grid_x[DSM_MAX_LEVELS], level_pts[DSM_MAX_LEVELS];
   bool spec[DSM_MAX_LEVELS];
   for (int L = 0; L < nlevels; L++) {
     int max_chunks = 1, max_it = 0, max_n = 0;
@@ -983,6 +983,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       if (ts[i]->params.max_iterations[L] > max_it) max_it = ts[i]->params.max_iterations[L];
     }
     grid_x[L] = max_chunks < 8 ? max_chunks : round8(max_chunks);
+    level_pts[L] = max_n;
     worst[L] = 2 * (7 + (max_it > 0 ? max_it : 0)); // upper bound of evaluations at one level
     // Speculative second candidate (dsm_device.hpp): doubles the evaluation work of a step to save the launches of
     // rejected steps.  It pays where a launch is latency- and not bandwidth-bound and rejections come in runs: the
@@ -1076,9 +1077,16 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
           // levels >= 1: the eval kernel's last-arriving workgroup per problem performs the LM step itself
           // (measured: -6 % latency for one frame in flight, -11 % throughput at 256 -- hence the batch rule)
           const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n <= 8));
+          // Large levels: the residual-only evaluations (the level's last ones, tracker_kernels.hip) get a launch of their own
+          // behind the full ones -- an instantiation without the 45 accumulators, 30-41 VGPRs = eight waves per SIMD instead
+          // of four or five.  Never in a level's first round (its evaluation is the level's first).  Measured (S2 dense, 512
+          // frames): level-0 evaluations 4.62 -> 4.40 ms per step, 54.3 -> 55.7 k frames/s with levels 0 and 1 split; with
+          // level 2 as well 53.7-55.3 k (the extra launch costs more than it gives there); one frame in flight 0.70 -> 0.74 ms
+          // (three more launches), hence the floor on the points per launch.
+          const bool split_ro = !fused && k > 0 && level_pts[L] >= 100000 && (long long)(g1 - g0) * level_pts[L] >= 8000000ll;
           launch_eval(st, mode, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
                       ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride,
-                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0, spec[L]);
+                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0, spec[L], split_ro);
           if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
           if (!fused)
             launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,

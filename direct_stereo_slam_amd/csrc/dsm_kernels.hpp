@@ -46,7 +46,7 @@ struct StartInfo { // host -> device, one per problem
 // mode: 0 = pose (calcResPose + calcGSSSEPose), 1 = scale (calcResScale + calcGSSSEScale)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out, bool spec = false);
+                 int partial_stride, int *tickets, int *status_out, bool spec = false, bool split_ro = false);
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
                SingleOut *single_out, int *status_out, bool spec = false);

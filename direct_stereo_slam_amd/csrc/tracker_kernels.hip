@@ -78,7 +78,7 @@ __device__ __forceinline__ TapBases tap_bases(const DSM_GLOBAL float *img, int w
   const long pitch = 4l * w;
   return TapBases{cb - pitch, cb - 4, cb + pitch - 4, cb + 2 * pitch};
 }
-// GRAD = false (residual-only evaluations): rows y-1 and y+2 are not fetched (the intensity needs rows y, y+1 only).
+// GRAD = false (residual-only evaluations): the intensity needs columns x, x+1 of rows y, y+1 only -- two 8-byte loads.
 template <bool GRAD = true>
 __device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, int w, Taps &T) {
   const int ix = (int)x;
@@ -88,16 +88,21 @@ __device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, i
   T.dy = __builtin_amdgcn_fractf(y);
   // (Shift-add / 24-bit forms of this multiply were measured: no gain.)
   const unsigned off = 4u * (unsigned)(ix + iy * w);
-  const fvec4u a = *(const DSM_GLOBAL fvec4u *)(B.r1 + off); // (x-1 .. x+2, y)
-  const fvec4u b = *(const DSM_GLOBAL fvec4u *)(B.r2 + off); // (x-1 .. x+2, y+1)
-  T.r1[0] = a.x, T.r1[1] = a.y, T.r1[2] = a.z, T.r1[3] = a.w;
-  T.r2[0] = b.x, T.r2[1] = b.y, T.r2[2] = b.z, T.r2[3] = b.w;
   if (GRAD) {
+    const fvec4u a = *(const DSM_GLOBAL fvec4u *)(B.r1 + off); // (x-1 .. x+2, y)
+    const fvec4u b = *(const DSM_GLOBAL fvec4u *)(B.r2 + off); // (x-1 .. x+2, y+1)
     const fvec2u c = *(const DSM_GLOBAL fvec2u *)(B.r0 + off); // (x, x+1; y-1)
     const fvec2u d = *(const DSM_GLOBAL fvec2u *)(B.r3 + off); // (x, x+1; y+2)
+    T.r1[0] = a.x, T.r1[1] = a.y, T.r1[2] = a.z, T.r1[3] = a.w;
+    T.r2[0] = b.x, T.r2[1] = b.y, T.r2[2] = b.z, T.r2[3] = b.w;
     T.r0[0] = c.x, T.r0[1] = c.y;
     T.r3[0] = d.x, T.r3[1] = d.y;
-  } else {
+  } else { // the intensity alone: (x, x+1) of rows y and y+1
+    const fvec2u a = *(const DSM_GLOBAL fvec2u *)(B.r1 + off + 4u);
+    const fvec2u b = *(const DSM_GLOBAL fvec2u *)(B.r2 + off + 4u);
+    T.r1[0] = T.r1[3] = T.r2[0] = T.r2[3] = 0.f;
+    T.r1[1] = a.x, T.r1[2] = a.y;
+    T.r2[1] = b.x, T.r2[2] = b.y;
     T.r0[0] = T.r0[1] = T.r3[0] = T.r3[1] = 0.f;
   }
 }
@@ -1333,8 +1338,11 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
 // The plain form (levels >= 1 of the launch-per-step schedule) is held to 96 VGPRs = five waves per SIMD, which is worth
 // more there than the two or three registers the allocator would otherwise take (no spills); the level-0 and fused forms
 // need 104-109 and run four.
-template <int MODE, bool LVL0, bool FUSED>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 || FUSED || MODE == 1) ? 4 : 5))) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
+// ROSEL: 0 = full and residual-only evaluations alike (chosen per problem at run time); 1 = this launch takes the full
+// evaluations only, 2 = the residual-only ones only -- an instantiation of its own, without the 45 accumulators: 8 waves
+// per SIMD instead of 4.
+template <int MODE, bool LVL0, bool FUSED, int ROSEL = 0>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL == 2 ? 7 : (LVL0 || FUSED || MODE == 1) ? 4 : 5))) void eval_kernel(const TrackerDev *const *__restrict__ trackers,
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
                                                         int partial_stride, int lvl, int *__restrict__ tickets,
@@ -1348,6 +1356,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 
   const bool have_eval = !cand || S.spec_valid != 0;
   if (!FUSED && !have_eval) return;
   const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
+  if (ROSEL == 1 && in.residual_only) return;
+  if (ROSEL == 2 && !in.residual_only) return;
   const int n = in.n;
   const int P = pts_per_thread(n);
   const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
@@ -1369,7 +1379,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
     c.residual_only = in.residual_only;
     __shared__ float red[16][kNumSlots];
-    eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+    if (ROSEL == 2)
+      eval_chunk_impl<MODE, LVL0, true>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+    else if (ROSEL == 1)
+      eval_chunk_impl<MODE, LVL0, false>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+    else
+      eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
     if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
   } else if (!FUSED) {
     return;
@@ -1394,14 +1409,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((LVL0 
 
 template <int MODE>
 static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
-                           float *partials, int partial_stride, int *tickets, int *status_out, int spec_nprob) {
+                           float *partials, int partial_stride, int *tickets, int *status_out, int spec_nprob, bool split_ro) {
   if (tickets) { // fused LM step (never level 0: its kernel stays a pure evaluation)
     hipLaunchKernelGGL((eval_kernel<MODE, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
+  } else if (lvl == 0 && split_ro) {
+    hipLaunchKernelGGL((eval_kernel<MODE, true, false, 1>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
+    hipLaunchKernelGGL((eval_kernel<MODE, true, false, 2>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out, spec_nprob);
   } else if (lvl == 0)
     hipLaunchKernelGGL((eval_kernel<MODE, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out, spec_nprob);
-  else
+  else if (split_ro) {
+    hipLaunchKernelGGL((eval_kernel<MODE, false, false, 1>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
+    hipLaunchKernelGGL((eval_kernel<MODE, false, false, 2>), grid, dim3(kThreads), 0, s, trackers, states, partials,
+                       partial_stride, lvl, tickets, status_out, spec_nprob);
+  } else
     hipLaunchKernelGGL((eval_kernel<MODE, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
                        partial_stride, lvl, tickets, status_out, spec_nprob);
 }
@@ -1409,16 +1434,16 @@ static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *
 // tickets != nullptr (levels >= 1 only): the kernel also performs the LM step (no lm_kernel launch needed)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out, bool spec) {
+                 int partial_stride, int *tickets, int *status_out, bool spec, bool split_ro) {
   dim3 grid(grid_x, spec ? 2 * nprob : nprob);
   const int spec_nprob = spec ? nprob : 0;
   if (lvl == 0) tickets = nullptr;
   if (mode == 0)
-    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
+    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
   else if (mode == 2)
-    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
+    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
   else
-    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob);
+    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
 }
 
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,

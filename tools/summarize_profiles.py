@@ -11,7 +11,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")  # on a gpurun box only gpurun_out/ travels back
 os.makedirs(dst, exist_ok=True)
-L0 = "eval_kernel<0, true, false>"  # level-0 pose evaluation (MODE 0, LVL0, not fused)
+L0 = "eval_kernel<0, true, false"  # every instantiation of the level-0 pose evaluation: ", 0>" mixed, ", 1>" full, ", 2>" residual-only launches  # level-0 pose evaluation (MODE 0, LVL0, not fused)
 
 
 def last_json(path):
@@ -71,7 +71,7 @@ if trace:
     bytes_eval = bench["roofline"]["bytes_per_launch"] * bench["roofline"]["launches"] / l0["evals"]
     summary = {
         "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu --no-second-leg",
-        "kernel": "dsm::" + L0,
+        "kernel": "dsm::" + L0 + ", *>",
         "dispatches": len(d), "dispatches_with_work": len(work),
         "avg_ns_dispatches_with_work": sum(work) / max(1, len(work)),
         "sum_ns_dispatches_with_work": sum(work), "union_ns_dispatches_with_work": busy,
@@ -84,8 +84,10 @@ if trace:
         "bench_avg_dispatch_us": bench["roofline"]["avg_launch_us"],
         "note": "2 stream groups: each launch = 2 concurrent dispatches over half of the batch, so per-dispatch durations "
                 "overlap and the rate uses the union of the dispatch intervals -- in the trace and in bench.py's HIP-event "
-                "leg alike; avg_ns_all_dispatches (= rocprofv3 --stats AverageNs) is to be compared with bench.py's "
-                "roofline.avg_launch_us (per-dispatch average of one steady-state step)",
+                "leg alike; avg_ns_all_dispatches (= rocprofv3 --stats AverageNs over the level-0 instantiations) is to be "
+                "compared with bench.py's roofline.avg_launch_us (average of one steady-state step per launch_eval call, "
+                "which after a level's first round is TWO dispatches: the full evaluations <..., 1>, then the residual-only "
+                "ones <..., 2>)",
     }
     json.dump(summary, open(os.path.join(dst, f"{tag}_level0_eval_trace_summary.json"), "w"), indent=1)
     print("trace:", summary["achieved_GBps_from_trace"], "bench:", bench["roofline"]["achieved"])
@@ -120,7 +122,7 @@ if fetch is not None:
     wr = (write or 0.0) * 1024.0
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-second-leg --steps 2 --warmup 1",
-        "config": pb["config"]["name"], "kernel": "dsm::" + L0, "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
+        "config": pb["config"]["name"], "kernel": "dsm::" + L0 + ", *>", "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; the tap gathers of the 4-byte-per-texel intensity plane are taken as reported -- calibrated on known byte counts by tools/pmc_calibrate.sh (<tag>_pmc_calibration.json: template stream tallied at 0.50, tap stream at 0.95 of its unique bytes)",
         "level0_residual_only_evals": n_ro,

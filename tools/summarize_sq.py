@@ -5,7 +5,7 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-L0 = "eval_kernel<0, true, false>"
+L0 = "eval_kernel<0, true, false"  # every instantiation of the level-0 pose evaluation: ", 0>" mixed, ", 1>" full, ", 2>" residual-only launches
 sums, avg, ndisp = {}, {}, 0
 for p in ("p1", "p2", "p3", "p4", "p5"):
     files = sorted(glob.glob(os.path.join(src, p, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
