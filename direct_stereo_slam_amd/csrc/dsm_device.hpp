@@ -29,10 +29,7 @@ constexpr int kTexel = 1;         // floats per target texel: the intensity; gra
 struct LevelDev {
   const float4 *pts;   // n template points
   const float *img[2]; // slot 0 = new left frame, slot 1 = right frame: intensity planes
-  int n, w, h;
-  int residual_only; // the LM loop ends after this evaluation whatever it yields (:588, the iteration bound): only the
-                     // residual side (calcResPose / calcResScale) is needed -- the normal equations calcGSSSE* would build
-                     // from it are never read by the reference either
+  int n, w, h, pad;
   float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
   float Ki[9];              // inverse of K at this level (float, :135-140)
   float fx1, fy1, cx1, cy1; // camera 1 (:89-98)
