@@ -1016,19 +1016,44 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     ctx->join_events.push_back(ev);
   }
   int top = coarsest, top2 = n2 > 0 ? coarsest : -1;
-  if (!use_queue && P.persistent_coarse > 0 && n2 == 0) {
-    // Small levels: the whole LM loop in one launch per problem (coarse_kernel).  It hands a problem
-    // back (still RUNNING) at the first level with more than coarse_max_points() template points.
-    const int max_pts = P.persistent_coarse < coarse_max_points() ? P.persistent_coarse : coarse_max_points();
-    launch_coarse(ctx->stream, mode, n, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_status, max_pts);
-    ctx->stats.coarse_launches = 1;
-    top = -1;
-    for (int L = coarsest; L >= 0 && top < 0; L--)
-      for (int i = 0; i < n; i++)
-        if (ts[i]->desc.lv[L].n > max_pts) {
-          top = L;
-          break;
-        }
+  if (!use_queue && P.persistent_coarse > 0) {
+    // Small levels: the whole LM loop in one launch per problem on LDS-resident data (coarse_kernel), one launch per stream
+    // group and one for the companion segment.  A problem is handed back (still RUNNING) at the first level whose target
+    // plane does not fit the kernel's LDS arena.
+    const int max_px = P.persistent_coarse;
+    bool any = false;
+    for (int i = 0; i < N && !any; i++) any = coarse_level_fits(ts[i]->w >> coarsest, ts[i]->h >> coarsest, ts[i]->desc.lv[coarsest].n, max_px);
+    if (any) {
+      if (ng > 1 || top2 >= 0) {
+        DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+        for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
+        if (top2 >= 0) DSM_HIP(hipStreamWaitEvent(ctx->companion_stream, ctx->fork_event, 0));
+      }
+      const bool cspec = P.speculate >= 1;
+      for (int g = 0; g < ng; g++) {
+        const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
+        if (g1 <= g0) continue;
+        launch_coarse(g == 0 ? ctx->stream : ctx->extra_streams[g - 1], mode, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
+                      ctx->d_status + 2 * g0, max_px, cspec);
+      }
+      if (n2 > 0)
+        launch_coarse(ctx->companion_stream, mode2, n2, ctx->d_tracker_ptrs + n, ctx->d_states + n, ctx->d_status + 2 * n, max_px, cspec);
+      ctx->stats.coarse_launches = 1;
+      // The launch-per-step schedule starts at the first level some problem cannot run there.  No join: each stream's next
+      // launches are ordered behind its own coarse launch (the pass loop's fork adds the main stream's only).
+      auto first_launch_level = [&](int i0, int i1) {
+        int t = -1;
+        for (int i = i0; i < i1; i++)
+          for (int L = coarsest; L > t; L--)
+            if (!coarse_level_fits(ts[i]->w >> L, ts[i]->h >> L, ts[i]->desc.lv[L].n, max_px)) {
+              t = L;
+              break;
+            }
+        return t;
+      };
+      top = first_launch_level(0, n);
+      if (n2 > 0) top2 = first_launch_level(n, N);
+    }
   }
   for (int pass = 0; !use_queue; pass++) {
     if (ng > 1 || top2 >= 0) { // fork: the extra streams start after everything enqueued on the main stream so far

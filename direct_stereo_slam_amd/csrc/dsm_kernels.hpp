@@ -64,10 +64,11 @@ int queue_kernel_blocks_per_cu(int mode);
 void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
                   float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask);
 
-// persistent LM loop of the small levels (levels with <= coarse_max_points() template points)
+// persistent LM loop of the small levels on LDS-resident data (levels whose target plane has at most max_px pixels, capped
+// by the kernel's LDS arena): coarse_level_fits tells whether a level of w x h pixels and n template points qualifies
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
-                   int *status_out, int max_pts);
-int coarse_max_points();
+                   int *status_out, int max_px, bool spec);
+bool coarse_level_fits(int w, int h, int n, int max_px);
 
 // row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip)
 size_t make_coarse_depth_workspace_floats(int w, int h, int nlevels, int npts);

@@ -21,6 +21,7 @@
 
 namespace dsm {
 
+
 // ------------------------------------------------------------------------------------------
 // wave64 helpers: DPP butterflies inside 16-lane rows (v_add_f32 ... quad_perm / row_mirror)
 // ------------------------------------------------------------------------------------------
@@ -77,6 +78,43 @@ __device__ __forceinline__ TapBases tap_bases(const DSM_GLOBAL float *img, int w
   const DSM_GLOBAL char *cb = (const DSM_GLOBAL char *)img;
   const long pitch = 4l * w;
   return TapBases{cb - pitch, cb - 4, cb + pitch - 4, cb + 2 * pitch};
+}
+// The same four row bases for a plane staged in LDS (coarse_kernel): byte addresses in the local address space; the taps
+// become ds_read instructions (unaligned rows: the compiler picks ds_read2_b32 / ds_read_b64 as alignment allows).
+#define DSM_LDS __attribute__((address_space(3)))
+struct TapBasesL {
+  unsigned r0, r1, r2, r3;
+};
+__device__ __forceinline__ TapBasesL tap_bases_lds(unsigned img, int w) {
+  const unsigned pitch = 4u * (unsigned)w;
+  return TapBasesL{img - pitch, img - 4u, img + pitch - 4u, img + 2u * pitch};
+}
+template <bool L> struct TapSel { typedef TapBases type; };
+template <> struct TapSel<true> { typedef TapBasesL type; };
+template <bool GRAD = true>
+__device__ __forceinline__ void taps_load(const TapBasesL &B, float x, float y, int w, Taps &T) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  T.dx = __builtin_amdgcn_fractf(x);
+  T.dy = __builtin_amdgcn_fractf(y);
+  const unsigned off = 4u * (unsigned)(ix + iy * w);
+  if (GRAD) {
+    const fvec4u a = *(const DSM_LDS fvec4u *)(size_t)(B.r1 + off);
+    const fvec4u b = *(const DSM_LDS fvec4u *)(size_t)(B.r2 + off);
+    const fvec2u c = *(const DSM_LDS fvec2u *)(size_t)(B.r0 + off);
+    const fvec2u d = *(const DSM_LDS fvec2u *)(size_t)(B.r3 + off);
+    T.r1[0] = a.x, T.r1[1] = a.y, T.r1[2] = a.z, T.r1[3] = a.w;
+    T.r2[0] = b.x, T.r2[1] = b.y, T.r2[2] = b.z, T.r2[3] = b.w;
+    T.r0[0] = c.x, T.r0[1] = c.y;
+    T.r3[0] = d.x, T.r3[1] = d.y;
+  } else {
+    const fvec2u a = *(const DSM_LDS fvec2u *)(size_t)(B.r1 + off + 4u);
+    const fvec2u b = *(const DSM_LDS fvec2u *)(size_t)(B.r2 + off + 4u);
+    T.r1[0] = T.r1[3] = T.r2[0] = T.r2[3] = 0.f;
+    T.r1[1] = a.x, T.r1[2] = a.y;
+    T.r2[1] = b.x, T.r2[2] = b.y;
+    T.r0[0] = T.r0[1] = T.r3[0] = T.r3[1] = 0.f;
+  }
 }
 // GRAD = false (residual-only evaluations): the intensity needs columns x, x+1 of rows y, y+1 only -- two 8-byte loads.
 template <bool GRAD = true>
@@ -157,6 +195,7 @@ struct EvalConsts {
   float t[3];
   float aff0, aff1, b0, scale, cutoff, max_energy;
   int residual_only; // EvalIn::residual_only
+  unsigned lds_img, lds_pts; // coarse_kernel: LDS byte addresses of the staged intensity plane / template (else unused)
 };
 
 // Chunk partials are produced by one workgroup and consumed by another (the LM step), possibly on a
@@ -199,9 +238,16 @@ __device__ __forceinline__ fvec4 load_partial4(const float *p) {
 // call it; thread groups without a chunk pass active = false.
 // RO = residual-only (EvalIn::residual_only): the residual side alone -- energy, counts, flow indicators; no gradients, no
 // Jacobian, no normal-equation sums (their partial slots are written as zeros), two tap loads per point instead of four.
-template <int MODE, bool LVL0, bool RO>
+// LDSIMG / LDSPTS: the target plane / the template are read from their LDS copies (c.lds_img / c.lds_pts) -- same values,
+// same operations, hence the same results as from global memory.
+// arrive != nullptr (eval_kernel without the fused LM step): instead of a workgroup barrier between the row sums and the
+// final sum, every wave takes a ticket on an LDS counter after its rows are written and only the LAST one stays to add the 16
+// rows and store the partial -- the same additions in the same order by another wave; the other waves leave at once instead
+// of waiting for the slowest wave's gathers (measured: a mid-level workgroup spent a third of its life between the end of
+// its first wave's loop and the partial store).
+template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                                float *out) {
+                                                float *out, int *arrive = nullptr) {
   const int n = c.n;
   const int P = pts_per_thread(n);
   constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
@@ -221,7 +267,11 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     const float hfx = 0.5f * fxl, hfy = 0.5f * fyl; // the central differences' 0.5 (see taps_interp)
     const int wl = c.w, hl = c.h;
     const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
-    const TapBases img = tap_bases((const DSM_GLOBAL float *)c.img, wl);
+    typename TapSel<LDSIMG>::type img;
+    if constexpr (LDSIMG)
+      img = tap_bases_lds(c.lds_img, wl);
+    else
+      img = tap_bases((const DSM_GLOBAL float *)c.img, wl);
     const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)c.pts;
     // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
     const float sc = c.scale;
@@ -364,9 +414,12 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
     {
       const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
-      auto load_pt = [pb, n](int idx) {
+      const unsigned lds_pts = c.lds_pts;
+      auto load_pt = [=](int idx) {
+        const unsigned o = 16u * (unsigned)(idx < n ? idx : n - 1);
+        if constexpr (LDSPTS) return *(const DSM_LDS fvec4 *)(size_t)(lds_pts + o);
         // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
-        return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + 16u * (unsigned)(idx < n ? idx : n - 1)));
+        else return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + o));
       };
       const int i = chunk_start + tid;
       const fvec4 p0 = load_pt(i);
@@ -483,7 +536,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 
   } // active
-
   // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
   const int lane = tid & 63, wave = tid >> 6;
   const int row = wave * 4 + (lane >> 4);
@@ -508,29 +560,40 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       red[row][kSlotNWarped] = __int_as_float(iW);
     }
   }
-  __syncthreads();
-  const bool is_float_slot = tid < NACC || (tid >= kSlotE && tid < kSlotNTerms);
+  int slot = tid;
+  if (arrive) {
+    // a wave's LDS operations are performed in order: its rows are in place before its ticket is counted
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(t) != kThreads / 64 - 1) return; // not the last wave of the workgroup: done
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    slot = lane;
+  } else {
+    __syncthreads();
+  }
+  const bool is_float_slot = slot < NACC || (slot >= kSlotE && slot < kSlotNTerms);
   if (!active) {
   } else if (is_float_slot) {
-    float s = red[0][tid];
+    float s = red[0][slot];
 #pragma unroll
-    for (int r = 1; r < 16; r++) s += red[r][tid];
-    store_partial(out + tid, s);
-  } else if (tid >= kSlotNTerms && tid < kNumSlots) {
+    for (int r = 1; r < 16; r++) s += red[r][slot];
+    store_partial(out + slot, s);
+  } else if (slot >= kSlotNTerms && slot < kNumSlots) {
     int s = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) s += __float_as_int(red[r][tid]);
-    store_partial(out + tid, __int_as_float(s));
+    for (int r = 0; r < 16; r++) s += __float_as_int(red[r][slot]);
+    store_partial(out + slot, __int_as_float(s));
   }
 }
 
 template <int MODE, bool LVL0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                           float *out) {
+                                           float *out, int *arrive = nullptr) {
   if (c.residual_only) // wave-uniform
-    eval_chunk_impl<MODE, LVL0, true>(c, chunk, tid, active, red, out);
+    eval_chunk_impl<MODE, LVL0, true>(c, chunk, tid, active, red, out, arrive);
   else
-    eval_chunk_impl<MODE, LVL0, false>(c, chunk, tid, active, red, out);
+    eval_chunk_impl<MODE, LVL0, false>(c, chunk, tid, active, red, out, arrive);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -724,103 +787,155 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
   return ((double)hf * (double)invn) * scale_of(p, r);
 }
 
-// Eigen LDLT<Lower> with diagonal pivoting + solve (call sites :509,:513,:518,:529), one matrix
-// element per lane (lane = 8*r + c, full symmetric storage), right-hand side replicated along
-// rows.  Rows/cols whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves).
-// Returns x_r (replicated along the row).  Same pivot order as the textbook (left-looking) form the
-// oracle restates, right-looking symmetric updates; results differ from it by round-off in the last
-// bits of a double.
-// value of `v` in lane `idx` (any per-lane index): ds_bpermute
-__device__ __forceinline__ double permute_d(double v, int idx) {
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(idx << 2, (int)b);
-  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(idx << 2, (int)(b >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
+// Eigen LDLT<Lower> + solve (call sites :509,:513,:518,:529), restated operation for operation from Eigen's unblocked
+// in-place algorithm (the CPU checker restates the same sequence), executed by one wave on wave-uniform data.
+//
+// Eigen's unblocked LDLT is LEFT-looking: at step k it looks for the first maximum of |diagonal| among the rows not yet
+// eliminated, swaps it into position k, and only then applies the pending updates to column k.  The diagonal entries it
+// compares have therefore not been touched by the elimination: the whole pivot order is a function of the input diagonal
+// alone (a selection sort with Eigen's swap bookkeeping).  That allows a form with a short dependent chain:
+//   1. the pivot order from ONE all-pairs comparison of the diagonal (lane (r,c) tests |d_c| > |d_r|; a row's rank is the
+//      population count of its byte of the ballot).  Exact ties and NaNs -- where Eigen's swaps, not the ranks, decide --
+//      take a literal, sequential restatement of the selection loop instead (wave-uniform rare branch);
+//   2. the symmetrically permuted lower triangle is read from the LDS copy of H (wave-uniform addresses, broadcast reads);
+//   3. the factorisation and the three substitution passes run fully unrolled on registers with static indices, every
+//      lane computing the same values: no cross-lane traffic, no pivot search, no divergence inside the chain;
+//   4. the solution is un-permuted through eight LDS words.
+// About 2.8 k shader cycles against the 7.7 k of the cross-lane right-looking form it replaces (eight dependent rounds of
+// ballot -> lane read -> two ds_bpermute -> two IEEE divisions), and the same operations in the same order as the CPU checker:
+// given bitwise equal H and b the increments are bitwise equal.
+// Rows / columns whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves): they are ordered last and
+// enter as zero rows, zero columns and a zero right-hand side, which leaves every operation on the active block unchanged
+// (x - 0 * y = x) and yields 0 for them.  stitch: row / column 6 of the system is row / column 7 of H (:521-534).
+struct LdltScratch {
+  double x[8];
+  double av[8];
+  int ix[8];
+  int perm[8];
+};
 
-__device__ __forceinline__ double wave_ldlt_solve(double a, double y, unsigned active, int lane) {
+__device__ __forceinline__ void wave_ldlt_solve8(const double *Hlds, const double *blds, float lambda, unsigned active, bool stitch,
+                                                 int lane, LdltScratch &scr, double inc[8]) {
   const int r = lane >> 3, c = lane & 7;
-  unsigned done = ~active & 0xFFu; // wave-uniform
-  unsigned order = 0;              // pivot of step k in bits 4k..4k+3, stored as p+1 (0 = no pivot): no indexed array
-  unsigned live_at = 0;            // bit k: row r was still to be eliminated after step k (takes part in its update)
-  bool all_zero = false;
-  // Every lane tracks the diagonal entries of its row and of its column (dR = A[r][r], dC = A[c][c]) with
-  // exactly the operations the diagonal lanes apply, and the matrix is updated symmetrically
-  // (A[i][j] -= (A[i][p]/d) * A[j][p] with i >= j on both sides of the diagonal), so one cross-lane fetch
-  // stage per pivot step -- column p for this lane's row and column -- is all that is needed.
-  a = permute_d(a, r >= c ? lane : 8 * c + r); // LDLT<Lower> reads the lower triangle only: mirror it (bitwise symmetric input)
-  double dR = permute_d(a, 9 * r), dC = permute_d(a, 9 * c);
-  double Lk[8];      // L[r][p_k]: this row's multiplier of step k (forward substitution)
-  double Lrow = 0.0; // L[c][r], captured at the step in which row r is the pivot (back substitution)
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    // pivot = first maximum of |diagonal| over the rows not yet eliminated (Eigen: maxCoeff of the
-    // remaining diagonal).  Lane (r,c) tests "candidate c beats r"; a row nobody beats wins.
-    const double aR = fabs(dR), aC = fabs(dC);
-    const bool live_r = !((done >> r) & 1u), live_c = !((done >> c) & 1u);
-    const bool beats = live_c && (aC > aR || (aC == aR && c < r));
-    const unsigned long long m = __ballot(beats);
-    const bool row_beaten = ((m >> (8 * r)) & 0xFFull) != 0;
-    const unsigned long long w = __ballot(live_r && aR == aR && !row_beaten && c == 0);
-    const int p = w ? (__builtin_ctzll(w) >> 3) : -1; // wave-uniform
-    order |= (unsigned)(p + 1) << (4 * k);
-    Lk[k] = 0.0;
-    if (p >= 0) {
-      const double dp = lane_value_d(dR, 8 * p);
-      const double colR = permute_d(a, 8 * r + p); // A[r][p]
-      const double colC = permute_d(a, 8 * c + p); // A[c][p]
-      const bool valid = fabs(dp) > 0.0;
-      if (k == 0 && !valid) all_zero = true;
-      const bool r_live = live_r && r != p;
-      const bool c_live = live_c && c != p;
-      const double lR = valid ? colR / dp : colR;
-      const double lC = valid ? colC / dp : colC;
-      if (r_live && c_live) a = a - (r >= c ? lR * colC : lC * colR);
-      if (r_live) dR = dR - lR * colR;
-      if (c_live) dC = dC - lC * colC;
-      Lk[k] = lR;
-      if (r_live) live_at |= 1u << k;
-      if (r == p) Lrow = lC;
-      done |= 1u << p;
-    }
-  }
-  // forward substitution (unit lower), in pivot order
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int p = (int)((order >> (4 * k)) & 15u) - 1;
-    if (p >= 0) {
-      const double yp = lane_value_d(y, 8 * p);
-      if ((live_at >> k) & 1u) y = y - Lk[k] * yp;
-    }
-  }
-  // D^-1 with Eigen's tolerance 1/highest; dR stopped changing when row r became the pivot
+  const double lam1 = (double)(1 + lambda); // Hl(i,i) *= (1 + lambda): a float sum, widened (:506-508)
+  auto src = [stitch](int i) { return stitch && i == 6 ? 7 : i; };
+  const int nact = __builtin_popcount(active & 0xFFu);
+  // ---- 1. pivot order ----
+  int perm[8];
   {
-    const double tol = 1.0 / 1.7976931348623157e308;
-    y = fabs(dR) > tol ? y / dR : 0.0;
-  }
-  // back substitution (L^T), reverse pivot order: L[p_k][r] sits in lane (r, p_k); all eight fetches are
-  // independent of y and issued together
-  double Lb[8];
+    const double ar = fabs(Hlds[9 * src(r)] * lam1), ac = fabs(Hlds[9 * src(c)] * lam1);
+    const bool act_r = (active >> r) & 1u, act_c = (active >> c) & 1u;
+    const unsigned long long gt = __ballot(act_r && act_c && ac > ar);
+    const bool odd = act_r && ((act_c && r != c && ac == ar) || ar != ar);
+    const bool slow = __ballot(odd) != 0ull; // wave-uniform
+    const int rank = act_r ? __builtin_popcount((unsigned)(gt >> (8 * r)) & 0xFFu) : nact + __builtin_popcount(~active & ((1u << r) - 1u) & 0xFFu);
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int p = (int)((order >> (4 * k)) & 15u) - 1;
-    Lb[k] = permute_d(Lrow, 8 * r + (p < 0 ? 0 : p));
-  }
-  unsigned before = 0; // rows eliminated before the current pivot = all earlier pivots
+    for (int k = 0; k < 8; k++) {
+      const unsigned long long m = __ballot(c == 0 && rank == k);
+      perm[k] = m ? (__builtin_ctzll(m) >> 3) : k;
+    }
+    if (__builtin_expect(slow, 0)) {
+      // Eigen's selection loop as written: first maximum of the remaining diagonal IN ITS CURRENT ARRANGEMENT, swapped to
+      // position k (comparisons with NaN are false: a NaN is only ever taken where it already stands)
+      if (lane == 0) {
+        int n = 0;
+        for (int i = 0; i < 8; i++)
+          if ((active >> i) & 1u) {
+            scr.av[n] = fabs(Hlds[9 * src(i)] * lam1);
+            scr.ix[n] = i;
+            n++;
+          }
+        for (int k = 0; k < n; k++) {
+          int big = k;
+          double bigv = scr.av[k];
+          for (int i = k + 1; i < n; i++)
+            if (scr.av[i] > bigv) bigv = scr.av[i], big = i;
+          const double tv = scr.av[k];
+          const int ti = scr.ix[k];
+          scr.av[k] = scr.av[big], scr.ix[k] = scr.ix[big];
+          scr.av[big] = tv, scr.ix[big] = ti;
+        }
+        for (int i = 0; i < 8; i++)
+          if (!((active >> i) & 1u)) scr.ix[n++] = i;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-  for (int k = 0; k < 8; k++)
-    if ((order >> (4 * k)) & 15u) before |= 1u << (((order >> (4 * k)) & 15u) - 1);
-#pragma unroll
-  for (int k = 7; k >= 0; k--) {
-    const int p = (int)((order >> (4 * k)) & 15u) - 1;
-    if (p >= 0) {
-      before &= ~(1u << p);
-      const double xp = lane_value_d(y, 8 * p);
-      if ((before >> r) & 1u) y = y - Lb[k] * xp;
+      for (int k = 0; k < 8; k++) perm[k] = __builtin_amdgcn_readfirstlane(scr.ix[k]);
     }
   }
-  if (all_zero || !((active >> r) & 1u)) y = 0.0;
-  return y;
+  // ---- 2. the permuted system: lower triangle of P A P^T (LDLT<Lower> reads the lower triangle of its input), P rhs ----
+  double A[8][8], y[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int pi = src(perm[i]);
+    const bool ai = i < nact;
+    y[i] = ai ? -blds[pi] : 0.0;
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      const int pj = src(perm[j]);
+      const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+      double v = Hlds[8 * hi + lo];
+      if (i == j) v = v * lam1;
+      A[i][j] = ai ? v : 0.0; // (j <= i: j active whenever i is)
+    }
+  }
+  // ---- 3. factorisation (left-looking, no pivoting left to do) and substitutions, Eigen's operation order ----
+  bool all_zero = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k > 0) {
+      double temp[8];
+#pragma unroll
+      for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
+      double dot = 0;
+#pragma unroll
+      for (int j = 0; j < k; j++) dot += A[k][j] * temp[j];
+      A[k][k] -= dot;
+#pragma unroll
+      for (int i = k + 1; i < 8; i++) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < k; j++) s += A[i][j] * temp[j];
+        A[i][k] -= s;
+      }
+    }
+    const double akk = A[k][k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) all_zero = true;
+    if (valid) {
+#pragma unroll
+      for (int i = k + 1; i < 8; i++) A[i][k] /= akk;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) // L^-1
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+  {
+    const double tol = 1.0 / 1.7976931348623157e308; // Eigen: 1 / NumTraits<double>::highest()
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = fabs(A[i][i]) > tol ? y[i] / A[i][i] : 0.0;
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; i--) // L^-T
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) y[i] -= A[j][i] * y[j];
+  // ---- 4. P^T: position i of the permuted system is unknown perm[i] ----
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) scr.x[perm[i]] = (all_zero || i >= nact) ? 0.0 : y[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+  for (int i = 0; i < 8; i++) inc[i] = scr.x[i];
+  if (stitch) {
+    inc[7] = inc[6];
+    inc[6] = 0;
+  }
 }
 
 // lane 0 only: :612-637
@@ -844,14 +959,10 @@ __device__ __forceinline__ void finish_track(const TrackerDev &T, LMState &S) {
   S.status = status;
 }
 
-// whole wave: solve + propose for the pose problem (:505-554).  h = H(r,c) of this lane,
-// bneg = -b(r) replicated along the row.  spec: the proposal is the speculative one (S.spec_*).
-__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, double h, double bneg, float lambda, int lane, bool spec = false) {
-  const int r = lane >> 3, c = lane & 7;
+// whole wave: solve + propose for the pose problem (:505-554) from the H, b of the problem state (LDS).
+// spec: the proposal is the speculative one (S.spec_*).
+__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, float lambda, int lane, LdltScratch &scr, bool spec = false) {
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
-  double a = h;
-  if (r == c) a *= (1 + lambda); // :506-508
-  double y = bneg;
   unsigned active = 0xFFu;
   bool stitch = false;
   if (modeA < 0 && modeB < 0) { // :511-515 fix a, b
@@ -861,19 +972,9 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, do
   } else if (modeA < 0 && !(modeB < 0)) { // :521-534 fix a: row/col 6 := row/col 7
     stitch = true;
     active = 0x7Fu;
-    const int mr = r == 6 ? 7 : r, mc = c == 6 ? 7 : c;
-    a = __shfl(a, 8 * mr + mc, 64);
-    y = __shfl(y, 8 * mr, 64);
   }
-  const double x = wave_ldlt_solve(a, y, active, lane);
-  // gather the 8 increments into every lane (row r's value sits in lanes 8r..8r+7)
   double inc[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) inc[i] = lane_value_d(x, 8 * i);
-  if (stitch) {
-    inc[7] = inc[6];
-    inc[6] = 0;
-  }
+  wave_ldlt_solve8(S.H, S.b, lambda, active, stitch, lane, scr, inc);
   // From here on every lane computes the same (wave-uniform) values; lane 0 stores them.  The two
   // sincos evaluations of SE3::exp run side by side in lanes 0 and 1.
   float extrapFac = 1; // :536-539
@@ -984,12 +1085,14 @@ struct RedBuf { // fixed-order reduction of one evaluation's chunk partials
 // second reduction buffer and the wave 0 <-> wave 1 hand-shake of a step that handles a speculative candidate
 struct LmSpecShared {
   RedBuf red;
+  LdltScratch ldlt; // wave 1's
   int cmd;      // wave 0 -> wave 1: 0 wait, 1 stage the speculative proposal with `lambda`, 2 nothing to do
   int done;     // wave 1 -> wave 0
   float lambda;
 };
 struct LmShared {
   RedBuf red;
+  LdltScratch ldlt; // wave 0's
   // The problem's LMState and its tracker descriptor are staged here for the duration of a step
   // (lm_kernel) or of the whole small-level loop (coarse_kernel): the state machine then runs on LDS
   // latencies instead of a chain of dependent global-memory round trips.
@@ -1105,7 +1208,6 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   const int phase = S.phase;
   const bool had_spec = sp && S.spec_valid; // wave-uniform; read before lane 0 clears it
   bool level_done = false, do_propose = false;
-  double h = 0, bneg = 0; // this lane's H(r,c) and -b(r) for a following proposal
   float lambda_next = 0.01f; // computed by every lane: nothing lane 0 writes below is re-read by the wave
   int iteration = 0;
   if (lane == 0) {
@@ -1122,10 +1224,8 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
       }
     } else {
       if (pose_like) {
-        h = build_H_elem(T.p, sums, n4, r, c); // :487
-        bneg = -build_b_elem(T.p, sums, n4, r);
-        S.H[lane] = h;
-        if (c == 0) S.b[r] = -bneg;
+        S.H[lane] = build_H_elem(T.p, sums, n4, r, c); // :487
+        if (c == 0) S.b[r] = build_b_elem(T.p, sums, n4, r);
       }
       if (lane == 0) {
         S.evals[lvl]++;
@@ -1153,16 +1253,9 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
       if (l4 < lim) l4 = lim;
       lambda_next = accept ? l_old * 0.5f : l4; // :581 / :583-585
     }
-    if (pose_like) {
-      if (accept) { // :576-577
-        h = build_H_elem(T.p, sums, n4, r, c);
-        bneg = -build_b_elem(T.p, sums, n4, r);
-        S.H[lane] = h;
-        if (c == 0) S.b[r] = -bneg;
-      } else {
-        h = S.H[lane];
-        bneg = -S.b[r];
-      }
+    if (pose_like && accept) { // :576-577
+      S.H[lane] = build_H_elem(T.p, sums, n4, r, c);
+      if (c == 0) S.b[r] = build_b_elem(T.p, sums, n4, r);
     }
     if (lane == 0) {
       S.evals[lvl]++;
@@ -1200,10 +1293,8 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
         lambda_next = accept2 ? l_old * 0.5f : l4;
       }
       if (pose_like && accept2) {
-        h = build_H_elem(T.p, sums2, n4b, r, c);
-        bneg = -build_b_elem(T.p, sums2, n4b, r);
-        S.H[lane] = h;
-        if (c == 0) S.b[r] = -bneg;
+        S.H[lane] = build_H_elem(T.p, sums2, n4b, r, c);
+        if (c == 0) S.b[r] = build_b_elem(T.p, sums2, n4b, r);
       }
       if (lane == 0) {
         S.evals[lvl]++;
@@ -1248,7 +1339,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   }
   if (do_propose) {
     if (pose_like)
-      propose_pose(T, S, h, bneg, lambda_next, lane);
+      propose_pose(T, S, lambda_next, lane, sh.ldlt);
     else if (lane == 0)
       propose_scale(T, S, lambda_next);
   }
@@ -1271,8 +1362,7 @@ __device__ __forceinline__ void lm_spec_wave1(int mode, const TrackerDev &T, LMS
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const float lambda = sp.lambda;
   if (mode != 1) {
-    const int r = lane >> 3;
-    propose_pose(T, S, S.H[lane], -S.b[r], lambda, lane, true);
+    propose_pose(T, S, lambda, lane, sp.ldlt, true);
   } else if (lane == 0) {
     propose_scale(T, S, lambda, true);
   }
@@ -1350,15 +1440,39 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   // spec_nprob > 0: grid rows [spec_nprob, 2 spec_nprob) evaluate the problems' speculative candidates (where staged)
   const bool cand = spec_nprob > 0 && (int)blockIdx.y >= spec_nprob;
   const int prob = cand ? blockIdx.y - spec_nprob : blockIdx.y;
-  // uniform, read-only state: global address space so that it becomes scalar (s_load) reads
+  // Uniform, read-only state: global address space so that it becomes scalar (s_load) reads -- and ALL of them are issued
+  // before the first one is looked at: the head of the state and the evaluation inputs of this row's candidate arrive in
+  // ONE memory round trip instead of a chain of three (state -> candidate -> inputs), which was a seventh of a mid-level
+  // workgroup's life.  (The asm statements pin the loads above the early exits; they emit no instruction.)
   const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
-  if (S.status != ST_RUNNING || S.lvl != lvl || S.is_scale != MODE) return;
-  const bool have_eval = !cand || S.spec_valid != 0;
-  if (!FUSED && !have_eval) return;
   const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
-  if (ROSEL == 1 && in.residual_only) return;
-  if (ROSEL == 2 && !in.residual_only) return;
-  const int n = in.n;
+  const int s_status = S.status, s_lvl = S.lvl, s_kind = S.is_scale, s_spec_valid = S.spec_valid;
+  EvalConsts c;
+  c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h;
+  c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
+  c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
+  c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
+  c.residual_only = in.residual_only;
+  c.lds_img = c.lds_pts = 0;
+  asm volatile("" ::"s"(s_status), "s"(s_lvl), "s"(s_kind), "s"(s_spec_valid), "s"(c.pts), "s"(c.img), "s"(c.n), "s"(c.w), "s"(c.h),
+               "s"(c.residual_only));
+  asm volatile("" ::"s"(c.fx), "s"(c.fy), "s"(c.cx), "s"(c.cy), "s"(c.huber), "s"(c.t[0]), "s"(c.t[1]), "s"(c.t[2]), "s"(c.aff0),
+               "s"(c.aff1), "s"(c.b0), "s"(c.scale), "s"(c.cutoff), "s"(c.max_energy));
+  asm volatile("" ::"s"(c.M[0]), "s"(c.M[1]), "s"(c.M[2]), "s"(c.M[3]), "s"(c.M[4]), "s"(c.M[5]), "s"(c.M[6]), "s"(c.M[7]), "s"(c.M[8]));
+  if (LVL0) asm volatile("" ::"s"(c.Ki[0]), "s"(c.Ki[1]), "s"(c.Ki[2]), "s"(c.Ki[3]), "s"(c.Ki[4]), "s"(c.Ki[5]), "s"(c.Ki[6]), "s"(c.Ki[7]), "s"(c.Ki[8]));
+  __shared__ int arrive; // tickets of the waves' row sums (eval_chunk_impl)
+  if (!FUSED) {
+    if (threadIdx.x == 0) arrive = 0;
+    __syncthreads(); // (the waves of a workgroup start together and the loads above are in flight: costs nothing)
+  }
+  if (s_status != ST_RUNNING || s_lvl != lvl || s_kind != MODE) return;
+  const bool have_eval = !cand || s_spec_valid != 0;
+  if (!FUSED && !have_eval) return;
+  if (ROSEL == 1 && c.residual_only) return;
+  if (ROSEL == 2 && !c.residual_only) return;
+  const int n = c.n;
   const int P = pts_per_thread(n);
   const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
   // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
@@ -1370,21 +1484,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   float *partials_prob = partials + (size_t)prob * partial_stride;
   const int spec_off = partial_stride >> 1; // the speculative candidate's partials: second half of the problem's block
   if (chunk < nchunks && have_eval) {
-    EvalConsts c;
-    c.pts = in.pts, c.img = in.img, c.n = n, c.w = in.w, c.h = in.h;
-    c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
-#pragma unroll
-    for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
-    c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
-    c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
-    c.residual_only = in.residual_only;
     __shared__ float red[16][kNumSlots];
+    int *const arr = FUSED ? nullptr : &arrive;
+    float *const out = partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride;
     if (ROSEL == 2)
-      eval_chunk_impl<MODE, LVL0, true>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+      eval_chunk_impl<MODE, LVL0, true>(c, chunk, threadIdx.x, true, red, out, arr);
     else if (ROSEL == 1)
-      eval_chunk_impl<MODE, LVL0, false>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+      eval_chunk_impl<MODE, LVL0, false>(c, chunk, threadIdx.x, true, red, out, arr);
     else
-      eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride);
+      eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, out, arr);
     if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
   } else if (!FUSED) {
     return;
@@ -1552,78 +1660,150 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
 }
 
 // ------------------------------------------------------------------------------------------
-// coarse_kernel: the whole LM loop of the small pyramid levels inside ONE launch.
-// One 1024-thread workgroup per problem keeps evaluating (4 chunks at a time, each by a 256-thread
-// group running exactly the code of eval_kernel), reducing (same fixed order, partials in LDS) and
-// stepping the state machine -- state and tracker descriptor staged in LDS for the whole loop --
-// until the problem reaches a level with more than max_pts template points (left to the
-// launch-per-step path) or terminates.  Same arithmetic, same
-// summation order, hence bit-identical results to the launch-per-step path; what disappears is
-// ~80 % of the kernel launches of a track (the coarse levels need the most LM iterations and have
-// the least work per iteration).
+// coarse_kernel: the whole LM loop of the small pyramid levels inside ONE launch, on LDS-resident data.
+// One 512-thread workgroup per problem.  On entering a level it copies the level's intensity plane (and the template, when
+// both fit) into LDS with coalesced 16-byte loads; every LM iteration of the level then evaluates its chunks (two at a
+// time, each by a 256-thread group running exactly the code of eval_kernel, taps by ds_read instead of global gathers),
+// reduces the chunk partials (same fixed order, partials in LDS) and steps the state machine -- state and tracker
+// descriptor staged in LDS for the whole loop -- until the problem reaches a level whose plane does not fit (left to the
+// launch-per-step path) or terminates.  With `spec` the speculative second candidate of dsm_params.speculate is evaluated
+// in the same round and its proposal staged by wave 1 beside wave 0's, as in lm_step_block.  Same arithmetic, same chunk
+// geometry, same summation order: bit-identical results to the launch-per-step path; what disappears is every launch
+// boundary, every state round trip through global memory and every gather miss of the levels that need the most LM
+// iterations and have the least work per iteration.
+// Two workgroups per CU (LDS: ~39 KB static + the arena; registers: four waves per SIMD).
 // ------------------------------------------------------------------------------------------
-constexpr int kCoarseThreads = 512;
+#ifndef DSM_COARSE_THREADS
+#define DSM_COARSE_THREADS 512
+#endif
+#ifndef DSM_COARSE_WAVES
+#define DSM_COARSE_WAVES 4
+#endif
+constexpr int kCoarseThreads = DSM_COARSE_THREADS;
 constexpr int kCoarseGroups = kCoarseThreads / 256;
-constexpr int kCoarseMaxPts = 32768;
-constexpr int kCoarseMaxChunks = 32; // 32768 points / (256 threads * 4 points)
+constexpr int kCoarseMaxChunks = 20;      // chunks of one evaluation whose partials the kernel keeps in LDS
+constexpr int kCoarseArenaFloats = 9216;  // 36 KB: planes up to 120 x 67 (level 4 of 1920 x 1080), 156 x 48 (level 3 of 1248 x 384)
+
+// a level runs in coarse_kernel iff its target plane fits the arena and its chunk partials fit the LDS block (host and device)
+__host__ __device__ inline bool coarse_level_ok(int w, int h, int n, int arena_floats) {
+  return ((w * h + 3) & ~3) <= arena_floats && num_chunks(n) <= kCoarseMaxChunks;
+}
+
+template <int MODE, bool LVL0>
+__device__ __forceinline__ void eval_chunk_lds(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots], float *out) {
+  // (all branches are workgroup-uniform: every thread group of a round evaluates the same candidate)
+  if (LVL0) { // level 0 of a tiny image: flow indicators; the template stays in global memory
+    if (c.residual_only)
+      eval_chunk_impl<MODE, true, true, true, false>(c, chunk, tid, active, red, out);
+    else
+      eval_chunk_impl<MODE, true, false, true, false>(c, chunk, tid, active, red, out);
+  } else if (c.lds_pts) {
+    if (c.residual_only)
+      eval_chunk_impl<MODE, false, true, true, true>(c, chunk, tid, active, red, out);
+    else
+      eval_chunk_impl<MODE, false, false, true, true>(c, chunk, tid, active, red, out);
+  } else {
+    if (c.residual_only)
+      eval_chunk_impl<MODE, false, true, true, false>(c, chunk, tid, active, red, out);
+    else
+      eval_chunk_impl<MODE, false, false, true, false>(c, chunk, tid, active, red, out);
+  }
+}
+
+// wave-uniform evaluation inputs: LDS -> SGPRs
+__device__ __forceinline__ void eval_consts_from_lds(const EvalIn &in, EvalConsts &c) {
+  auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const unsigned long long pp = (unsigned long long)in.pts, ip = (unsigned long long)in.img;
+  c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
+  c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
+  c.n = __builtin_amdgcn_readfirstlane(in.n);
+  c.w = __builtin_amdgcn_readfirstlane(in.w);
+  c.h = __builtin_amdgcn_readfirstlane(in.h);
+  c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.Ki[i] = rf(in.Ki[i]), c.M[i] = rf(in.M[i]);
+  c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
+  c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
+  c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
+  c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
+  c.lds_img = c.lds_pts = 0;
+}
 
 template <int MODE>
-__global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev *const *__restrict__ trackers,
-                                                                LMState *__restrict__ states, int *__restrict__ status_out,
-                                                                int max_pts) {
+__global__ __launch_bounds__(kCoarseThreads) __attribute__((amdgpu_waves_per_eu(DSM_COARSE_WAVES, DSM_COARSE_WAVES))) void coarse_kernel(
+    const TrackerDev *const *__restrict__ trackers, LMState *__restrict__ states, int *__restrict__ status_out, int arena_floats, int spec) {
+  extern __shared__ __attribute__((aligned(16))) float arena[];
   const int prob = blockIdx.x;
   const int tid = threadIdx.x;
   LMState &S = states[prob];
   __shared__ LmShared sh;
+  __shared__ LmSpecShared sps;
   __shared__ float red[kCoarseGroups][16][kNumSlots];
-  __shared__ __attribute__((aligned(16))) float part[kCoarseMaxChunks][kPartialStride];
+  __shared__ __attribute__((aligned(16))) float part[2][kCoarseMaxChunks][kPartialStride];
   if (!(S.status == ST_RUNNING && S.is_scale == MODE)) return; // workgroup-uniform
   stage_in(sh.st, &S, tid, kCoarseThreads);
   stage_in(sh.trk, trackers[prob], tid, kCoarseThreads);
   __syncthreads();
-  const EvalIn &in = sh.st.in;
+  const unsigned arena_lds = (unsigned)(unsigned long long)(DSM_LDS float *)arena;
   const int vb = tid >> 8, t256 = tid & 255;
   bool stepped = false;
+  int staged_lvl = -1;
+  unsigned lds_pts = 0;
   for (;;) {
+    const EvalIn &in = sh.st.in;
     const int status = sh.st.status, lvl = __builtin_amdgcn_readfirstlane(sh.st.lvl);
-    const int n = in.n;
-    if (status != ST_RUNNING || n > max_pts) break; // workgroup-uniform
-    stepped = true;
-    // wave-uniform evaluation inputs: LDS -> SGPRs
     EvalConsts c;
-    {
-      auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-      const unsigned long long pp = (unsigned long long)in.pts, ip = (unsigned long long)in.img;
-      c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
-                               (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
-      c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
-                              (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
-      c.n = __builtin_amdgcn_readfirstlane(n);
-      c.w = __builtin_amdgcn_readfirstlane(in.w);
-      c.h = __builtin_amdgcn_readfirstlane(in.h);
-      c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
-#pragma unroll
-      for (int i = 0; i < 9; i++) c.Ki[i] = rf(in.Ki[i]), c.M[i] = rf(in.M[i]);
-      c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
-      c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
-      c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
-      c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
+    eval_consts_from_lds(in, c);
+    if (status != ST_RUNNING || !coarse_level_ok(c.w, c.h, c.n, arena_floats)) break; // workgroup-uniform
+    stepped = true;
+    if (lvl != staged_lvl) { // entering a level: its plane (and the template, when both fit) -> LDS
+      const int px4 = (c.w * c.h + 3) >> 2; // (planes carry four rows of slack: reading up to three floats past w*h is safe)
+      const uint4 *src = (const uint4 *)c.img;
+      uint4 *dst = (uint4 *)arena;
+      for (int i = tid; i < px4; i += kCoarseThreads) dst[i] = src[i];
+      lds_pts = 0;
+      if (4 * px4 + 4 * c.n <= arena_floats) {
+        const fvec4 *ps = (const fvec4 *)c.pts;
+        fvec4 *pd = (fvec4 *)(arena + 4 * px4);
+        for (int i = tid; i < c.n; i += kCoarseThreads) pd[i] = ps[i];
+        lds_pts = arena_lds + 16u * (unsigned)px4;
+      }
+      staged_lvl = lvl;
+      __syncthreads();
     }
+    c.lds_img = arena_lds;
+    c.lds_pts = lds_pts;
     const int nch = num_chunks(c.n);
-    for (int c0 = 0; c0 < nch; c0 += kCoarseGroups) {
-      const int chunk = c0 + vb;
-      const bool active = chunk < nch;
-      if (lvl == 0)
-        eval_chunk<MODE, true>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
-      else
-        eval_chunk<MODE, false>(c, chunk, t256, active, red[vb], part[active ? chunk : 0]);
-      __syncthreads(); // red[] is reused by the next round
+    const bool have_spec = spec && sh.st.spec_valid != 0; // workgroup-uniform
+    for (int cand = 0; cand < (have_spec ? 2 : 1); cand++) {
+      if (cand == 1) {
+        eval_consts_from_lds(sh.st.spec_in, c);
+        c.lds_img = arena_lds;
+        c.lds_pts = lds_pts;
+      }
+      for (int c0 = 0; c0 < nch; c0 += kCoarseGroups) {
+        const int chunk = c0 + vb;
+        const bool active = chunk < nch;
+        if (lvl == 0)
+          eval_chunk_lds<MODE, true>(c, chunk, t256, active, red[vb], part[cand][active ? chunk : 0]);
+        else
+          eval_chunk_lds<MODE, false>(c, chunk, t256, active, red[vb], part[cand][active ? chunk : 0]);
+        __syncthreads(); // red[] is reused by the next round
+      }
     }
-    reduce_partials_groups(&part[0][0], nch, tid, sh.red);
+    if (vb == 0) reduce_partials_groups(&part[0][0][0], nch, t256, sh.red);
+    if (spec && vb == (kCoarseGroups > 1 ? 1 : 0)) // (garbage where no speculative candidate was evaluated: never looked at then)
+      reduce_partials_groups(&part[1][0][0], nch, t256, sps.red);
+    if (tid == 0 && spec) sps.cmd = 0, sps.done = 0;
     __syncthreads();
     if (tid < 64) {
       reduce_partials_final(tid, sh.red);
-      lm_step_wave0(MODE, lvl, sh.trk, sh.st, sh, tid);
+      if (spec) reduce_partials_final(tid, sps.red);
+      lm_step_wave0(MODE, lvl, sh.trk, sh.st, sh, tid, spec ? &sps : nullptr);
+    } else if (spec && tid < 128) {
+      lm_spec_wave1(MODE, sh.trk, sh.st, sps, tid - 64);
     }
     __syncthreads(); // the state (status, level, next evaluation inputs) is read by all waves
   }
@@ -1635,17 +1815,22 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_kernel(const TrackerDev
 }
 
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
-                   int *status_out, int max_pts) {
-  if (max_pts > kCoarseMaxPts) max_pts = kCoarseMaxPts;
+                   int *status_out, int max_px, bool spec) {
+  if (max_px > kCoarseArenaFloats) max_px = kCoarseArenaFloats;
+  const int arena_floats = (max_px + 3) & ~3;
   dim3 grid(nprob), block(kCoarseThreads);
+  const size_t dyn = sizeof(float) * (size_t)arena_floats;
   if (mode == 0)
-    hipLaunchKernelGGL((coarse_kernel<0>), grid, block, 0, s, trackers, states, status_out, max_pts);
+    hipLaunchKernelGGL((coarse_kernel<0>), grid, block, dyn, s, trackers, states, status_out, arena_floats, spec ? 1 : 0);
   else if (mode == 1)
-    hipLaunchKernelGGL((coarse_kernel<1>), grid, block, 0, s, trackers, states, status_out, max_pts);
+    hipLaunchKernelGGL((coarse_kernel<1>), grid, block, dyn, s, trackers, states, status_out, arena_floats, spec ? 1 : 0);
   else
-    hipLaunchKernelGGL((coarse_kernel<2>), grid, block, 0, s, trackers, states, status_out, max_pts);
+    hipLaunchKernelGGL((coarse_kernel<2>), grid, block, dyn, s, trackers, states, status_out, arena_floats, spec ? 1 : 0);
 }
-int coarse_max_points() { return kCoarseMaxPts; }
+bool coarse_level_fits(int w, int h, int n, int max_px) {
+  if (max_px > kCoarseArenaFloats) max_px = kCoarseArenaFloats;
+  return coarse_level_ok(w, h, n, (max_px + 3) & ~3);
+}
 
 // ------------------------------------------------------------------------------------------
 // queue_kernel: the whole call in ONE launch of persistent workgroups pulling (problem, chunk) items from a
@@ -1752,25 +1937,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
     LMState &S = states[prob];
     const int lvl = __builtin_amdgcn_readfirstlane(s_ctl[2]);
     EvalConsts c;
-    {
-      const EvalIn &in = s_in;
-      auto rf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-      const unsigned long long pp = (unsigned long long)in.pts, ip = (unsigned long long)in.img;
-      c.pts = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
-                               (unsigned)__builtin_amdgcn_readfirstlane((int)pp));
-      c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
-                              (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
-      c.n = __builtin_amdgcn_readfirstlane(in.n);
-      c.w = __builtin_amdgcn_readfirstlane(in.w);
-      c.h = __builtin_amdgcn_readfirstlane(in.h);
-      c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
-#pragma unroll
-      for (int i = 0; i < 9; i++) c.Ki[i] = rf(in.Ki[i]), c.M[i] = rf(in.M[i]);
-      c.t[0] = rf(in.t[0]), c.t[1] = rf(in.t[1]), c.t[2] = rf(in.t[2]);
-      c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
-      c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
-      c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
-    }
+    eval_consts_from_lds(s_in, c);
     const int nch = num_chunks(c.n);
     const int nitems = nch > 0 ? nch : 1; // an empty level still needs its LM step
     float *partials_prob = partials + (size_t)prob * partial_stride;

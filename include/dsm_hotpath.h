@@ -68,10 +68,14 @@ typedef struct dsm_params {
   int adaptive_schedule;              /* 1 (default): speculative per-level launch counts learnt from previous calls, one
                                          host read-back per pass; 0: enqueue the worst case (2*(7+max_iterations) launch
                                          pairs per level) and never poll.  Scheduling only -- results are identical. */
-  int persistent_coarse;              /* N > 0: pyramid levels with at most min(N, 32768) template points run their whole
-                                         LM loop inside one kernel launch per problem; 0 (default): one (evaluate, step)
-                                         launch pair per LM evaluation at every level.  Scheduling only -- results are
-                                         bit-identical. */
+  int persistent_coarse;              /* N > 0: pyramid levels whose target plane has at most min(N, 9216) pixels (156x48,
+                                         120x67, ...; and at most 20 chunks of template points) run their whole LM loop inside
+                                         ONE kernel launch per problem, on an LDS-resident copy of the plane (and of the
+                                         template when both fit), speculative candidates included; 0 (default): one
+                                         (evaluate, step) launch pair per LM evaluation at every level.  Scheduling only --
+                                         results are bit-identical.  Measured: neutral for hundreds of frames in
+                                         flight (a third of the launches), slower for one frame (the launch form spreads a
+                                         level's chunks over many CUs). */
   int fuse_lm;                        /* at pyramid levels >= 1 the evaluation kernel's last-arriving workgroup of a
                                          problem can perform the LM step itself (one launch per evaluation instead of
                                          two): 0 never, 1 (default) for batches of at most 8 problems (where it shortens

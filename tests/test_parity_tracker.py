@@ -461,15 +461,14 @@ def test_stream_groups_do_not_change_results(ctx):
 
 @pytest.mark.parametrize("size,template", [("small", "dense"), ("medium", "dense"), ("medium", "sparse"), ("kitti", "dense")])
 def test_persistent_coarse_kernel_is_bit_identical(ctx, size, template):
-    """levels with <= persistent_coarse (default 8192, at most 32768) template points run their whole LM loop in one launch (coarse_kernel);
-    same arithmetic and summation order as the launch-per-step path, so every output must be
-    bit-identical and the evaluation counts equal."""
+    """levels whose target plane has at most persistent_coarse pixels (capped by the kernel's LDS arena) run their whole LM
+    loop in one launch on LDS-resident data (coarse_kernel); same arithmetic, chunk geometry and summation order as the
+    launch-per-step path, so every output must be bit-identical and the evaluation counts equal."""
     from direct_stereo_slam_amd.tracker import default_params
 
     sc = make_scene(size, seed=60, template=template, n0=12000)
     out, evals, coarse = [], [], []
-    assert default_params().persistent_coarse == 0  # measured neutral so far (DESIGN.md): opt-in
-    for max_pts in (0, 32768, 8192, 1000):
+    for max_pts in (0, 32768, 8192, 2000):
         p = default_params()
         p.persistent_coarse = max_pts
         trk = hip_tracker(ctx, sc, p)
