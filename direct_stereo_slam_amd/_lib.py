@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSM_HOTPATH_LIB: developer override used for A/B builds of the same sources (e.g. other compiler flags)
 LIB_PATH = os.environ.get("DSM_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libdsm_hotpath.so")
 MAX_LEVELS = 6
+ABI_VERSION = 2  # DSM_ABI_VERSION of the header the structures below mirror
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -22,6 +23,7 @@ class DsmError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_size_t),
         ("huber_th", C.c_float),
         ("coarse_cutoff_th", C.c_float),
         ("scale_xi_rot", C.c_float),
@@ -37,6 +39,10 @@ class Params(C.Structure):
         ("fuse_lm", C.c_int),
         ("work_queue", C.c_int),
         ("speculate", C.c_int),
+        ("compact_tail", C.c_int),
+        ("fixed_schedule", C.c_int),
+        ("frame_check", C.c_int),
+        ("frame_grad_tol", C.c_float),
     ]
 
 
@@ -79,6 +85,7 @@ MERGE_ALGOS = {"allreduce_min": 0, "allgather": 1}
 SYMBOLS = {
     "dsm_last_error": (C.c_char_p, []),
     "dsm_abi_version": (C.c_int, []),
+    "dsm_tracker_upload_intensity": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
     "dsm_params_default": (None, [C.POINTER(Params)]),
     "dsm_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "dsm_context_destroy": (C.c_int, [_vp]),
@@ -89,6 +96,7 @@ SYMBOLS = {
     "dsm_context_stream": (_vp, [_vp]),
     "dsm_diag_read_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, c_double_p]),
     "dsm_diag_read_bandwidth_chunked": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_int, c_double_p]),
+    "dsm_diag_xwg_litmus": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dsm_tracker_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, c_double_p, c_float_p, C.POINTER(Params), C.POINTER(_vp)]),
     "dsm_tracker_destroy": (C.c_int, [_vp]),
     "dsm_tracker_make_k": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
@@ -175,6 +183,10 @@ def load():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the struct layouts above are those of ABI version ABI_VERSION (include/dsm_hotpath.h: DSM_ABI_VERSION)
+    have = L.dsm_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} implements ABI version {have}, this binding was written for {ABI_VERSION}: rebuild the library")
     _lib = L
     return L
 

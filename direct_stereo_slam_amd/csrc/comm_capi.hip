@@ -16,7 +16,9 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <vector>
 
 #include "dsm_internal.hpp"
 #include "ringdb_internal.hpp"
@@ -125,6 +127,7 @@ struct dsm_comm {
   dsm_context *ctx = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  std::vector<dsm_ringdb *> attached; // databases that borrow this communicator (detached by dsm_comm_destroy)
 };
 
 namespace {
@@ -186,8 +189,13 @@ int dsm_comm_create(dsm_context *ctx, const unsigned char id[DSM_COMM_ID_BYTES],
   return DSM_OK;
 }
 
+// Destroy order: databases may outlive the communicator (they are detached here: a later collective query fails with
+// DSM_ERR_STATE instead of touching freed memory); the communicator must be destroyed BEFORE its context.
 int dsm_comm_destroy(dsm_comm *c) {
   if (!c) return DSM_OK;
+  for (dsm_ringdb *db : c->attached)
+    if (db->comm == c) db->comm = nullptr;
+  c->attached.clear();
   hipSetDevice(c->ctx->device);
   hipStreamSynchronize(c->ctx->stream);
   if (c->comm) g_rccl.CommDestroy(c->comm);
@@ -247,13 +255,20 @@ int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm) {
   if (!db) return invalid("dsm_ringdb_attach_comm: null database");
   if (comm && (comm->ctx != db->ctx || comm->nranks != db->shard_count || comm->rank != db->shard_rank))
     return invalid("dsm_ringdb_attach_comm: the communicator's context / rank / size must match the database's shard");
+  if (db->comm && db->comm != comm) ringdb_forget_comm(db);
+  if (comm && !db->d_agree) DSM_HIP(hipMalloc(&db->d_agree, 4 * sizeof(unsigned long long)));
   db->comm = comm;
+  if (comm && std::find(comm->attached.begin(), comm->attached.end(), db) == comm->attached.end()) comm->attached.push_back(db);
   return DSM_OK;
 }
 
 int dsm_ringdb_attach_transport(dsm_ringdb *db, int nranks, dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather, void *user) {
   if (!db) return invalid("dsm_ringdb_attach_transport: null database");
   if (allreduce_min && nranks != db->shard_count) return invalid("dsm_ringdb_attach_transport: nranks must equal the database's shard count");
+  if (allreduce_min && !db->d_agree) {
+    DSM_HIP(hipSetDevice(db->ctx->device));
+    DSM_HIP(hipMalloc(&db->d_agree, 4 * sizeof(unsigned long long)));
+  }
   db->tr_allreduce = allreduce_min;
   db->tr_allgather = allgather;
   db->tr_user = user;
@@ -273,4 +288,38 @@ int dsm::ringdb_merge_attached(dsm_ringdb *db, void *d_packed, int nq) {
     return DSM_ERR_STATE;
   }
   return dsm_ringdb_merge_topk(db, db->comm, d_packed, nq, DSM_MERGE_ALLREDUCE_MIN);
+}
+
+void dsm::ringdb_forget_comm(dsm_ringdb *db) {
+  if (!db->comm) return;
+  auto &v = db->comm->attached;
+  v.erase(std::remove(v.begin(), v.end(), db), v.end());
+  db->comm = nullptr;
+}
+
+int dsm::ringdb_agree(dsm_ringdb *db, bool ready, const char *why_not) {
+  if (!db->d_agree || (!db->comm && !db->tr_allreduce)) {
+    set_error("sharded ring-key DB: attach a communicator first (dsm_ringdb_attach_comm)");
+    return DSM_ERR_STATE;
+  }
+  hipStream_t st = db->ctx->stream;
+  // (every word stays below 2^63: transports may order the words as signed integers, as the packed candidates allow)
+  const unsigned long long kBig = 1ull << 62, sz = (unsigned long long)db->size_global;
+  unsigned long long w[3] = {ready ? 1ull : 0ull, sz, kBig - sz};
+  DSM_HIP(hipMemcpyAsync(db->d_agree, w, sizeof w, hipMemcpyHostToDevice, st));
+  int rc = db->comm ? rccl_allreduce_min(db->comm, db->d_agree, 3, (void *)st) : db->tr_allreduce(db->tr_user, db->d_agree, 3, (void *)st);
+  if (rc) return rc;
+  DSM_HIP(hipMemcpyAsync(w, db->d_agree, sizeof w, hipMemcpyDeviceToHost, st));
+  DSM_HIP(hipStreamSynchronize(st));
+  if (w[0] != 1ull) {
+    set_error(ready ? "collective ring-key query: another rank could not take part (see its dsm_last_error); no rank entered the merge"
+                    : (std::string("collective ring-key query: this rank could not take part: ") + (why_not ? why_not : "")).c_str());
+    return DSM_ERR_STATE;
+  }
+  if (w[1] != kBig - w[2]) { // min of the sizes != max of the sizes
+    set_error("collective ring-key query: the ranks' databases hold different numbers of entries (every rank must make the same "
+              "add_points / query_then_enqueue calls); no rank entered the merge");
+    return DSM_ERR_STATE;
+  }
+  return DSM_OK;
 }

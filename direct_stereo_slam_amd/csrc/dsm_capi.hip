@@ -74,6 +74,8 @@ int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride) {
   if ((rc = realloc_pinned(&ctx->h_single, cap))) return rc;
   if ((rc = realloc_dev(&ctx->d_status, 2 * (size_t)cap))) return rc;
   if ((rc = realloc_pinned(&ctx->h_status, 2 * (size_t)cap))) return rc;
+  if ((rc = realloc_dev(&ctx->d_rowmap, cap))) return rc;
+  if ((rc = realloc_pinned(&ctx->h_rowmap, cap))) return rc;
   if ((rc = realloc_dev(&ctx->d_tickets, cap))) return rc;
   DSM_HIP(hipMemsetAsync(ctx->d_tickets, 0, sizeof(int) * cap, ctx->stream));
   DSM_HIP(hipMemsetAsync(ctx->d_states, 0, sizeof(LMState) * cap, ctx->stream));
@@ -205,6 +207,8 @@ const char *dsm_last_error(void) { return g_err.c_str(); }
 int dsm_abi_version(void) { return DSM_ABI_VERSION; }
 
 void dsm_params_default(dsm_params *p) {
+  memset(p, 0, sizeof *p);
+  p->struct_size = sizeof(dsm_params);
   p->huber_th = 9.0f;
   p->coarse_cutoff_th = 20.0f;
   p->scale_xi_rot = 1.0f;
@@ -221,6 +225,10 @@ void dsm_params_default(dsm_params *p) {
   p->fuse_lm = 1;
   p->work_queue = 1;
   p->speculate = 1;
+  p->compact_tail = 1;
+  p->fixed_schedule = 0;
+  p->frame_check = 1;
+  p->frame_grad_tol = 0.0f;
 }
 
 int dsm_context_create(int device_ordinal, dsm_context **out) {
@@ -263,6 +271,8 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipFree(ctx->d_single);
   hipHostFree(ctx->h_single);
   hipFree(ctx->d_status);
+  hipFree(ctx->d_rowmap);
+  if (ctx->h_rowmap) hipHostFree(ctx->h_rowmap);
   hipFree(ctx->d_tickets);
   hipFree(ctx->d_queue);
   hipFree(ctx->d_qitems);
@@ -348,10 +358,14 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
   t->w = w;
   t->h = h;
   t->nlevels = nlevels;
-  if (params)
+  if (params) {
+    if (params->struct_size != sizeof(dsm_params))
+      return invalid("dsm_params.struct_size does not match this library's dsm_params: the caller was built against another "
+                     "version of dsm_hotpath.h (use dsm_params_default, compare dsm_abi_version() with DSM_ABI_VERSION)");
     t->params = *params;
-  else
+  } else {
     dsm_params_default(&t->params);
+  }
   TrackerDev &D = t->desc;
   memset(&D, 0, sizeof D);
   D.nlevels = nlevels;
@@ -365,6 +379,7 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
   D.p.affine_opt_mode_b = t->params.affine_opt_mode_b;
   D.p.lambda_extrapolation_limit = t->params.lambda_extrapolation_limit;
   for (int l = 0; l < DSM_MAX_LEVELS; l++) D.p.max_iterations[l] = t->params.max_iterations[l];
+  D.p.fixed_schedule = t->params.fixed_schedule;
   se3_from_matrix(T_f1_f0, D.T10);
   for (int l = 0; l < nlevels; l++) { // TrackerAndScaler.cpp:52-64
     const int wl = w >> l, hl = h >> l;
@@ -562,24 +577,49 @@ int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, 
   dsm_context *ctx = t->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
   // The device keeps channel 0 only; channels 1 and 2 must be what FrameHessian::makeImages derives
-  // from it -- which is all the reference ever passes -- and that is checked, not assumed.
+  // from it -- which is all the reference ever passes -- and that is checked (dsm_params.frame_check, frame_grad_tol), not
+  // assumed: per level the number of offending texels and the first of them.
   const size_t npx0 = (size_t)t->w * t->h;
-  int rc = ensure_stage(ctx, 3 * npx0 + 4);
+  int rc = ensure_stage(ctx, 3 * npx0 + 4 * DSM_MAX_LEVELS);
   if (rc) return rc;
-  int *d_bad = (int *)(ctx->d_stage + 3 * npx0);
-  DSM_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
+  int *d_bad = (int *)(ctx->d_stage + 3 * npx0); // [level]{count, first index}
+  int h_bad[2 * DSM_MAX_LEVELS];
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) h_bad[2 * l] = 0, h_bad[2 * l + 1] = 0x7FFFFFFF;
+  const bool check = t->params.frame_check != 0;
+  if (check) DSM_HIP(hipMemcpyAsync(d_bad, h_bad, sizeof h_bad, hipMemcpyHostToDevice, ctx->stream));
   for (int l = 0; l < t->nlevels; l++) {
     const int wl = t->w >> l, hl = t->h >> l;
     DSM_HIP(hipMemcpyAsync(ctx->d_stage, dIp[l], (size_t)wl * hl * 12, hipMemcpyHostToDevice, ctx->stream));
-    launch_dip_import(ctx->stream, wl, hl, ctx->d_stage, t->d_img[slot][l], d_bad);
+    launch_dip_import(ctx->stream, wl, hl, ctx->d_stage, t->d_img[slot][l], check ? d_bad + 2 * l : nullptr, t->params.frame_grad_tol);
   }
-  int bad = 0;
-  DSM_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (check) DSM_HIP(hipMemcpyAsync(h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
-  if (bad) {
-    t->have_frame[slot] = false;
-    return invalid("dsm_tracker_upload_frame: the gradient channels are not the central differences of channel 0 (makeImages)");
+  for (int l = 0; check && l < t->nlevels; l++)
+    if (h_bad[2 * l]) {
+      t->have_frame[slot] = false;
+      const int wl = t->w >> l, idx = h_bad[2 * l + 1];
+      char msg[320];
+      snprintf(msg, sizeof msg,
+               "dsm_tracker_upload_frame: level %d: %d texel(s) whose gradient channels are not the central differences of channel 0 "
+               "(makeImages), the first at index %d (x = %d, y = %d); see dsm_params.frame_check / frame_grad_tol",
+               l, h_bad[2 * l], idx, idx % wl, idx / wl);
+      return invalid(msg);
+    }
+  t->desc.exposure[slot] = ab_exposure;
+  t->have_frame[slot] = true;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
+int dsm_tracker_upload_intensity(dsm_tracker *t, int slot, const float *const *I, float ab_exposure) {
+  if (!t || !I || slot < 0 || slot > 1) return invalid("dsm_tracker_upload_intensity: bad argument");
+  dsm_context *ctx = t->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  for (int l = 0; l < t->nlevels; l++) {
+    if (!I[l]) return invalid("dsm_tracker_upload_intensity: null level");
+    DSM_HIP(hipMemcpyAsync(t->d_img[slot][l], I[l], sizeof(float) * (size_t)(t->w >> l) * (t->h >> l), hipMemcpyHostToDevice, ctx->stream));
   }
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
   t->desc.exposure[slot] = ab_exposure;
   t->have_frame[slot] = true;
   t->desc_dirty = true;
@@ -919,12 +959,12 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   // results are bit-identical to the launch-per-step form below.
   // Default rule (measured): the queue form wins while the batch is large enough to fill the
   // persistent workgroups and small enough that its per-item cost (a few microseconds per chunk) does not add up --
-  // up to about 32 k finest-level chunks per call (256 dense KITTI frames; thousands of sparse ones).
+  // up to about 24 k finest-level chunks per call (about 200 dense KITTI frames; thousands of sparse ones).
   bool use_queue = P.work_queue >= 2 && n2 == 0;
   if (P.work_queue == 1 && n >= 32 && n2 == 0) {
     long long chunks0 = 0;
     for (int i = 0; i < n; i++) chunks0 += num_chunks(ts[i]->desc.lv[0].n);
-    use_queue = chunks0 <= 32768;
+    use_queue = chunks0 <= 24576; // (256 dense S2 frames = 29.7 k chunks: 4 % slower than the launch form; 192: faster)
   }
   if (use_queue) {
     int max_items = 1;
@@ -965,6 +1005,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   }
   size_t ev_used = 0;
   std::vector<int> ev_lvl;
+  int rc_build = DSM_OK;
   // Launch schedule.  The LM loop is sequential per problem and its length is data dependent
   // (TrackerAndScaler.cpp:477,505,588,601); polling the device after every few launches costs a
   // host round trip each time.  Instead every level gets a speculative number of (eval, lm) launch
@@ -980,7 +1021,8 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       const int c = num_chunks(ts[i]->desc.lv[L].n);
       if (c > max_chunks) max_chunks = c;
       if (ts[i]->desc.lv[L].n > max_n) max_n = ts[i]->desc.lv[L].n;
-      if (ts[i]->params.max_iterations[L] > max_it) max_it = ts[i]->params.max_iterations[L];
+      const int it_i = ts[i]->params.fixed_schedule > 0 ? ts[i]->params.fixed_schedule : ts[i]->params.max_iterations[L];
+      if (it_i > max_it) max_it = it_i;
     }
     grid_x[L] = max_chunks < 8 ? max_chunks : round8(max_chunks);
     level_pts[L] = max_n;
@@ -997,10 +1039,11 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       int groups = ctx->n_streams < 1 ? 1 : ctx->n_streams;
       if (groups > N) groups = N;
       const long long launch_points = (long long)((N + groups - 1) / groups) * max_n;
-      spec[L] = P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192 && launch_points <= 1000000ll);
+      spec[L] = P.fixed_schedule <= 0 && (P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192 && launch_points <= 1000000ll));
     }
   }
   int *sched = ctx->sched[mode], *sched2 = ctx->sched[mode2];
+  const int *bulk = ctx->sched_bulk[mode], *bulk2 = ctx->sched_bulk[mode2];
   if (n2 > 0 && !ctx->companion_stream) {
     DSM_HIP(hipStreamCreateWithFlags(&ctx->companion_stream, hipStreamNonBlocking));
     DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
@@ -1029,7 +1072,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
         if (top2 >= 0) DSM_HIP(hipStreamWaitEvent(ctx->companion_stream, ctx->fork_event, 0));
       }
-      const bool cspec = P.speculate >= 1;
+      const bool cspec = P.speculate >= 1 && P.fixed_schedule <= 0;
       for (int g = 0; g < ng; g++) {
         const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
         if (g1 <= g0) continue;
@@ -1055,11 +1098,81 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       if (n2 > 0) top2 = first_launch_level(n, N);
     }
   }
+  // Segments of the launch schedule: the stream groups of the main batch (the batch is split into `ng` contiguous groups,
+  // each with its own HIP stream: a group's lm_kernel -- one small workgroup per problem -- and its small-level eval kernels
+  // leave most of the chip idle; another group's kernels fill it) and the companion segment.  Per-problem results do not
+  // depend on the split.
+  struct Seg {
+    hipStream_t st;
+    int i0, i1, mode;
+    bool companion;
+    int rows; // >= 0: compact launches over the first `rows` entries of the segment's row map; -1: one row per problem
+  };
+  std::vector<Seg> segs;
+  for (int g = 0; g < ng; g++) {
+    const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
+    if (g1 > g0) segs.push_back(Seg{g == 0 ? ctx->stream : ctx->extra_streams[g - 1], g0, g1, mode, false, -1});
+  }
+  if (n2 > 0) segs.push_back(Seg{ctx->companion_stream, n, N, mode2, true, -1});
+  // one (evaluate, step) round of a segment at level L
+  auto launch_round = [&](const Seg &sg, int L, int k, int pass) -> int {
+    const int np = sg.i1 - sg.i0, rows = sg.rows >= 0 ? sg.rows : np;
+    if (rows == 0) return DSM_OK;
+    const int *rowmap = sg.rows >= 0 ? ctx->d_rowmap + sg.i0 : nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (ctx->timing && !sg.companion) {
+      ea = get_event(ctx, ev_used++);
+      eb = get_event(ctx, ev_used++);
+      ev_lvl.push_back(L);
+      if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
+    }
+    // levels >= 1: the eval kernel's last-arriving workgroup per problem can perform the LM step itself (one launch per
+    // round instead of two): for launches of few problems -- small batches (measured: -6 % latency for one frame in flight,
+    // -11 % throughput at 256) and compact launches over a handful of stragglers.
+    // (Up to 8 rows: the fused kernel runs four workgroups per CU against five of the plain one and carries the LM step's LDS;
+    // measured on 45 level-1 stragglers: 59 us per fused round against ~37 for the pair.)
+    const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && rows <= 8));
+    // Large levels: the residual-only evaluations (the level's last ones, tracker_kernels.hip) get a launch of their own
+    // behind the full ones -- an instantiation without the 45 accumulators, 30-41 VGPRs = eight waves per SIMD instead
+    // of four or five.  Never in a level's first round (its evaluation is the level's first).  Measured (S2 dense, 512
+    // frames): level-0 evaluations 4.62 -> 4.40 ms per step, 54.3 -> 55.7 k frames/s with levels 0 and 1 split; with
+    // level 2 as well 53.7-55.3 k (the extra launch costs more than it gives there); one frame in flight 0.70 -> 0.74 ms
+    // (three more launches), hence the floor on the points per launch.
+    const bool split_ro = !sg.companion && !fused && k > 0 && level_pts[L] >= 100000 && (long long)rows * level_pts[L] >= 8000000ll;
+    launch_eval(sg.st, sg.mode, L, grid_x[L], rows, ctx->d_tracker_ptrs + sg.i0, ctx->d_states + sg.i0,
+                ctx->d_partials + (size_t)sg.i0 * ctx->partial_stride, ctx->partial_stride, fused ? ctx->d_tickets + sg.i0 : nullptr,
+                ctx->d_status + 2 * sg.i0, spec[L], split_ro, rowmap);
+    if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
+    if (!fused)
+      launch_lm(sg.st, sg.mode, LM_OP_STEP, L, rows, ctx->d_tracker_ptrs + sg.i0, ctx->d_states + sg.i0,
+                ctx->d_partials + (size_t)sg.i0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr, ctx->d_status + 2 * sg.i0,
+                spec[L], rowmap);
+    return DSM_OK;
+  };
+  // row map of a segment: the problems (relative to its first) for which `keep(status, level)` holds, from h_status
+  auto build_rowmap = [&](Seg &sg, auto keep) -> int {
+    int r = 0;
+    for (int i = sg.i0; i < sg.i1; i++)
+      if (keep(ctx->h_status[2 * i], ctx->h_status[2 * i + 1])) ctx->h_rowmap[sg.i0 + r++] = i - sg.i0;
+    sg.rows = r;
+    if (r > 0) DSM_HIP(hipMemcpyAsync(ctx->d_rowmap + sg.i0, ctx->h_rowmap + sg.i0, sizeof(int) * r, hipMemcpyHostToDevice, sg.st));
+    return DSM_OK;
+  };
   for (int pass = 0; !use_queue; pass++) {
     if (ng > 1 || top2 >= 0) { // fork: the extra streams start after everything enqueued on the main stream so far
       DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
       for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
       if (top2 >= 0) DSM_HIP(hipStreamWaitEvent(ctx->companion_stream, ctx->fork_event, 0));
+    }
+    // Later passes only continue what the previous one left unfinished: compact launches over the problems still running
+    // (a launch over all problems of a batch costs ~1.6 ns per idle workgroup: 100 us for a level-0 grid of 512 problems).
+    const bool compact_ok = P.adaptive_schedule != 0 && P.compact_tail != 0;
+    for (Seg &sg : segs) {
+      sg.rows = -1;
+      if (pass > 0 && compact_ok) {
+        rc_build = build_rowmap(sg, [](int st, int) { return st == ST_RUNNING; });
+        if (rc_build) return rc_build;
+      }
     }
     for (int L = top > top2 ? top : top2; L >= 0; L--) {
       int steps = P.adaptive_schedule ? sched[L] << (pass > 3 ? 3 : pass) : worst[L];
@@ -1072,52 +1185,45 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         if (steps2 > worst[L]) steps2 = worst[L];
         if (steps2 < 1) steps2 = 1;
       }
-      for (int k = 0; k < steps2 || k < steps; k++) {
-        if (k < steps2) { // the companion segment: one (evaluate, step) pair on its own stream
-          hipStream_t cs = ctx->companion_stream;
-          const bool fused2 = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n2 <= 8));
-          launch_eval(cs, mode2, L, grid_x[L], n2, ctx->d_tracker_ptrs + n, ctx->d_states + n,
-                      ctx->d_partials + (size_t)n * ctx->partial_stride, ctx->partial_stride, fused2 ? ctx->d_tickets + n : nullptr,
-                      ctx->d_status + 2 * n, spec[L]);
-          if (!fused2)
-            launch_lm(cs, mode2, LM_OP_STEP, L, n2, ctx->d_tracker_ptrs + n, ctx->d_states + n,
-                      ctx->d_partials + (size_t)n * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr, ctx->d_status + 2 * n,
-                      spec[L]);
-        }
-        if (k >= steps) continue;
-        // Stream groups: the batch is split into `ng` contiguous groups, each with its own HIP stream.
-        // A group's lm_kernel (one small workgroup per problem) and its small-level eval kernels leave
-        // most of the chip idle; another group's kernels fill it.  Per-problem results are unchanged.
-        for (int g = 0; g < ng; g++) {
-          const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
-          if (g1 <= g0) continue;
-          hipStream_t st = g == 0 ? ctx->stream : ctx->extra_streams[g - 1];
-          hipEvent_t ea = nullptr, eb = nullptr;
-          if (ctx->timing) {
-            ea = get_event(ctx, ev_used++);
-            eb = get_event(ctx, ev_used++);
-            ev_lvl.push_back(L);
-            if (ea) DSM_HIP(hipEventRecord(ea, st));
+      // Phase A: the rounds most problems need (up to the third quartile of what recent calls' problems took), one row per
+      // problem.  Phase B, first pass only: ONE read-back of the level's status, then the remaining rounds as compact
+      // launches over the problems still at this level -- the stragglers (a level's last rounds are needed by a handful of
+      // problems: 52 launches at levels 2 and 3 of 512 distinct S2 frames where the median problem needs 6 and 10).
+      auto seg_steps = [&](const Seg &sg) { return sg.companion ? steps2 : steps; };
+      auto seg_bulk = [&](const Seg &sg) {
+        const int st = seg_steps(sg), bk = (sg.companion ? bulk2 : bulk)[L];
+        const bool worth = compact_ok && pass == 0 && sg.i1 - sg.i0 >= 32 && (long long)grid_x[L] * (sg.i1 - sg.i0) >= 1024 && st - bk >= 3;
+        return worth ? bk : st;
+      };
+      int kmax = 0;
+      for (const Seg &sg : segs) kmax = seg_bulk(sg) > kmax ? seg_bulk(sg) : kmax;
+      for (int k = 0; k < kmax; k++)
+        for (int si = (int)segs.size() - 1; si >= 0; si--) { // (the companion's round first, as before)
+          const Seg &sg = segs[si];
+          if (k < seg_bulk(sg)) {
+            const int rc = launch_round(sg, L, k, pass);
+            if (rc) return rc;
           }
-          // levels >= 1: the eval kernel's last-arriving workgroup per problem performs the LM step itself
-          // (measured: -6 % latency for one frame in flight, -11 % throughput at 256 -- hence the batch rule)
-          const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && n <= 8));
-          // Large levels: the residual-only evaluations (the level's last ones, tracker_kernels.hip) get a launch of their own
-          // behind the full ones -- an instantiation without the 45 accumulators, 30-41 VGPRs = eight waves per SIMD instead
-          // of four or five.  Never in a level's first round (its evaluation is the level's first).  Measured (S2 dense, 512
-          // frames): level-0 evaluations 4.62 -> 4.40 ms per step, 54.3 -> 55.7 k frames/s with levels 0 and 1 split; with
-          // level 2 as well 53.7-55.3 k (the extra launch costs more than it gives there); one frame in flight 0.70 -> 0.74 ms
-          // (three more launches), hence the floor on the points per launch.
-          const bool split_ro = !fused && k > 0 && level_pts[L] >= 100000 && (long long)(g1 - g0) * level_pts[L] >= 8000000ll;
-          launch_eval(st, mode, L, grid_x[L], g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
-                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride,
-                      fused ? ctx->d_tickets + g0 : nullptr, ctx->d_status + 2 * g0, spec[L], split_ro);
-          if (ctx->timing && eb) DSM_HIP(hipEventRecord(eb, st));
-          if (!fused)
-            launch_lm(st, mode, LM_OP_STEP, L, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0,
-                      ctx->d_partials + (size_t)g0 * ctx->partial_stride, ctx->partial_stride, nullptr, nullptr,
-                      ctx->d_status + 2 * g0, spec[L]);
         }
+      bool any_tail = false;
+      for (const Seg &sg : segs) any_tail = any_tail || seg_bulk(sg) < seg_steps(sg);
+      if (any_tail) {
+        for (const Seg &sg : segs)
+          if (seg_bulk(sg) < seg_steps(sg))
+            DSM_HIP(hipMemcpyAsync(ctx->h_status + 2 * sg.i0, ctx->d_status + 2 * sg.i0, sizeof(int) * 2 * (sg.i1 - sg.i0), hipMemcpyDeviceToHost, sg.st));
+        for (Seg &sg : segs) {
+          const int kb = seg_bulk(sg), ks = seg_steps(sg);
+          if (kb >= ks) continue;
+          DSM_HIP(hipStreamSynchronize(sg.st));
+          rc_build = build_rowmap(sg, [L](int st, int lv) { return st == ST_RUNNING && lv == L; });
+          if (rc_build) return rc_build;
+          for (int k = kb; k < ks; k++) {
+            const int rc = launch_round(sg, L, k, pass);
+            if (rc) return rc;
+          }
+          sg.rows = -1; // the next level starts with one row per problem again
+        }
+        ctx->stats.polls++;
       }
       ctx->stats.launches[L] += steps;
       ctx->stats2.launches[L] += steps2;
@@ -1212,6 +1318,20 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       // or, for a sparse template, the four 12-byte taps of every point if that is less
       const long long nl = ts[i]->desc.lv[l].n, img = 12ll * (ts[i]->w >> l) * (ts[i]->h >> l);
       st.algorithmic_bytes += S.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
+    }
+  }
+  // the third quartile of the rounds per problem and level: where the next call's launches turn to the fused form
+  {
+    std::vector<int> r;
+    for (int seg = 0; seg < (n2 > 0 ? 2 : 1); seg++) {
+      const int i0 = seg ? n : 0, i1 = seg ? N : n;
+      int *dst = ctx->sched_bulk[seg ? mode2 : mode];
+      for (int l = 0; l < nlevels; l++) {
+        r.clear();
+        for (int i = i0; i < i1; i++) r.push_back((int)ctx->h_states[i].rounds[l]);
+        std::nth_element(r.begin(), r.begin() + (3 * r.size()) / 4, r.end());
+        dst[l] = r[(3 * r.size()) / 4] + 1;
+      }
     }
   }
   // next call's schedule: what this batch needed plus one, decaying slowly towards it

@@ -4,8 +4,8 @@
 //   template  : per level one float4 {u, v, idepth, color} per point (16 B, one coalesced
 //               global_load_dwordx4 per lane)           <- pc_u/pc_v/pc_idepth/pc_color SoA of the
 //               reference (TrackerAndScaler.h:90-94), interleaved at upload time
-//   target    : per level the reference's AoS (I,dx,dy) float3 texels (FrameHessian::dIp,
-//               TrackerAndScaler.cpp:709,1016), 12 B per texel, row-major
+//   target    : per level the intensity plane (channel 0 of the reference's AoS (I,dx,dy) texels FrameHessian::dIp,
+//               TrackerAndScaler.cpp:709,1016), 4 B per texel, row-major; gradients are formed from neighbours
 //   partials  : per problem, per chunk 64 floats (45 upper-triangular 9x9 sums, E, flow sums,
 //               integer counts)
 #pragma once
@@ -41,6 +41,7 @@ struct ParamsDev {
   float affine_opt_mode_a, affine_opt_mode_b;
   float lambda_extrapolation_limit;
   int max_iterations[DSM_MAX_LEVELS];
+  int fixed_schedule; // dsm_params.fixed_schedule: K > 0 = benchmark schedule (1 + K evaluations per level, every step taken)
 };
 
 // Read-only (during track / optimize_scale) description of one TrackerAndScaler.

@@ -65,12 +65,17 @@ struct dsm_context {
   unsigned long long *d_qitems = nullptr;
   size_t qcap = 0;
   int queue_blocks[3] = {0, 0, 0}; // co-resident grid size per mode
+  int *d_rowmap = nullptr, *h_rowmap = nullptr; // compact launches: row -> problem (relative to the segment), device / pinned
   int *d_tickets = nullptr; // per-problem arrival counters of the fused eval+LM kernels (zero between launches)
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;
   // speculative launch schedule per mode (0 = track, 1 = scale, 2 = loop-closure pose) and level, adapted after every call
   int sched[3][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}, {6, 8, 10, 12, 16, 16}};
+  // ... and the number of launches after which only a level's stragglers are still at work (the third quartile of the
+  // rounds the problems of recent calls needed): from there on a round is ONE fused evaluate + step launch (dsm_params.fuse_lm = 1)
+  int sched_bulk[3][DSM_MAX_LEVELS] = {{1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30}, {1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30},
+                                       {1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30}};
   // stats / timing
   bool timing = false;
   dsm_stats stats{};

@@ -44,12 +44,14 @@ struct StartInfo { // host -> device, one per problem
 };
 
 // mode: 0 = pose (calcResPose + calcGSSSEPose), 1 = scale (calcResScale + calcGSSSEScale)
+// rowmap != nullptr: compact launch over nprob rows, row r = problem rowmap[r] (indices relative to trackers / states)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out, bool spec = false, bool split_ro = false);
+                 int partial_stride, int *tickets, int *status_out, bool spec = false, bool split_ro = false,
+                 const int *rowmap = nullptr);
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
-               SingleOut *single_out, int *status_out, bool spec = false);
+               SingleOut *single_out, int *status_out, bool spec = false, const int *rowmap = nullptr);
 
 // work-queue kernel (queue_kernel): header of the device-side queue, zeroed before every launch; counters on their
 // own 128-byte lines.  Items: (index + 1) << 32 | problem << kQueueChunkBits | chunk.
@@ -82,10 +84,11 @@ void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float 
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
 // makeImages (upstream DSO): the intensity plane of level 0 from the float image, of level l from level l-1
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img);
-// the reference's (I, dx, dy) texels out of / into an intensity plane; import counts texels whose gradient channels are
-// not makeImages' central differences of channel 0 into *d_bad
+// the reference's (I, dx, dy) texels out of / into an intensity plane; with d_bad != nullptr import counts the texels whose
+// gradient channels are not makeImages' central differences of channel 0 (bitwise, or beyond tol) into d_bad[0] and keeps
+// the first such index in d_bad[1]
 void launch_dip_export(hipStream_t s, int w, int h, const float *plane, float *out3);
-void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad);
+void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad, float tol);
 // one image of a batched hand-over (dsm_upload_images): staged level-0 pixels (float or u8) and the pyramid levels
 struct PyrJob {
   const void *raw;

@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "dsm_internal.hpp"
+#include <string>
+
 #include "ringdb_internal.hpp"
 
 using namespace dsm;
@@ -140,6 +142,8 @@ int dsm_ringdb_destroy(dsm_ringdb *db) {
   hipFree(db->d_scratch);
   hipFree(db->d_out);
   hipFree(db->d_merge);
+  hipFree(db->d_agree);
+  dsm::ringdb_forget_comm(db);
   delete db;
   return DSM_OK;
 }
@@ -210,14 +214,19 @@ int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_ou
     return DSM_ERR_STATE;
   }
   int nc = 0;
-  if (db->size_global > db->k) { // `ringkeys->size() > FLANN_NN`, search_place.h:29
-    int64_t packed[4];
-    int rc;
-    if (db->shard_count == 1) {
-      rc = dsm_ringdb_knn_packed_host(db, key, 1, packed);
+  const bool search = db->size_global > db->k; // `ringkeys->size() > FLANN_NN`, search_place.h:29
+  int64_t packed[4] = {DSM_RINGDB_NO_CANDIDATE, DSM_RINGDB_NO_CANDIDATE, DSM_RINGDB_NO_CANDIDATE, DSM_RINGDB_NO_CANDIDATE};
+  if (db->shard_count == 1) {
+    if (search) {
+      const int rc = dsm_ringdb_knn_packed_host(db, key, 1, packed);
       if (rc) return rc;
-    } else {
-      DSM_HIP(hipSetDevice(db->ctx->device));
+    }
+  } else {
+    DSM_HIP(hipSetDevice(db->ctx->device));
+    // Local part first; whatever goes wrong here is agreed upon by ALL ranks (round 0, also when the index is still too small
+    // to be searched: the ranks must agree on that as well) before any of them enters the merge rounds -- a rank that
+    // returned early on its own would leave the others waiting in an all-reduce.
+    auto local_scan = [&]() -> int {
       if ((size_t)db->k > db->out_words) {
         if (db->d_out) DSM_HIP(hipFree(db->d_out));
         db->d_out = nullptr;
@@ -225,21 +234,26 @@ int dsm_ringdb_query_then_enqueue(dsm_ringdb *db, const float *key, int *cand_ou
         DSM_HIP(hipMalloc(&db->d_out, 4 * sizeof(unsigned long long)));
         db->out_words = 4;
       }
-      rc = rdb_stage(db, (size_t)db->dim);
-      if (rc) return rc;
+      const int r = rdb_stage(db, (size_t)db->dim);
+      if (r) return r;
       DSM_HIP(hipMemcpyAsync(db->d_q, key, sizeof(float) * db->dim, hipMemcpyHostToDevice, db->ctx->stream));
-      rc = rdb_knn_dev(db, db->d_q, 1, db->d_out);
-      if (rc) return rc;
+      return rdb_knn_dev(db, db->d_q, 1, db->d_out);
+    };
+    const int rc_local = search ? local_scan() : DSM_OK;
+    const std::string why = rc_local ? dsm_last_error() : "";
+    int rc = ringdb_agree(db, rc_local == DSM_OK, why.c_str());
+    if (rc) return rc_local ? rc_local : rc;
+    if (search) {
       rc = ringdb_merge_attached(db, db->d_out, 1);
       if (rc) return rc;
       DSM_HIP(hipMemcpyAsync(packed, db->d_out, sizeof(unsigned long long) * db->k, hipMemcpyDeviceToHost, db->ctx->stream));
       DSM_HIP(hipStreamSynchronize(db->ctx->stream));
     }
-    for (int i = 0; i < db->k; i++) {
-      if (packed[i] == DSM_RINGDB_NO_CANDIDATE) continue; // dist >= RINGKEY_THRES was filtered on the device
-      const int idx = (int)(packed[i] & 0xFFFFFFFFll);
-      if (idx > 0) cand_out[nc++] = idx - 1; // :34-38
-    }
+  }
+  for (int i = 0; search && i < db->k; i++) {
+    if (packed[i] == DSM_RINGDB_NO_CANDIDATE) continue; // dist >= RINGKEY_THRES was filtered on the device
+    const int idx = (int)(packed[i] & 0xFFFFFFFFll);
+    if (idx > 0) cand_out[nc++] = idx - 1; // :34-38
   }
   *ncand_out = nc;
   return dsm_ringdb_enqueue(db, key);

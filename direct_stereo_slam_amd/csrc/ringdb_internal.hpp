@@ -24,7 +24,9 @@ struct dsm_ringdb {
   // cross-shard merge (comm_capi.hip): workspace and the communicator attached for query_then_enqueue
   unsigned long long *d_merge = nullptr;
   size_t merge_words = 0;
-  struct dsm_comm *comm = nullptr; // borrowed
+  struct dsm_comm *comm = nullptr; // borrowed; dsm_comm_destroy detaches it from every database it is attached to
+  unsigned long long *d_agree = nullptr; // 4 words: the ranks' agreement round of a collective query (allocated when a
+                                         // communicator / transport is attached, so that the query path allocates nothing)
   // ... or a caller-supplied transport (dsm_ringdb_attach_transport)
   dsm_allreduce_min_u64_fn tr_allreduce = nullptr;
   dsm_allgather_u64_fn tr_allgather = nullptr;
@@ -35,4 +37,10 @@ struct dsm_ringdb {
 namespace dsm {
 // merge d_packed (nq x k local candidates) across the shards through the attached communicator
 int ringdb_merge_attached(dsm_ringdb *db, void *d_packed, int nq);
+// Round 0 of a collective query: one all-reduce(min) over {this rank is ready, index size, 2^62 - index size}.  Returns DSM_OK on
+// every rank only if every rank was ready and all hold the same index size; otherwise every rank gets the same error and
+// none enters the merge rounds (a rank that bailed out alone would leave the others waiting in a collective).
+int ringdb_agree(dsm_ringdb *db, bool ready, const char *why_not);
+// the communicator is going away: detach it from the databases that borrow it
+void ringdb_forget_comm(dsm_ringdb *db);
 } // namespace dsm

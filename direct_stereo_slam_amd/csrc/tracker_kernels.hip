@@ -17,6 +17,7 @@
 // float rounding (quirk Q4 is a CPU artefact, not reproduced).  No float atomics.
 #include "dsm_kernels.hpp"
 #include "lm_math.hpp"
+#include "xwg_sync.hpp"
 
 
 namespace dsm {
@@ -197,39 +198,6 @@ struct EvalConsts {
   int residual_only; // EvalIn::residual_only
   unsigned lds_img, lds_pts; // coarse_kernel: LDS byte addresses of the staged intensity plane / template (else unused)
 };
-
-// Chunk partials are produced by one workgroup and consumed by another (the LM step), possibly on a
-// different XCD and -- in the fused eval+LM kernel -- inside the same launch: written and read with
-// device-scope accesses (write-through / L2-coherent), so no cache-wide write-back or invalidate is
-// ever needed for them.
-//
-// Ordering between workgroups (arrival tickets, queue items).  Everything one workgroup writes for another inside a
-// launch -- chunk partials, the LMState, queue items -- is written with device-scope (sc1, write-through) stores and read
-// with device-scope loads, which the non-coherent cache levels do not serve from stale lines.  What the producer still
-// owes is that those stores have been PERFORMED before the device-scope atomic that announces them: s_waitcnt vmcnt(0)
-// between the two (a workgroup-scope fence alone emits no wait, and the announcing atomic could overtake the stores).
-// The textbook form, an agent-scope release fence, emits the same wait plus an L2 write-back (buffer_wbl2 sc1) that has
-// nothing to write back here and costs a factor of three on the work-queue kernel (measured on MI355X, 256 dense frames:
-// 10.9-11.8 k frames/s with agent-scope release / release+acquire fences against 32.7-33.1 k with this form); an
-// agent-scope acquire on the consumer side would invalidate the L2 under the streaming evaluations for the same reason.
-__device__ __forceinline__ void xwg_release() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // compiler + LDS ordering
-  __builtin_amdgcn_s_waitcnt(0);                         // vmcnt(0): the written-through stores have been acknowledged
-}
-__device__ __forceinline__ void xwg_acquire() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // later (device-scope) loads are not moved above the announcement
-}
-__device__ __forceinline__ void store_partial(float *p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ fvec4 load_partial4(const float *p) {
-  const unsigned long long a = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  fvec4 v;
-  v.x = __uint_as_float((unsigned)a), v.y = __uint_as_float((unsigned)(a >> 32));
-  v.z = __uint_as_float((unsigned)b), v.w = __uint_as_float((unsigned)(b >> 32));
-  return v;
-}
 
 // One chunk of one evaluation by 256 threads (tid = 0..255 inside the chunk's thread group):
 // the per-point loop, the flow-indicator pass and the fixed-order reduction into the chunk's 52-slot
@@ -755,6 +723,9 @@ __device__ __forceinline__ void begin_level(const TrackerDev &T, LMState &S, int
   make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
 }
 
+// iteration bound of a level: maxIterations[lvl] (:463,:505 / :862,:897), or the benchmark schedule's K (dsm_params.fixed_schedule)
+__device__ __forceinline__ int level_max_it(const ParamsDev &p, int lvl) { return p.fixed_schedule > 0 ? p.fixed_schedule : p.max_iterations[lvl]; }
+
 // Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
 __device__ __forceinline__ void build_rs(const double *sums, const long long *isums, double rs[6]) {
   const float E = (float)sums[kSlotE];
@@ -1019,7 +990,7 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, fl
   }
   // Is this the loop's last evaluation?  The step that consumes it ends the level when the increment is small (:588) or the
   // iteration bound is reached (:505) -- both known now; the speculative proposal is consumed one iteration later.
-  const bool last = !(sqrt(nrm) > 1e-3) || S.iteration + (spec ? 2 : 1) >= T.p.max_iterations[S.lvl];
+  const bool last = (T.p.fixed_schedule <= 0 && !(sqrt(nrm) > 1e-3)) || S.iteration + (spec ? 2 : 1) >= level_max_it(T.p, S.lvl);
   make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0, spec, last);
 }
 
@@ -1042,7 +1013,7 @@ __device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, f
     S.scale_cand = cand;
     S.phase = PH_ITER;
   }
-  const bool last = !(inc > 1e-3) || S.iteration + (spec ? 2 : 1) >= T.p.max_iterations[S.lvl]; // :937 (signed, Q7) / :897
+  const bool last = (T.p.fixed_schedule <= 0 && !(inc > 1e-3)) || S.iteration + (spec ? 2 : 1) >= level_max_it(T.p, S.lvl); // :937 (signed, Q7) / :897
   make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, true, spec, last);
 }
 
@@ -1055,7 +1026,7 @@ __device__ __forceinline__ void end_level(const TrackerDev &T, LMState &S) {
     S.flow[0] = S.res_old[2]; // :597
     S.flow[1] = S.res_old[3];
     S.flow[2] = S.res_old[4];
-    if (S.last_residuals[lvl] > 1.5 * S.min_res[lvl]) { // :598
+    if (T.p.fixed_schedule <= 0 && S.last_residuals[lvl] > 1.5 * S.min_res[lvl]) { // :598
       S.status = ST_ABORTED;
       return;
     }
@@ -1203,7 +1174,8 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   const int n4 = (n_warped + 3) & ~3; // :824-835 padding counts in n (quirk Q3)
   const int r = lane >> 3, c = lane & 7;
   // ---- LM_OP_STEP: every lane of wave 0 evaluates the same (uniform) decisions; lane 0 writes ----
-  const int max_it = T.p.max_iterations[lvl];
+  const int max_it = level_max_it(T.p, lvl);
+  const bool fixed = T.p.fixed_schedule > 0; // benchmark schedule: every step is taken, nothing ends a level but the bound
   const float lim = T.p.lambda_extrapolation_limit;
   const int phase = S.phase;
   const bool had_spec = sp && S.spec_valid; // wave-uniform; read before lane 0 clears it
@@ -1215,7 +1187,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
     S.spec_valid = 0;
   }
   if (phase == PH_INIT) {
-    if (rs[5] > 0.6 && S.level_cutoff_repeat < 50) { // :477-485 / :875-883
+    if (!fixed && rs[5] > 0.6 && S.level_cutoff_repeat < 50) { // :477-485 / :875-883
       if (lane == 0) {
         S.evals[lvl]++;
         S.level_cutoff_repeat *= 2;
@@ -1244,8 +1216,8 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
     }
   } else {
     const double old_ratio = S.res_old[0] / S.res_old[1];
-    const bool accept = (rs[0] / rs[1]) < old_ratio; // :559 / :915
-    const bool small = pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // :588 / :937 (signed, Q7)
+    const bool accept = fixed || (rs[0] / rs[1]) < old_ratio; // :559 / :915
+    const bool small = !fixed && (pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3)); // :588 / :937 (signed, Q7)
     iteration = S.iteration + 1;
     {
       const float l_old = S.lambda;
@@ -1330,7 +1302,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   // the speculative proposal: what the loop proposes after rejecting the main one -- lambda four times larger (:583-585);
   // it exists only if the loop would go on after that rejection (one more iteration allowed; the main step not "too small")
-  const bool want_spec = sp && do_propose && iteration + 1 < max_it;
+  const bool want_spec = sp && do_propose && !fixed && iteration + 1 < max_it;
   if (sp && lane == 0) {
     float l4 = lambda_next * 4;
     if (l4 < lim) l4 = lim;
@@ -1436,10 +1408,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
                                                         const LMState *__restrict__ states,
                                                         float *__restrict__ partials,
                                                         int partial_stride, int lvl, int *__restrict__ tickets,
-                                                        int *__restrict__ status_out, int spec_nprob) {
+                                                        int *__restrict__ status_out, int spec_nprob, const int *__restrict__ rowmap) {
   // spec_nprob > 0: grid rows [spec_nprob, 2 spec_nprob) evaluate the problems' speculative candidates (where staged)
+  // rowmap != nullptr: a COMPACT launch -- grid row r works on problem rowmap[r] (the host lists the problems still at this
+  // level after a read-back: a launch over all problems of a batch costs ~1.6 ns per workgroup just to start and end the
+  // idle ones, 100 us for a level-0 grid of 512 problems; a level's last rounds are needed by a few stragglers only)
   const bool cand = spec_nprob > 0 && (int)blockIdx.y >= spec_nprob;
-  const int prob = cand ? blockIdx.y - spec_nprob : blockIdx.y;
+  const int row = cand ? blockIdx.y - spec_nprob : blockIdx.y;
+  const int prob = rowmap ? ((const DSM_GLOBAL int *)rowmap)[row] : row;
   // Uniform, read-only state: global address space so that it becomes scalar (s_load) reads -- and ALL of them are issued
   // before the first one is looked at: the head of the state and the evaluation inputs of this row's candidate arrive in
   // ONE memory round trip instead of a chain of three (state -> candidate -> inputs), which was a seventh of a mid-level
@@ -1517,41 +1493,41 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
 
 template <int MODE>
 static void launch_eval_ml(hipStream_t s, int lvl, dim3 grid, const TrackerDev *const *trackers, const LMState *states,
-                           float *partials, int partial_stride, int *tickets, int *status_out, int spec_nprob, bool split_ro) {
+                           float *partials, int partial_stride, int *tickets, int *status_out, int spec_nprob, bool split_ro, const int *rowmap) {
   if (tickets) { // fused LM step (never level 0: its kernel stays a pure evaluation)
     hipLaunchKernelGGL((eval_kernel<MODE, false, true>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
   } else if (lvl == 0 && split_ro) {
     hipLaunchKernelGGL((eval_kernel<MODE, true, false, 1>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
     hipLaunchKernelGGL((eval_kernel<MODE, true, false, 2>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
   } else if (lvl == 0)
     hipLaunchKernelGGL((eval_kernel<MODE, true, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
   else if (split_ro) {
     hipLaunchKernelGGL((eval_kernel<MODE, false, false, 1>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
     hipLaunchKernelGGL((eval_kernel<MODE, false, false, 2>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
   } else
     hipLaunchKernelGGL((eval_kernel<MODE, false, false>), grid, dim3(kThreads), 0, s, trackers, states, partials,
-                       partial_stride, lvl, tickets, status_out, spec_nprob);
+                       partial_stride, lvl, tickets, status_out, spec_nprob, rowmap);
 }
 
 // tickets != nullptr (levels >= 1 only): the kernel also performs the LM step (no lm_kernel launch needed)
 void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
                  const TrackerDev *const *trackers, const LMState *states, float *partials,
-                 int partial_stride, int *tickets, int *status_out, bool spec, bool split_ro) {
+                 int partial_stride, int *tickets, int *status_out, bool spec, bool split_ro, const int *rowmap) {
   dim3 grid(grid_x, spec ? 2 * nprob : nprob);
   const int spec_nprob = spec ? nprob : 0;
   if (lvl == 0) tickets = nullptr;
   if (mode == 0)
-    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
+    launch_eval_ml<0>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro, rowmap);
   else if (mode == 2)
-    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
+    launch_eval_ml<2>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro, rowmap);
   else
-    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro);
+    launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro, rowmap);
 }
 
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
@@ -1560,8 +1536,8 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
                                                         const float *__restrict__ partials, int partial_stride,
                                                         const StartInfo *__restrict__ start,
                                                         SingleOut *__restrict__ single_out,
-                                                        int *__restrict__ status_out, int spec) {
-  const int prob = blockIdx.x;
+                                                        int *__restrict__ status_out, int spec, const int *__restrict__ rowmap) {
+  const int prob = rowmap ? rowmap[blockIdx.x] : blockIdx.x; // (compact launch: see eval_kernel)
   const bool pose_like = mode != 1; // 0: frame tracking, 2: loop-closure pose -- same 8-DoF LM; 1: stereo scale
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2003,9 +1979,9 @@ void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const Tracker
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,
                LMState *states, const float *partials, int partial_stride, const StartInfo *start,
-               SingleOut *single_out, int *status_out, bool spec) {
+               SingleOut *single_out, int *status_out, bool spec, const int *rowmap) {
   hipLaunchKernelGGL(lm_kernel, dim3(nprob), dim3(kLmThreads), 0, s, mode, op, lvl, trackers, states, partials,
-                     partial_stride, start, single_out, status_out, spec ? 1 : 0);
+                     partial_stride, start, single_out, status_out, spec ? 1 : 0, rowmap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2116,23 +2092,36 @@ __global__ void dip_import_kernel(int npx, const float *__restrict__ in3, float 
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npx; idx += gridDim.x * blockDim.x) I[idx] = in3[3 * idx];
 }
 // step 2: the caller's gradient channels must be what makeImages derives from channel 0 (they are not stored): count
-// the texels of the rows makeImages fills whose dx or dy differs bitwise
-__global__ void dip_verify_kernel(int w, int h, const float *__restrict__ in3, const float *__restrict__ I, int *__restrict__ bad) {
-  int mine = 0;
+// the texels of the rows makeImages fills whose dx or dy differs (bitwise, or by more than tol * max(1, |g|)) and keep the
+// first of them: bad = {count, smallest index}
+__global__ void dip_verify_kernel(int w, int h, const float *__restrict__ in3, const float *__restrict__ I, int *__restrict__ bad, float tol) {
+  int mine = 0, first = 0x7FFFFFFF;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < w * h; idx += gridDim.x * blockDim.x) {
     if (idx < w || idx >= w * (h - 1)) continue; // rows makeImages leaves untouched are never read by the tracker
     float dx, dy;
     dip_gradients(I, w, h, idx, dx, dy);
-    mine += (__float_as_uint(dx) != __float_as_uint(in3[3 * idx + 1])) || (__float_as_uint(dy) != __float_as_uint(in3[3 * idx + 2]));
+    const float gx = in3[3 * idx + 1], gy = in3[3 * idx + 2];
+    bool off;
+    if (tol > 0.0f)
+      off = !(__builtin_fabsf(gx - dx) <= tol * __builtin_fmaxf(1.0f, __builtin_fabsf(dx))) || !(__builtin_fabsf(gy - dy) <= tol * __builtin_fmaxf(1.0f, __builtin_fabsf(dy)));
+    else
+      off = (__float_as_uint(dx) != __float_as_uint(gx)) || (__float_as_uint(dy) != __float_as_uint(gy));
+    if (off) {
+      mine++;
+      if (idx < first) first = idx;
+    }
   }
-  if (mine) atomicAdd(bad, mine);
+  if (mine) {
+    atomicAdd(bad, mine);
+    atomicMin(bad + 1, first);
+  }
 }
 void launch_dip_export(hipStream_t s, int w, int h, const float *plane, float *out3) {
   hipLaunchKernelGGL(dip_export_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w, h, plane, out3);
 }
-void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad) {
+void launch_dip_import(hipStream_t s, int w, int h, const float *in3, float *plane, int *d_bad, float tol) {
   hipLaunchKernelGGL(dip_import_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w * h, in3, plane);
-  hipLaunchKernelGGL(dip_verify_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w, h, in3, plane, d_bad);
+  if (d_bad) hipLaunchKernelGGL(dip_verify_kernel, dim3(grid_for(w * h)), dim3(256), 0, s, w, h, in3, plane, d_bad, tol);
 }
 // descriptors of many trackers in one copy + one launch (after a batched hand-over every tracker's exposure changed)
 __global__ void desc_scatter_kernel(const TrackerDev *__restrict__ src, TrackerDev *const *__restrict__ dst) {

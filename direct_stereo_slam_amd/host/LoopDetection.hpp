@@ -35,6 +35,7 @@ class RingKeyIndex {
 public:
   RingKeyIndex(dsm_context *ctx, int ringkey_dim, const float *dummy_key = nullptr, int shard_rank = 0, int shard_count = 1)
       : dim_(ringkey_dim) {
+    if (dsm_abi_version() != DSM_ABI_VERSION) throw std::runtime_error("libdsm_hotpath: ABI version mismatch with this host's dsm_hotpath.h");
     loop_check(dsm_ringdb_create(ctx, ringkey_dim, kLoopMargin, kFlannNN, kRingkeyThres, dummy_key, 4096, shard_rank, shard_count, &db_),
                "dsm_ringdb_create");
   }

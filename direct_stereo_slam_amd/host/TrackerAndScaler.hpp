@@ -46,6 +46,12 @@ struct TemplateLists {
 inline void check(int rc, const char *what) {
   if (rc != DSM_OK) throw std::runtime_error(std::string(what) + ": " + dsm_last_error());
 }
+// the structures of dsm_hotpath.h this translation unit was compiled with must be the library's
+inline void check_abi() {
+  if (dsm_abi_version() != DSM_ABI_VERSION)
+    throw std::runtime_error("libdsm_hotpath implements ABI version " + std::to_string(dsm_abi_version()) + ", this host was built against " +
+                             std::to_string(DSM_ABI_VERSION));
+}
 
 class TrackerAndScaler {
 public:
@@ -54,6 +60,7 @@ public:
                    const float K1_fx_fy_cx_cy[4], const dsm_params *params = nullptr)
       : refFrameID(-1), lastRef(nullptr), lastRef_aff_g2l(0, 0), firstCoarseRMSE(-1), levels_(pyrLevelsUsed) {
     if (tfm_vec.size() != 16) throw std::invalid_argument("tfm_vec must hold 16 doubles");
+    check_abi();
     check(dsm_tracker_create(ctx, w, h, pyrLevelsUsed, tfm_vec.data(), K1_fx_fy_cx_cy, params, &t_), "dsm_tracker_create");
     lastFlowIndicators[0] = lastFlowIndicators[1] = lastFlowIndicators[2] = 1000;
   }
@@ -238,6 +245,7 @@ inline HypothesesResult trackHypotheses(dsm_context *ctx, TrackerAndScaler &trac
 class PoseEstimator {
 public:
   PoseEstimator(dsm_context *ctx, int w, int h, int pyrLevelsUsed, const dsm_params *params = nullptr) {
+    check_abi();
     check(dsm_pose_estimator_create(ctx, w, h, pyrLevelsUsed, params, &pe_), "dsm_pose_estimator_create");
   }
   ~PoseEstimator() { dsm_pose_estimator_destroy(pe_); }

@@ -111,6 +111,12 @@ class Context:
         check(self.L.dsm_diag_read_bandwidth(self.h, nbytes, iters, C.byref(g)))
         return g.value
 
+    def xwg_litmus(self, pairs=128, iters=80000):
+        """(hand-offs, stale words) of the cross-workgroup hand-off litmus (dsm_diag_xwg_litmus)"""
+        n, bad = C.c_longlong(), C.c_longlong()
+        check(self.L.dsm_diag_xwg_litmus(self.h, pairs, iters, C.byref(n), C.byref(bad)))
+        return n.value, bad.value
+
     def read_bandwidth_chunked(self, nbytes=1 << 30, chunk_bytes=112 * 1024, iters=10):
         """measurement aid: same, one contiguous chunk per workgroup (the eval kernels' access pattern)"""
         g = C.c_double()
@@ -268,6 +274,11 @@ class TrackerAndScaler:
     def upload_frame(self, slot, dIp, ab_exposure=1.0):
         dIp = [np.ascontiguousarray(a, np.float32) for a in dIp]
         check(self.L.dsm_tracker_upload_frame(self.h, slot, _ptr_array(dIp), ab_exposure))
+
+    def upload_intensity(self, slot, planes, ab_exposure=1.0):
+        """the intensity channel of every level alone (dsm_tracker_upload_intensity)"""
+        planes = [np.ascontiguousarray(a, np.float32) for a in planes]
+        check(self.L.dsm_tracker_upload_intensity(self.h, slot, _ptr_array(planes), ab_exposure))
 
     def upload_image(self, slot, image, ab_exposure=1.0):
         image = np.ascontiguousarray(image, np.float32)

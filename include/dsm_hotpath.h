@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 1
+#define DSM_ABI_VERSION 2 /* 2: dsm_params.struct_size / fixed_schedule / frame_check / frame_grad_tol, dsm_stats.evals_residual_only */
 #define DSM_MAX_LEVELS 6 /* DSO PYR_LEVELS; the reference tracker uses <= 5 (TrackerAndScaler.cpp:457,463) */
 
 typedef enum dsm_status {
@@ -55,6 +55,11 @@ typedef struct dsm_pose_estimator dsm_pose_estimator; /* loop-closure direct ali
  * written by dsm_params_default() are the upstream DSO defaults as used by the
  * reference's default `mode=1` (src/main.cpp:117-121). */
 typedef struct dsm_params {
+  size_t struct_size;                 /* sizeof(dsm_params) of the header the CALLER was built with (dsm_params_default sets
+                                         it); every entry point that takes parameters returns DSM_ERR_INVALID on a mismatch,
+                                         so a host built against another version of this header fails loudly instead of
+                                         handing over a shorter struct.  Hosts should also compare dsm_abi_version() with
+                                         DSM_ABI_VERSION once (the Python and C++ adaptors in this repository do). */
   float huber_th;                     /* setting_huberTH            (TrackerAndScaler.cpp:727,795)   9    */
   float coarse_cutoff_th;             /* setting_coarseCutoffTH     (TrackerAndScaler.cpp:476)       20   */
   float scale_xi_rot;                 /* SCALE_XI_ROT               (TrackerAndScaler.cpp:542,685)   1    */
@@ -84,7 +89,7 @@ typedef struct dsm_params {
                                          items from a device-side queue; the workgroup completing an evaluation performs
                                          the LM step and enqueues the problem's next evaluation, so problems advance
                                          independently instead of in lock-step launches: 0 never, 1 (default) for batches
-                                         of at least 32 problems with at most 32768 finest-level chunks in all (beyond
+                                         of at least 32 problems with at most 24576 finest-level chunks in all (beyond
                                          that the lock-step launches are faster), 2 always.  Scheduling only -- results
                                          are bit-identical. */
   int speculate;                      /* launch-per-step form: next to the LM proposal being evaluated, the proposal that
@@ -96,6 +101,23 @@ typedef struct dsm_params {
                                          8192 template points whose launches evaluate at most a million points per stream
                                          group (where launches are latency-bound and rejections come in runs),
                                          2 on every level.  Scheduling only -- results are bit-identical. */
+  int compact_tail;                   /* launch-per-step form, batches: 1 (default) after the rounds most problems of a level
+                                         need (learnt from previous calls) the host reads the level's status back ONCE and
+                                         runs the remaining rounds -- needed by a few stragglers -- as compact launches over
+                                         those problems only, and every later pass over the problems still running; 0 every
+                                         launch covers every problem (idle workgroups cost ~1.6 ns each: 100 us for a level-0
+                                         launch over 512 problems).  Scheduling only -- results are bit-identical. */
+  int fixed_schedule;                 /* K > 0: BENCHMARK schedule of SURVEY.md section 8d -- every level runs exactly one
+                                         initial evaluation + K LM iterations whose steps are ALL taken (no accept test, no
+                                         cut-off repeat, no small-step break, no abort), so that the evaluations and bytes
+                                         per frame do not depend on the input.  Not the reference's algorithm: 0 (default)
+                                         runs trackNewestCoarse / optimizeScale as written. */
+  int frame_check;                    /* dsm_tracker_upload_frame: 1 (default) verify that the caller's gradient channels
+                                         are makeImages' central differences of channel 0 (the device stores channel 0 only);
+                                         0 trust the caller (channels 1, 2 are ignored) */
+  float frame_grad_tol;               /* with frame_check = 1: 0 (default) bitwise equality; t > 0 accepts
+                                         |g - g'| <= t * max(1, |g'|) per texel and channel (a host whose makeImages was built
+                                         with other floating-point flags) */
 } dsm_params;
 
 /* Statistics of the last track / optimize_scale (batch) call on a context. */
@@ -142,6 +164,11 @@ int dsm_diag_read_bandwidth(dsm_context *ctx, size_t bytes, int iters, double *g
 /* same, but each workgroup streams its own contiguous chunk of `chunk_bytes` (the access pattern of the
  * evaluation kernels) instead of all workgroups advancing through memory side by side */
 int dsm_diag_read_bandwidth_chunked(dsm_context *ctx, size_t bytes, size_t chunk_bytes, int iters, double *gbps_out);
+/* test aid: message-passing litmus of the hand-off protocol the kernels use between workgroups (device-scope stores,
+ * drained store queue, ticket; device-scope loads on the other side): `pairs` producer / consumer workgroup pairs on
+ * different XCDs exchange `iters` 256-byte blocks each under uneven load; *stale_words_out = words read that were not the
+ * announced hand-off's (must be 0). */
+int dsm_diag_xwg_litmus(dsm_context *ctx, int pairs, int iters, long long *handoffs_out, long long *stale_words_out);
 
 /* ---- TrackerAndScaler ---------------------------------------------------------------- */
 /* replaces TrackerAndScaler::TrackerAndScaler(w,h,tfm_vec,K1)  (TrackerAndScaler.cpp:47-109).
@@ -183,9 +210,13 @@ enum { DSM_SLOT_NEW_LEFT = 0, DSM_SLOT_NEW_RIGHT = 1 };
  * and forms the gradients where they are interpolated, from the neighbouring intensities, exactly as
  * FrameHessian::makeImages (upstream DSO) defines them -- dx = 0.5 (I[idx+1] - I[idx-1]), dy = 0.5 (I[idx+w] - I[idx-w]),
  * zero where not finite -- which is the only way the reference ever fills channels 1 and 2.  The call verifies that
- * (bitwise, rows 1 .. h_l-2; makeImages leaves the first and last row unset and the tracker never reads them) and
- * returns DSM_ERR_INVALID for texels that were built any other way. */
+ * (rows 1 .. h_l-2; makeImages leaves the first and last row unset and the tracker never reads them; bitwise, or to
+ * dsm_params.frame_grad_tol) and returns DSM_ERR_INVALID -- naming the first offending level and texel -- for texels that
+ * were built any other way; dsm_params.frame_check = 0 skips the check. */
 int dsm_tracker_upload_frame(dsm_tracker *t, int slot, const float *const *dIp, float ab_exposure);
+/* the same hand-over without the gradient channels: I[lvl] = the w_l*h_l intensities of level lvl (channel 0 of dIp[lvl]),
+ * 4 bytes per texel over the link instead of 12 and nothing to verify */
+int dsm_tracker_upload_intensity(dsm_tracker *t, int slot, const float *const *I, float ab_exposure);
 /* "next" row N1: build the pyramid on the device from the level-0 float image (upstream DSO FrameHessian::makeImages,
  * call sites FrontEnd.cpp:605,680): the intensity plane of every level; see dsm_tracker_upload_frame. */
 int dsm_tracker_upload_image(dsm_tracker *t, int slot, const float *image, float ab_exposure);
@@ -348,8 +379,11 @@ typedef int (*dsm_allreduce_min_u64_fn)(void *user, void *d_buf, size_t count, v
 typedef int (*dsm_allgather_u64_fn)(void *user, const void *d_send, void *d_recv, size_t count, void *hip_stream);
 int dsm_ringdb_merge_topk_with(dsm_ringdb *db, void *d_packed, int nq, int algo, int nranks,
                                dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather, void *user);
-/* attach (or, with NULL, detach) the communicator dsm_ringdb_query_then_enqueue uses on a sharded handle; borrowed:
- * destroy the database or detach before destroying the communicator */
+/* attach (or, with NULL, detach) the communicator dsm_ringdb_query_then_enqueue uses on a sharded handle.  Borrowed:
+ * dsm_comm_destroy detaches it from every database it is attached to (a later collective query on such a database fails
+ * with DSM_ERR_STATE); destroy communicators before their context.  A collective query starts with an agreement round
+ * (one all-reduce word per rank): if any rank cannot take part -- allocation failure, a different number of entries --
+ * EVERY rank returns an error and none enters the merge rounds. */
 int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm);
 /* the same with a caller-supplied transport instead of an RCCL communicator (allreduce_min NULL detaches) */
 int dsm_ringdb_attach_transport(dsm_ringdb *db, int nranks, dsm_allreduce_min_u64_fn allreduce_min, dsm_allgather_u64_fn allgather,

@@ -37,6 +37,7 @@ void orc_params_default(orc_params *p) {
   p->lambda_extrapolation_limit = 0.001f; /* TrackerAndScaler.cpp:464,863 */
   const int it[ORC_MAX_LEVELS] = {10, 20, 50, 50, 50, 50}; /* :463,:862 ([5] is an extension) */
   memcpy(p->max_iterations, it, sizeof it);
+  p->fixed_schedule = 0;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -679,6 +680,7 @@ int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsestL
   memset(t->res_evals, 0, sizeof t->res_evals);
   memset(t->gs_evals, 0, sizeof t->gs_evals);
   const int *maxIterations = t->p.max_iterations;
+  const int fixed = t->p.fixed_schedule > 0 ? t->p.fixed_schedule : 0; /* benchmark schedule (orc_params), not the reference */
   const float lambdaExtrapolationLimit = t->p.lambda_extrapolation_limit;
   const float cutoff0 = t->p.coarse_cutoff_th;
   double cur[7], aff_cur[2];
@@ -693,14 +695,14 @@ int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsestL
     double H[64], b[8], resOld[6];
     float levelCutoffRepeat = 1;
     orc_calc_res_pose(t, lvl, cur, aff_cur, cutoff0 * levelCutoffRepeat, resOld); /* :475 */
-    while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {                            /* :477-485 */
+    while (!fixed && resOld[5] > 0.6 && levelCutoffRepeat < 50) {                  /* :477-485 */
       levelCutoffRepeat *= 2;
       orc_calc_res_pose(t, lvl, cur, aff_cur, cutoff0 * levelCutoffRepeat, resOld);
     }
     orc_calc_gs_pose(t, lvl, cur, aff_cur, H, b); /* :487 */
     float lambda = 0.01;
 
-    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+    for (int iteration = 0; iteration < (fixed ? fixed : maxIterations[lvl]); iteration++) {
       double Hl[64], inc[8], nb[8];
       memcpy(Hl, H, sizeof Hl);
       for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda); /* :506-508 */
@@ -759,7 +761,7 @@ int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsestL
 
       double resNew[6];
       orc_calc_res_pose(t, lvl, newp, aff_new, cutoff0 * levelCutoffRepeat, resNew); /* :556 */
-      const int accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);           /* :559 */
+      const int accept = fixed || (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);  /* :559 */
       if (accept) { /* :576-586 */
         orc_calc_gs_pose(t, lvl, newp, aff_new, H, b);
         memcpy(resOld, resNew, sizeof resOld);
@@ -773,13 +775,13 @@ int orc_track(orc_tracker *t, double pose_io[7], double aff_io[2], int coarsestL
       double nrm = 0;
       for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
       nrm = sqrt(nrm);
-      if (!(nrm > 1e-3)) break; /* :588 */
+      if (!fixed && !(nrm > 1e-3)) break; /* :588 */
     }
     lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1])); /* :596 */
     flow_out[0] = resOld[2];                                     /* :597 */
     flow_out[1] = resOld[3];
     flow_out[2] = resOld[4];
-    if (minResForAbort && lastResiduals[lvl] > 1.5 * minResForAbort[lvl]) return 0; /* :598 (NULL = all NaN) */
+    if (!fixed && minResForAbort && lastResiduals[lvl] > 1.5 * minResForAbort[lvl]) return 0; /* :598 (NULL = all NaN) */
     if (levelCutoffRepeat > 1 && !haveRepeated) {                 /* :601-604 */
       lvl++;
       haveRepeated = 1;
@@ -950,6 +952,7 @@ float orc_optimize_scale(orc_tracker *t, float *scale_io, int coarsestLvl) {
   const int *maxIterations = t->p.max_iterations;
   const float lambdaExtrapolationLimit = t->p.lambda_extrapolation_limit;
   const float cutoff0 = t->p.coarse_cutoff_th;
+  const int fixed = t->p.fixed_schedule > 0 ? t->p.fixed_schedule : 0; /* benchmark schedule (orc_params), not the reference */
   float scale_current = *scale_io;
   int haveRepeated = 0;
   for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
@@ -957,13 +960,13 @@ float orc_optimize_scale(orc_tracker *t, float *scale_io, int coarsestLvl) {
     float levelCutoffRepeat = 1;
     double resOld[6];
     orc_calc_res_scale(t, lvl, scale_current, cutoff0 * levelCutoffRepeat, resOld);
-    while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+    while (!fixed && resOld[5] > 0.6 && levelCutoffRepeat < 50) {
       levelCutoffRepeat *= 2;
       orc_calc_res_scale(t, lvl, scale_current, cutoff0 * levelCutoffRepeat, resOld);
     }
     orc_calc_gs_scale(t, lvl, scale_current, &H, &b);
     float lambda = 0.01;
-    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+    for (int iteration = 0; iteration < (fixed ? fixed : maxIterations[lvl]); iteration++) {
       float Hl = H;
       Hl *= (1 + lambda);
       float inc = -b / Hl;
@@ -974,7 +977,7 @@ float orc_optimize_scale(orc_tracker *t, float *scale_io, int coarsestLvl) {
       const float scale_new = scale_current + inc;
       double resNew[6];
       orc_calc_res_scale(t, lvl, scale_new, cutoff0 * levelCutoffRepeat, resNew);
-      const int accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      const int accept = fixed || (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
       if (accept) {
         orc_calc_gs_scale(t, lvl, scale_new, &H, &b);
         memcpy(resOld, resNew, sizeof resOld);
@@ -984,7 +987,7 @@ float orc_optimize_scale(orc_tracker *t, float *scale_io, int coarsestLvl) {
         lambda *= 4;
         if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
       }
-      if (!(inc > 1e-3)) break; /* :937, signed (quirk Q7) */
+      if (!fixed && !(inc > 1e-3)) break; /* :937, signed (quirk Q7) */
     }
     last_residuals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
     if (levelCutoffRepeat > 1 && !haveRepeated) {

@@ -29,6 +29,8 @@ typedef struct orc_params {
   float affine_opt_mode_a, affine_opt_mode_b;
   float lambda_extrapolation_limit;
   int max_iterations[ORC_MAX_LEVELS];
+  int fixed_schedule; /* K > 0: the BENCHMARK schedule of SURVEY.md section 8d (1 + K evaluations per level, every step taken:
+                         no accept test, cut-off repeat, small-step break or abort) -- not the reference's algorithm; 0 = as written */
 } orc_params;
 
 typedef struct orc_tracker orc_tracker;

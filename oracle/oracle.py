@@ -29,6 +29,7 @@ class Params(C.Structure):
         ("affine_opt_mode_b", C.c_float),
         ("lambda_extrapolation_limit", C.c_float),
         ("max_iterations", C.c_int * MAX_LEVELS),
+        ("fixed_schedule", C.c_int),
     ]
 
 

@@ -4,7 +4,7 @@ build).  The reference itself has no tests, golden vectors or buildable sources 
 (SURVEY.md sections 4 and 8c), so these vectors pin the ORACLE (against accidental change) and the
 HIP path (against the oracle) -- they are not outputs of the reference binary.
 
-    python tests/golden/make_golden.py        # rewrites tracker_tiny.npz and ringkey_500.npz
+    python tests/golden/make_golden.py        # rewrites every *.npz of this directory
 
 Inputs are seeded synthetic scenes (direct_stereo_slam_amd/synth.py); every array needed to replay
 the case is stored next to the expected outputs, so the tests do not depend on numpy's RNG stream.
@@ -88,7 +88,70 @@ def ringkey_fixture():
                         knn_idx=idx, knn_dist=dist)
 
 
+def tracker_small_fixture():
+    """the 308x92 pair of SURVEY.md section 8c (three levels): inputs (raw images; the pyramids are makeImages of them),
+    dense template, expected track, the scale results of the front end's guess list (FrontEnd.cpp:995-1003) and of the
+    fixed benchmark schedule"""
+    sc = make_scene("small", seed=2025)
+    orc = oracle_tracker(sc)
+    out = {"w": sc.w, "h": sc.h, "nl": sc.nl, "K": np.asarray(sc.K, np.float64), "T": sc.T, "gt_pose": sc.gt_pose,
+           "ref_img": sc.ref_img, "new_img": sc.new_img, "right_img": sc.right_img}
+    for l in range(sc.nl):
+        for name, arr in zip(("u", "v", "id", "c"), sc.tpl):
+            out[f"tpl_{name}{l}"] = arr[l]
+    good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    out["track_good"], out["track_pose"], out["track_aff"], out["track_last"], out["track_flow"] = good, pose, aff, last, flow
+    out["track_evals"] = np.array(orc.eval_counts()[0])
+    guesses = np.array([0.1, 1, 5, 10, 15, 25, 30, 50], np.float32)  # FrontEnd.cpp:995 scale_guess
+    res, sev = [], []
+    for g in guesses:
+        res.append(orc.optimize_scale(float(g), sc.nl - 1))
+        sev.append(orc.eval_counts()[0])
+    out["scale_guesses"] = guesses
+    out["scale_evals"] = np.array(sev)
+    out["scale_err"] = np.array([r[0] for r in res], np.float32)
+    out["scale_out"] = np.array([r[1] for r in res], np.float32)
+    op = O.default_params()
+    op.fixed_schedule = 3
+    orc3 = oracle_tracker(sc, op)
+    g3, p3, a3, l3, _ = orc3.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    out["fixed3_pose"], out["fixed3_aff"], out["fixed3_last"] = p3, a3, l3
+    np.savez_compressed(os.path.join(HERE, "tracker_small.npz"), **out)
+
+
+def pose_estimator_fixture():
+    """PoseEstimator::estimate (PoseEstimator.cpp:84-506) on 1500 loop-closure points of a 308x92 keyframe pair"""
+    from test_pose_estimator import gt_matrix, loop_inputs
+
+    sc = make_scene("small", seed=2026, a=0.01, b=2.0)
+    xyz, cols = loop_inputs(sc, n=1500, seed=3)
+    pe = O.OraclePoseEstimator(sc.w, sc.h, sc.nl)
+    out = {"w": sc.w, "h": sc.h, "nl": sc.nl, "K": np.asarray(sc.K, np.float64), "new_img": sc.new_img, "xyz": xyz, "gt": gt_matrix(sc)}
+    for l in range(sc.nl):
+        out[f"col{l}"] = cols[l]
+    for tag, guess in (("eye", np.eye(4)), ("far", np.array([[1, 0, 0, 3.0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]))):
+        ok, T, err, inl = pe.estimate(xyz, cols, 1.0, sc.new_p, 1.0, sc.K, sc.nl - 1, guess)
+        out[f"{tag}_guess"], out[f"{tag}_ok"], out[f"{tag}_T"], out[f"{tag}_err"], out[f"{tag}_inl"] = guess, ok, T, np.float32(err), inl
+    np.savez_compressed(os.path.join(HERE, "pose_estimator_small.npz"), **out)
+
+
+def loop_descriptor_fixture():
+    """generate_spherical_points (generate_spherical_points.h:27-85) + ScanContext::generate (ScanContext.cpp:19-141) of one
+    keyframe job: the selected points, ring key, sparse signature and PCA transform (numpy / scipy oracle)"""
+    from oracle import scancontext as SC
+    from test_device_loopdet import make_job
+
+    kf_ids, poses, cur_cw, pt_kf, xyz = make_job(2027, n_kf=12, n_pts=3000)
+    keep, sel, pts = SC.generate_spherical_points(kf_ids, poses, cur_cw, 40.0, pt_kf, xyz)
+    rk, si, sv, tfm = SC.generate(pts, 40.0)
+    np.savez_compressed(os.path.join(HERE, "loop_descriptor.npz"), kf_ids=kf_ids, poses=poses, cur_cw=cur_cw, pt_kf=pt_kf, xyz=xyz,
+                        lidar_range=40.0, kf_keep=keep, sel_idx=sel, pts_spherical=pts, ringkey=rk, sig_idx=si, sig_val=sv, tfm_pca_rig=tfm)
+
+
 if __name__ == "__main__":
     tracker_fixture()
     ringkey_fixture()
+    tracker_small_fixture()
+    pose_estimator_fixture()
+    loop_descriptor_fixture()
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])

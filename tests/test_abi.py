@@ -45,7 +45,11 @@ def test_no_cpu_fallback(built):
     from direct_stereo_slam_amd import _lib
 
     L = _lib.load()
-    assert L.dsm_abi_version() == 1
+    assert L.dsm_abi_version() == _lib.ABI_VERSION == 2
+    # the header's DSM_ABI_VERSION is what the library reports
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'dsm_hotpath.h')).read()
+    assert int(re.search(r'#define DSM_ABI_VERSION (\d+)', hdr).group(1)) == L.dsm_abi_version()
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu tests")
     h = C.c_void_p()
@@ -104,3 +108,58 @@ def test_host_side_sc_distance(built):
                            cn, 60, C.byref(ri), C.byref(rd)) == 0
     ds = [O.sc_distance(a[0], a[1], c[0], c[1], 60) for c in cand]
     assert ri.value == 10 + int(np.argmin(ds)) and rd.value == min(ds)
+
+
+def _disassemble_gfx950(tmp_path):
+    """{kernel symbol: [instruction lines]} of every gfx950 code object embedded in the library"""
+    import shutil
+
+    from direct_stereo_slam_amd import _lib
+
+    so = os.path.join(tmp_path, "lib.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    subprocess.run([objdump, "--offloading", so], capture_output=True, text=True, check=True, cwd=tmp_path)
+    funcs = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", os.path.join(tmp_path, f)], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+            elif cur is not None and line.strip() and not line.lstrip().startswith(("//", ";")):
+                cur.append(line.split("//")[0].strip())
+    return funcs
+
+
+def test_ticket_atomics_follow_a_drained_store_queue(built, tmp_path):
+    """The cross-workgroup hand-off (xwg_sync.hpp) is: device-scope stores, `s_waitcnt vmcnt(0)`, THEN the device-scope atomic
+    that announces them.  Nothing in the language pins that order but the inline-assembly wait, so the emitted ISA is
+    checked: in every kernel that hands data to another workgroup, no global atomic read-modify-write may be reached with
+    a vector store still in flight (store ... atomic without a vmcnt(0) wait between them, in program order)."""
+    funcs = _disassemble_gfx950(str(tmp_path))
+    kernels = {n: ins for n, ins in funcs.items()
+               if re.search(r"eval_kernelILi\dELb[01]ELb1E", n) or "queue_kernel" in n or "queue_seed_kernel" in n or "xwg_litmus_kernel" in n}
+    assert any("queue_kernelILi0" in n for n in kernels) and any("xwg_litmus" in n for n in kernels)
+    assert sum(1 for n in kernels if "eval_kernel" in n) >= 3  # the fused eval + LM kernels of the three modes
+    checked = 0
+    for name, ins in kernels.items():
+        pending, n_atomics = None, 0
+        for i, line in enumerate(ins):
+            op = line.split()[0]
+            # the payload of a hand-off is written with device-scope (sc1) stores; plain stores are private results
+            if op.startswith(("global_store", "flat_store", "buffer_store")) and " sc1" in line:
+                pending = (i, line)
+            elif op == "s_waitcnt" and re.search(r"vmcnt\(0\)", line):
+                pending = None
+            elif op in ("s_branch", "s_endpgm", "s_setpc_b64"):  # what follows is not reached by falling through
+                pending = None
+            elif op.startswith(("global_atomic", "flat_atomic")):
+                n_atomics += 1
+                assert pending is None, f"{name}: `{line}` (instruction {i}) can overtake `{pending[1]}` (instruction {pending[0]}): no s_waitcnt vmcnt(0) between them"
+        assert n_atomics >= 1, name
+        checked += n_atomics
+    assert checked >= 12

@@ -22,7 +22,9 @@ def test_metric_is_baseline_jsons_and_defaults_are_the_contracts(monkeypatch):
     assert m.baseline_metric() == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = m.parse()
-    assert a.gpus == 1 and a.steps >= 1 and a.warmup >= 1 and not a.with_upload and a.queue == 0
+    assert a.gpus == 1 and a.steps >= 1 and a.warmup >= 1 and not a.with_upload
+    # the default line runs what ships (dsm_params_default: no scheduling switch is overridden) on all-distinct frames
+    assert a.queue is None and a.coarse is None and a.fuse is None and a.speculate is None and a.scenes is None and a.fixed_schedule == 0
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "3"])
     a = m.parse()
     assert (a.gpus, a.steps, a.warmup) == (4, 7, 3)
@@ -74,6 +76,13 @@ def test_bench_line_carries_every_key_of_the_contract():
     assert c["kind"] == "port" and c["form"] == "sse-restatement" and c["cores"] == 1 and c["value"] > 0
     ate = c["ate_vs_cpu_ref"]
     assert ate["frames"] >= 2 and ate["good_flags_equal"] and 0.99 <= ate["ate_ratio_gpu_over_cpu"] <= 1.01
+    # the three roofline fractions (contract bytes, residual-only evaluations priced at what they read, bytes the pins moved)
+    assert 0 < r["frac_full_evals"] <= r["frac"] and "frac_hbm_actual" in r and r["traffic_source"]
+    assert d["config"]["distinct_frames"] == 2 and d["config"]["work_queue"] == 1 and d["config"]["fixed_schedule"] == 0
+    # SURVEY.md 8d's fixed schedule as a second object: 1 + 3 evaluations per level on the GPU and on the CPU leg
+    fx = d["config"]["fixed_schedule_leg"]
+    assert all(abs(e - 4.0) < 1e-9 for e in fx["evals_per_frame_by_level"]) and fx["value"] > 0 and fx["cpu_baseline"]["value"] > 0
+    assert "same fixed schedule" in fx["cpu_baseline"]["sample"]
     ac = c["all_cores"]
     assert ac["cores"] >= 2 and ac["value"] > 0 and ac["cpu_model"]
     assert d["value"] > 0 and abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

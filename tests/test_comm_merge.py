@@ -183,3 +183,103 @@ def test_sharded_search_ringkey_is_a_drop_in_for_the_unsharded_one(built, G):
         assert got[r] == want, f"rank {r}"
     ref_db.close()
     ctx0.close()
+
+
+def test_collective_query_fails_on_every_rank_when_one_rank_cannot_take_part(built):
+    """round 0 of a collective query is an agreement: a rank whose index differs (or whose local scan failed) makes EVERY rank
+    return an error -- nobody is left waiting in the merge rounds"""
+    from direct_stereo_slam_amd._lib import DsmError
+
+    G = 3
+    keys = ring_keys(60, seed=3)
+    ex = HostExchange(G)
+    outcome, errs = [None] * G, []
+
+    def rank_main(r):
+        try:
+            ctx = Context(0)
+            db = RingKeyDB(ctx, margin=5, capacity=64, shard_rank=r, shard_count=G)
+            db.attach_transport(G, ex.allreduce_min(r))
+            db.add_points(keys[:40] if r != 1 else keys[:41])  # rank 1 holds one entry more
+            try:
+                db.search_ringkey(keys[50])
+                outcome[r] = "ok"
+            except DsmError as e:
+                outcome[r] = str(e)
+            db.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            ex.barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(G)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs and not any(t.is_alive() for t in ts), errs
+    assert all(o is not None and "different numbers of entries" in o for o in outcome), outcome
+
+
+def test_destroying_a_communicator_detaches_it(built, ctx):
+    from direct_stereo_slam_amd._lib import DsmError
+
+    db = RingKeyDB(ctx)
+    comm = Comm(ctx, Comm.unique_id(), 0, 1)
+    db.attach_comm(comm)
+    comm.close()  # the database outlives it: detached, not dangling
+    db.add_points(ring_keys(20, seed=2))
+    assert db.search_ringkey(np.zeros(20, np.float32)) == []  # one shard: no collective needed
+    db2 = RingKeyDB(ctx, shard_rank=0, shard_count=2)
+    with pytest.raises(DsmError, match="communicator"):
+        db2.search_ringkey(np.zeros(20, np.float32))
+    db.close()
+    db2.close()
+
+
+_TWO_RANKS = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from direct_stereo_slam_amd.ringdb import Comm, RingKeyDB
+from direct_stereo_slam_amd.tracker import Context
+from test_oracle_ringkey import ring_keys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo")  # plumbing only (the unique id); the merge itself runs on RCCL through the C ABI
+ctx = Context(rank)
+uid = [Comm.unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, 0)
+comm = Comm(ctx, uid[0], rank, world)
+keys = ring_keys(5000, seed=7)
+rng = np.random.default_rng(8)
+q = (keys[rng.integers(len(keys), size=40)] + rng.normal(0, 0.02, (40, 20))).astype(np.float32)
+q[-1] = 5.0
+full = RingKeyDB(ctx, capacity=len(keys) + 16); full.add_points(keys); want = full.knn_packed_host(q)
+db = RingKeyDB(ctx, capacity=len(keys) // world + 16, shard_rank=rank, shard_count=world); db.add_points(keys)
+for algo in ("allreduce_min", "allgather"):
+    local = torch.from_numpy(db.knn_packed_host(q)).cuda()
+    db.merge_topk_device(comm, local.data_ptr(), len(q), algo); ctx.sync()
+    assert np.array_equal(local.cpu().numpy(), want), (rank, algo)
+# search_ringkey as a collective over xGMI: the candidate lists of the unsharded index, query after query
+ref = RingKeyDB(ctx, margin=5, capacity=64); sh = RingKeyDB(ctx, margin=5, capacity=64, shard_rank=rank, shard_count=world)
+sh.attach_comm(comm)
+ks = ring_keys(120, seed=11); ks[40:60] = ks[:20] + np.float32(0.01)
+assert [sh.search_ringkey(k) for k in ks] == [ref.search_ringkey(k) for k in ks]
+dist.barrier()
+if rank == 0: print("RCCL-2-RANKS-OK")
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_rccl_merge_with_two_ranks_over_xgmi(built, tmp_path):
+    """the first multi-GPU box runs dsm_ringdb_merge_topk and the collective search_ringkey over real RCCL ranks"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(str(tmp_path), "two_ranks.py")
+    open(script, "w").write(_TWO_RANKS)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", script, root], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0 and "RCCL-2-RANKS-OK" in res.stdout, res.stderr[-3000:]

@@ -625,3 +625,78 @@ def test_scale_guess_list_as_one_batch_equals_the_sequential_loop(ctx):
         assert abs(s_g - new_scale) < 1e-4 * max(1.0, new_scale) and abs(err_g - scale_error) < 1e-3 * scale_error
         # (which guess wins is decided by the last bits when several guesses reach the same minimum -- here 5, 10 and 15 end at
         # the same scale with errors equal to 1e-6; the winner's scale and error are what FrontEnd uses)
+
+
+def test_fixed_schedule_runs_one_plus_k_evaluations_per_level_like_the_oracle(ctx):
+    """dsm_params.fixed_schedule (SURVEY.md 8d's benchmark schedule): exactly 1 + K evaluations per level, every step taken --
+    on the device and on the oracle alike, so the two end at the same pose / scale"""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene("medium", seed=77)
+    p, op = default_params(), O.default_params()
+    p.fixed_schedule = op.fixed_schedule = 3
+    orc, trk = oracle_tracker(sc, op), hip_tracker(ctx, sc, p)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    assert orc.eval_counts()[0][:sc.nl] == [4] * sc.nl
+    r = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    assert list(ctx.stats().evals)[:sc.nl] == [4] * sc.nl
+    assert r[0] == good_o
+    np.testing.assert_allclose(r[1], pose_o, atol=1e-4)
+    np.testing.assert_allclose(r[2], aff_o, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(r[3][:sc.nl], last_o[:sc.nl], rtol=1e-3)
+    err_o, s_o = orc.optimize_scale(1.2, sc.nl - 1)
+    assert orc.eval_counts()[0][:sc.nl] == [4] * sc.nl
+    err_g, s_g = trk.optimizeScale(1.2, sc.nl - 1)
+    assert list(ctx.stats().evals)[:sc.nl] == [4] * sc.nl
+    assert abs(s_g - s_o) < 1e-4 * abs(s_o) and abs(err_g - err_o) < 1e-3 * err_o
+    # ... whatever the scheduling form
+    for coarse, queue in ((9216, 0), (0, 2)):
+        p2 = default_params()
+        p2.fixed_schedule, p2.persistent_coarse, p2.work_queue = 3, coarse, queue
+        r2 = hip_tracker(ctx, sc, p2).trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        assert list(ctx.stats().evals)[:sc.nl] == [4] * sc.nl
+        for a, b in zip(r[1:], r2[1:]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_frame_hand_over_checks_and_the_intensity_only_form(ctx):
+    """dsm_tracker_upload_frame verifies the caller's gradient channels (the device keeps channel 0 only) and names the first
+    offending texel; dsm_params.frame_check / frame_grad_tol relax it; dsm_tracker_upload_intensity hands over channel 0 alone"""
+    from direct_stereo_slam_amd._lib import DsmError
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene("small", seed=5)
+    trk = hip_tracker(ctx, sc)
+    ref = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    # intensity planes alone: same frame on the device, same result
+    trk2 = hip_tracker(ctx, sc)
+    trk2.upload_intensity(0, [np.ascontiguousarray(l[..., 0]) for l in sc.new_p], 1.0)
+    for l in range(sc.nl):
+        np.testing.assert_array_equal(trk2.get_frame(0, l)[1:-1], sc.new_p[l][1:-1])
+    for a, b in zip(ref, trk2.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)):
+        np.testing.assert_array_equal(a, b)
+    # a gradient texel that is not makeImages': refused, with the level and the texel in the message
+    bad = [l.copy() for l in sc.new_p]
+    w1 = sc.w >> 1
+    bad[1][7, 11, 1] *= np.float32(1.0 + 3e-5)
+    with pytest.raises(DsmError, match=rf"level 1: 1 texel.*index {7 * w1 + 11} \(x = 11, y = 7\)"):
+        trk.upload_frame(0, bad, 1.0)
+    with pytest.raises(DsmError):  # the slot is unusable until a good frame arrives
+        trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+    # ... accepted to a tolerance, or unchecked: channel 0 is what is used either way
+    for check, tol in ((1, 1e-3), (0, 0.0)):
+        p = default_params()
+        p.frame_check, p.frame_grad_tol = check, tol
+        t3 = hip_tracker(ctx, sc, p)
+        t3.upload_frame(0, bad, 1.0)
+        for a, b in zip(ref, t3.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)):
+            np.testing.assert_array_equal(a, b)
+    p = default_params()
+    p.frame_grad_tol = 1e-6
+    with pytest.raises(DsmError, match="level 1"):
+        hip_tracker(ctx, sc, p).upload_frame(0, bad, 1.0)
+    # a parameter block of another header version is refused
+    p = default_params()
+    p.struct_size -= 4
+    with pytest.raises(DsmError, match="struct_size"):
+        hip_tracker(ctx, sc, p)

@@ -130,3 +130,94 @@ def test_track_and_scale_in_one_call_equals_the_two_calls(ctx):
         assert np.array_equal(c0[1], r[1]) and len(c0[5]) == 0
     finally:
         ctx.set_streams(1)
+
+
+def test_cross_xcd_hand_off_litmus(ctx):
+    """message passing through the kernels' hand-off primitives (device-scope stores, drained store queue, ticket; device-scope
+    loads): 10^7 hand-offs of 256-byte blocks between workgroups on different XCDs under uneven load, every word checked"""
+    n, stale = ctx.xwg_litmus(pairs=128, iters=80000)
+    assert n >= 10_000_000 and stale == 0
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from direct_stereo_slam_amd.tracker import Context
+from test_schedule_stress import _run
+from _scenes import make_scene
+ctx = Context(0)
+scs = [make_scene("small" if i % 2 else "medium", seed=200 + i, template="dense" if i % 3 else "sparse", n0=6000) for i in range(8)]
+ref = np.load(sys.argv[2], allow_pickle=True)["ref"]
+for it in range(3):
+    for fuse, ns, coarse, queue, spec in ((0, 1, 0, 0, 0), (2, 2, 0, 0, 0), (0, 1, 0, 2, 0), (1, 2, 0, 2, 2), (2, 2, 0, 0, 2)):
+        got = _run(ctx, scs, fuse, ns, coarse, queue, spec)
+        for g, r in zip(got, ref):
+            for a, b in zip(g, r):
+                assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), (it, fuse, ns, coarse, queue, spec)
+n, stale = ctx.xwg_litmus(pairs=64, iters=20000)
+assert stale == 0
+print("TEXTBOOK-OK", n)
+"""
+
+
+def test_textbook_fences_give_the_same_results(ctx, tmp_path):
+    """The hand-off of xwg_sync.hpp (workgroup fence + drained store queue) against the LLVM memory model's own form: a second
+    library built with -DDSM_TEXTBOOK_FENCES (agent-scope release / acquire fences) must produce bit-identical results in
+    the fused and work-queue forms -- the forms that hand data between workgroups inside a launch."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(str(tmp_path), "lib")
+    subprocess.run(["make", "-s", "-j", str(os.cpu_count() or 4), "-C", os.path.join(root, "direct_stereo_slam_amd", "csrc"), f"OUT={out}",
+                    "EXTRA=-DDSM_TEXTBOOK_FENCES"], check=True, timeout=1200)
+    scs = [make_scene("small" if i % 2 else "medium", seed=200 + i, template="dense" if i % 3 else "sparse", n0=6000) for i in range(8)]
+    try:
+        ref = _run(ctx, scs, 0, 1, 0)
+    finally:
+        ctx.set_streams(1)
+    arr = np.empty(len(ref), dtype=object)
+    for i, r in enumerate(ref):
+        arr[i] = [np.asarray(x) for x in r]
+    np.savez(os.path.join(str(tmp_path), "ref.npz"), ref=arr)
+    env = dict(os.environ, DSM_HOTPATH_LIB=os.path.join(out, "libdsm_hotpath.so"), PYTHONPATH=root)
+    res = subprocess.run([sys.executable, "-c", _CHILD, os.path.dirname(os.path.abspath(__file__)), os.path.join(str(tmp_path), "ref.npz")],
+                         capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert res.returncode == 0 and "TEXTBOOK-OK" in res.stdout, res.stderr[-3000:]
+
+
+def test_compact_straggler_launches_are_bit_identical(ctx):
+    """dsm_params.compact_tail: after the rounds most problems of a level need, the level's status is read back once and the
+    remaining rounds run as compact launches over the stragglers; later passes cover the running problems only.  Same
+    evaluations, same steps: bit-identical results, in every combination with the other scheduling switches."""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    scs = [make_scene("small", seed=400 + i, template="dense" if i % 4 else "sparse", n0=5000, motion_scale=3.0 if i % 5 == 0 else 1.0)
+           for i in range(48)]
+    poses0 = np.tile(S.IDENTITY_POSE, (len(scs), 1))
+    results, polls = {}, {}
+    try:
+        for compact, ns, fuse, spec in ((0, 1, 0, 0), (1, 1, 0, 0), (1, 2, 1, 1), (0, 2, 1, 1), (1, 3, 2, 2)):
+            p = default_params()
+            p.compact_tail, p.fuse_lm, p.speculate, p.work_queue = compact, fuse, spec, 0
+            ctx.set_streams(ns)
+            trks = [hip_tracker(ctx, sc, p) for sc in scs]
+            out = None
+            for rep in range(3):  # the schedule learns from call to call: the compact form sets in at the second
+                r = ctx.track_batch(trks, poses0.copy(), np.zeros((len(scs), 2)), scs[0].nl - 1)
+                pl = ctx.stats().polls
+                e = ctx.optimize_scale_batch(trks[::3], np.full(len(trks[::3]), 1.2), scs[0].nl - 1)
+                cur = tuple(np.asarray(x) for x in tuple(r) + tuple(e))
+                if out is not None:
+                    for a, b in zip(out, cur):
+                        assert np.array_equal(a, b, equal_nan=True), ("call-to-call", compact, ns, fuse, spec, rep)
+                out = cur
+            results[(compact, ns, fuse, spec)], polls[(compact, ns, fuse, spec)] = out, pl
+    finally:
+        ctx.set_streams(1)
+    ref = results[(0, 1, 0, 0)]
+    for key, got in results.items():
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True), key
+    assert polls[(1, 1, 0, 0)] > polls[(0, 1, 0, 0)]  # the per-level read-backs really happened

@@ -11,7 +11,7 @@ for rep in 1 2; do
     for l in "${libs[@]}"; do
       cp "$l" "$LIB"
       printf "%-18s %-50s " "$(basename $l)" "$a"
-      timeout 600 python "$R/bench.py" --no-cpu --no-second-leg $a 2>&1 | tail -1 | python -c "
+      timeout 600 python "$R/bench.py" --no-cpu --no-second-leg --no-fixed-leg $a 2>&1 | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 for rep in 1 2; do
   for a in "$@"; do
     printf "%-40s " "$a"
-    timeout 600 python "$R/bench.py" --no-cpu --no-second-leg $a 2>&1 | tail -1 | python -c "
+    timeout 600 python "$R/bench.py" --no-cpu --no-second-leg --no-fixed-leg $a 2>&1 | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']

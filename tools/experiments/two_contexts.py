@@ -28,12 +28,15 @@ steps = args.steps
 
 def run(nctx, offset_ms):
     args.batch = B // nctx
+    args.scenes = B  # the same B distinct frames, dealt out to the contexts
     ctxs, wls = [], []
     for c in range(nctx):
         ctx = Context(0)
         ctx.set_streams(args.streams)
         ctxs.append(ctx)
+        bench._FRAME_OFFSET = c * (B // nctx)
         wls.append(bench.build_workload(args, ctx, args.config))
+    bench._FRAME_OFFSET = 0
     kf = list(range(0, args.batch, args.kf_every))
     for c in range(nctx):
         for _ in range(2):
@@ -59,6 +62,6 @@ def run(nctx, offset_ms):
     return B * steps / dt, 1e3 * dt / steps
 
 
-for nctx, o in ((1, 0.0), (2, 0.0), (2, off), (2, 2 * off), (1, 0.0), (2, off)):
+for nctx, o in ((1, 0.0), (2, 0.0), (2, off), (4, off / 2), (1, 0.0), (2, off), (4, off / 2)):
     v, ms = run(nctx, o)
     print(f"contexts {nctx} x {B // nctx} frames, offset {o:4.1f} ms: {v:9.0f} frames/s  {ms:7.3f} ms per step of {B} frames", flush=True)

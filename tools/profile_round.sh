@@ -2,7 +2,7 @@
 # Regenerates the evidence under profiles/ on a GPU box:  bash tools/profile_round.sh rNN
 # (run through gpurun; raw outputs land in gpurun_out/<tag>/, summaries are written by tools/summarize_profiles.py)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,24 +11,24 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $OUT/bench_default.log 2>&1
 tail -1 $OUT/bench_default.log > $OUT/bench_default.json
 # 2. per-kernel statistics of the same command (no CPU leg, no second leg: they only add host time / other kernels)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu --no-second-leg > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg > $OUT/trace.log 2>&1
 # 3. HBM traffic counters, one pass each (never combined with other trace domains)
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu --no-second-leg --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu --no-second-leg --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --steps 2 --warmup 1 > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
 # 4. read-bandwidth ceilings, the single-frame latency line, the other workloads and forms
 timeout 300 python $R/bench.py --membw > $OUT/membw.log 2>&1
-timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-second-leg > $OUT/bench_b1.log 2>&1
-timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-second-leg --config S1 > $OUT/bench_b1_S1.log 2>&1
+timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-second-leg --no-fixed-leg > $OUT/bench_b1.log 2>&1
+timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-second-leg --no-fixed-leg --config S1 > $OUT/bench_b1_S1.log 2>&1
 timeout 300 python $R/bench.py --ringkey --no-cpu --rk-q 1 --rk-n 10000000 --steps 50 > $OUT/bench_ringkey_q1.log 2>&1
 timeout 300 python $R/bench.py --ringkey --no-cpu > $OUT/bench_ringkey.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --config S3 --batch 256 > $OUT/bench_cfg_S3.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --template sparse > $OUT/bench_cfg_sparse.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --queue 2 > $OUT/bench_queue.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --queue 2 --batch 256 > $OUT/bench_queue_b256.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --batch 256 > $OUT/bench_b256.log 2>&1
-timeout 400 python $R/bench.py --no-cpu --no-second-leg --batch 1024 > $OUT/bench_b1024.log 2>&1
-timeout 400 python $R/bench.py --evals-only --kf-every 100000 --no-cpu --no-second-leg --streams 1 > $OUT/bench_evals_only.log 2>&1
-timeout 600 python $R/bench.py --no-cpu --no-second-leg --with-upload --u8 --pinned --overlap > $OUT/bench_with_upload_u8_pinned_overlap.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --config S3 --batch 256 > $OUT/bench_cfg_S3.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --template sparse > $OUT/bench_cfg_sparse.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --queue 2 > $OUT/bench_queue.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --queue 2 --batch 256 > $OUT/bench_queue_b256.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --batch 256 > $OUT/bench_b256.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --batch 1024 > $OUT/bench_b1024.log 2>&1
+timeout 400 python $R/bench.py --evals-only --kf-every 100000 --no-cpu --no-second-leg --no-fixed-leg --streams 1 > $OUT/bench_evals_only.log 2>&1
+timeout 600 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --with-upload --u8 --pinned --overlap > $OUT/bench_with_upload_u8_pinned_overlap.log 2>&1
 # summaries go to gpurun_out/<tag>_profiles/ (gpurun merges only gpurun_out/ back, at most 64 MiB: the raw traces are dropped);
 # copy them into profiles/ afterwards:  cp gpurun_out/<tag>_profiles/* profiles/
 python $R/tools/summarize_profiles.py $OUT $TAG $R/gpurun_out/${TAG}_profiles > $OUT/summary.log 2>&1

@@ -2,6 +2,7 @@
 """Condenses the raw rocprofv3 / bench outputs of tools/profile_round.sh into the small tracked files
 under profiles/:  python tools/summarize_profiles.py gpurun_out/<tag> <tag>"""
 import csv
+import hashlib
 import glob
 import json
 import os
@@ -93,6 +94,15 @@ if trace:
     print("trace:", summary["achieved_GBps_from_trace"], "bench:", bench["roofline"]["achieved"])
 
 
+def kernel_source_sha():
+    """the same hash bench.kernel_source_sha() forms over the sources of the eval kernels"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for f in ("tracker_kernels.hip", "dsm_device.hpp", "dsm_kernels.hpp", "lm_math.hpp", "Makefile"):
+        hsh.update(open(os.path.join(root, "direct_stereo_slam_amd", "csrc", f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_sum(dirname, counter):
     files = newest(os.path.join(src, dirname, "*", "*counter_collection.csv"))
     if not files:
@@ -121,7 +131,8 @@ if fetch is not None:
     corrected = raw_fetch + 0.5 * n_evals * 16 * n0
     wr = (write or 0.0) * 1024.0
     out = {
-        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-second-leg --steps 2 --warmup 1",
+        "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --no-cpu --no-second-leg --no-fixed-leg --steps 2 --warmup 1",
+        "kernel_source_sha": kernel_source_sha(),  # bench.py refuses this file once the kernel sources change
         "config": pb["config"]["name"], "kernel": "dsm::" + L0 + ", *>", "dispatches": nf, "level0_pose_evals": n_evals, "algorithmic_bytes": alg,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md); half of 16*n0 per eval added back; the tap gathers of the 4-byte-per-texel intensity plane are taken as reported -- calibrated on known byte counts by tools/pmc_calibrate.sh (<tag>_pmc_calibration.json: template stream tallied at 0.50, tap stream at 0.95 of its unique bytes)",
