@@ -1129,9 +1129,10 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     // levels >= 1: the eval kernel's last-arriving workgroup per problem can perform the LM step itself (one launch per
     // round instead of two): for launches of few problems -- small batches (measured: -6 % latency for one frame in flight,
     // -11 % throughput at 256) and compact launches over a handful of stragglers.
-    // (Up to 8 rows: the fused kernel runs four workgroups per CU against five of the plain one and carries the LM step's LDS;
-    // measured on 45 level-1 stragglers: 59 us per fused round against ~37 for the pair.)
-    const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && rows <= 8));
+    // (Measured on 512 all-distinct S2 frames, same box: fused compact rounds 39.7-40.2 k frames/s, pairs above 8 rows
+    // 38.6-38.8 k, the speculative candidate on every level of the compact rounds 38.9 k: the pair's second launch and the
+    // doubled rows cost what they save.)
+    const bool fused = L > 0 && (P.fuse_lm >= 2 || (P.fuse_lm == 1 && (np <= 8 || sg.rows >= 0)));
     // Large levels: the residual-only evaluations (the level's last ones, tracker_kernels.hip) get a launch of their own
     // behind the full ones -- an instantiation without the 45 accumulators, 30-41 VGPRs = eight waves per SIMD instead
     // of four or five.  Never in a level's first round (its evaluation is the level's first).  Measured (S2 dense, 512
