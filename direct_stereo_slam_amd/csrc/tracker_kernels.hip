@@ -768,19 +768,24 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
 //   1. the pivot order from ONE all-pairs comparison of the diagonal (lane (r,c) tests |d_c| > |d_r|; a row's rank is the
 //      population count of its byte of the ballot).  Exact ties and NaNs -- where Eigen's swaps, not the ranks, decide --
 //      take a literal, sequential restatement of the selection loop instead (wave-uniform rare branch);
-//   2. the symmetrically permuted lower triangle is read from the LDS copy of H (wave-uniform addresses, broadcast reads);
-//   3. the factorisation and the three substitution passes run fully unrolled on registers with static indices, every
-//      lane computing the same values: no cross-lane traffic, no pivot search, no divergence inside the chain;
+//   2. lane i reads row i of the symmetrically permuted lower triangle from the LDS copy of H;
+//   3. the factorisation and the substitution passes run fully unrolled with static register indices, one ROW per lane:
+//      the d_j A[k][j] products of a step are wave-uniform (lane reads), each lane forms the dot product over its own row
+//      -- the update of A(k,k) in lane k, of column k's entries in the lanes below -- and the column is divided by the pivot
+//      with ONE division per step; no pivot search and no divergence inside the chain; L^-T gets its columns through a
+//      64-word LDS transpose;
 //   4. the solution is un-permuted through eight LDS words.
-// About 2.8 k shader cycles against the 7.7 k of the cross-lane right-looking form it replaces (eight dependent rounds of
-// ballot -> lane read -> two ds_bpermute -> two IEEE divisions), and the same operations in the same order as the CPU checker:
-// given bitwise equal H and b the increments are bitwise equal.
+// Every element sees Eigen's operations in Eigen's order (the CPU checker restates the same sequence): given bitwise equal H
+// and b the increments are bitwise equal.  (The fully wave-uniform form of the same arithmetic -- every lane all 36 entries --
+// took 6.8-7.7 k shader cycles, issue-bound by its 36 IEEE double divisions; the cross-lane right-looking form of rounds
+// 1-2, another pivot order, 7.7 k.)
 // Rows / columns whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves): they are ordered last and
 // enter as zero rows, zero columns and a zero right-hand side, which leaves every operation on the active block unchanged
 // (x - 0 * y = x) and yields 0 for them.  stitch: row / column 6 of the system is row / column 7 of H (:521-534).
 struct LdltScratch {
   double x[8];
   double av[8];
+  double L[8][8]; // the factor, for its transpose
   int ix[8];
   int perm[8];
 };
@@ -836,73 +841,86 @@ __device__ __forceinline__ void wave_ldlt_solve8(const double *Hlds, const doubl
       for (int k = 0; k < 8; k++) perm[k] = __builtin_amdgcn_readfirstlane(scr.ix[k]);
     }
   }
-  // ---- 2. the permuted system: lower triangle of P A P^T (LDLT<Lower> reads the lower triangle of its input), P rhs ----
-  double A[8][8], y[8];
+  // ---- 2. the permuted system, ONE ROW PER LANE (row i = lane & 7, replicated in every group of eight lanes): lower
+  // triangle of P A P^T (LDLT<Lower> reads the lower triangle of its input), P rhs ----
+  const int i = lane & 7;
+  int pl = perm[0]; // this lane's unknown (logical index)
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int pi = src(perm[i]);
-    const bool ai = i < nact;
-    y[i] = ai ? -blds[pi] : 0.0;
+  for (int k = 1; k < 8; k++) pl = i == k ? perm[k] : pl;
+  const int pi = src(pl);
+  const bool act_i = i < nact;
+  double a[8]; // a[j] = A[i][j], j <= i
 #pragma unroll
-    for (int j = 0; j <= i; j++) {
-      const int pj = src(perm[j]);
-      const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-      double v = Hlds[8 * hi + lo];
-      if (i == j) v = v * lam1;
-      A[i][j] = ai ? v : 0.0; // (j <= i: j active whenever i is)
-    }
+  for (int j = 0; j < 8; j++) {
+    const int pj = src(perm[j]);
+    const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+    const double v = Hlds[8 * hi + lo];
+    const double vd = v * lam1;
+    a[j] = (act_i && j <= i) ? (i == j ? vd : v) : 0.0; // (j <= i: j active whenever i is)
   }
-  // ---- 3. factorisation (left-looking, no pivoting left to do) and substitutions, Eigen's operation order ----
+  double y = act_i ? -blds[pi] : 0.0;
+  // ---- 3. factorisation, left-looking (no pivoting left to do), Eigen's operation order.  At step k every lane forms
+  // s = sum_j A[i][j] temp[j] over ITS row -- the dot product of A(k,k)'s update in lane k, the A21 update in the lanes below
+  // -- from the wave-uniform temp[j] = d_j A[k][j] (lane reads); ONE division per step instead of 7 - k. ----
+  double du[8]; // the diagonal D, wave-uniform
+  double d_own = 0.0;
   bool all_zero = false;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (k > 0) {
-      double temp[8];
+      double sacc = 0;
 #pragma unroll
-      for (int j = 0; j < k; j++) temp[j] = A[j][j] * A[k][j];
-      double dot = 0;
-#pragma unroll
-      for (int j = 0; j < k; j++) dot += A[k][j] * temp[j];
-      A[k][k] -= dot;
-#pragma unroll
-      for (int i = k + 1; i < 8; i++) {
-        double s = 0;
-#pragma unroll
-        for (int j = 0; j < k; j++) s += A[i][j] * temp[j];
-        A[i][k] -= s;
+      for (int j = 0; j < k; j++) {
+        const double temp = du[j] * lane_value_d(a[j], k);
+        sacc += a[j] * temp;
       }
+      a[k] = a[k] - sacc;
     }
-    const double akk = A[k][k];
+    const double akk = lane_value_d(a[k], k);
     const bool valid = fabs(akk) > 0.0;
     if (k == 0 && !valid) all_zero = true;
-    if (valid) {
-#pragma unroll
-      for (int i = k + 1; i < 8; i++) A[i][k] /= akk;
-    }
+    const double q = a[k] / akk;
+    a[k] = (i > k && valid) ? q : a[k];
+    du[k] = akk;
+    d_own = i == k ? akk : d_own;
   }
+  // L^-1: y[i] -= A[i][j] y[j], j ascending (lane j's value is final when its turn comes)
 #pragma unroll
-  for (int i = 0; i < 8; i++) // L^-1
-#pragma unroll
-    for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
+  for (int j = 0; j < 7; j++) {
+    const double yj = lane_value_d(y, j);
+    y = i > j ? y - a[j] * yj : y;
+  }
   {
     const double tol = 1.0 / 1.7976931348623157e308; // Eigen: 1 / NumTraits<double>::highest()
-#pragma unroll
-    for (int i = 0; i < 8; i++) y[i] = fabs(A[i][i]) > tol ? y[i] / A[i][i] : 0.0;
+    y = fabs(d_own) > tol ? y / d_own : 0.0;
   }
+  // L^-T needs column i of L in lane i: transpose through LDS
+  if (lane < 8) {
 #pragma unroll
-  for (int i = 7; i >= 0; i--) // L^-T
-#pragma unroll
-    for (int j = i + 1; j < 8; j++) y[i] -= A[j][i] * y[j];
-  // ---- 4. P^T: position i of the permuted system is unknown perm[i] ----
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) scr.x[perm[i]] = (all_zero || i >= nact) ? 0.0 : y[i];
+    for (int j = 0; j < 8; j++) scr.L[i][j] = a[j];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  double cl[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) inc[i] = scr.x[i];
+  for (int j = 0; j < 8; j++) cl[j] = scr.L[j][i]; // A[j][i]
+  // y[i] -= A[j][i] y[j] for i = 6 .. 0, j = i + 1 .. 7 ascending (Eigen's order); x_j is final once row j is done
+  double xu[8];
+  xu[7] = lane_value_d(y, 7);
+#pragma unroll
+  for (int ii = 6; ii >= 0; ii--) {
+#pragma unroll
+    for (int j = ii + 1; j < 8; j++) y = i == ii ? y - cl[j] * xu[j] : y;
+    xu[ii] = lane_value_d(y, ii);
+  }
+  // ---- 4. P^T: row i of the permuted system is unknown pl ----
+  if (lane < 8) scr.x[pl] = (all_zero || !act_i) ? 0.0 : y;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+  for (int k = 0; k < 8; k++) inc[k] = scr.x[k];
   if (stitch) {
     inc[7] = inc[6];
     inc[6] = 0;

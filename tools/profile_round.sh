@@ -28,10 +28,20 @@ timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --queue 2
 timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --batch 256 > $OUT/bench_b256.log 2>&1
 timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --batch 1024 > $OUT/bench_b1024.log 2>&1
 timeout 400 python $R/bench.py --evals-only --kf-every 100000 --no-cpu --no-second-leg --no-fixed-leg --streams 1 > $OUT/bench_evals_only.log 2>&1
+# round 2's workload (8 hand-picked frames cycled over the batch) and the scheduling switches on the all-distinct workload
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --scenes 8 --textures converging > $OUT/bench_r02_workload.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --compact 0 > $OUT/bench_compact0.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --coarse 9216 --speculate 0 > $OUT/bench_coarse9216.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --init constant-motion > $OUT/bench_init_constant_motion.log 2>&1
+timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --fixed-schedule 3 > $OUT/bench_fixed3.log 2>&1
+# launch chain of one track call, one stream group (tools/chain_timeline.py)
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/chain -- python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --streams 1 --separate-calls --steps 3 --warmup 2 > $OUT/chain.log 2>&1
+python $R/tools/chain_timeline.py $(find $OUT/chain -name "*kernel_trace.csv" | head -1) > $R/gpurun_out/${TAG}_profiles_chain.txt 2>&1
 timeout 600 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --with-upload --u8 --pinned --overlap > $OUT/bench_with_upload_u8_pinned_overlap.log 2>&1
 # summaries go to gpurun_out/<tag>_profiles/ (gpurun merges only gpurun_out/ back, at most 64 MiB: the raw traces are dropped);
 # copy them into profiles/ afterwards:  cp gpurun_out/<tag>_profiles/* profiles/
 python $R/tools/summarize_profiles.py $OUT $TAG $R/gpurun_out/${TAG}_profiles > $OUT/summary.log 2>&1
 tail -5 $OUT/summary.log
 cp $OUT/summary.log $R/gpurun_out/${TAG}_profiles/${TAG}_summary.log
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+cp $R/gpurun_out/${TAG}_profiles_chain.txt $R/gpurun_out/${TAG}_profiles/${TAG}_chain_timeline.txt
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/chain

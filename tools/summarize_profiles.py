@@ -25,7 +25,8 @@ def last_json(path):
 bench = last_json(os.path.join(src, "bench_default.json"))
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
 for name in ("bench_b1", "bench_b1_S1", "bench_ringkey", "bench_ringkey_q1", "membw", "bench_cfg_S3", "bench_cfg_sparse", "bench_queue", "bench_queue_b256",
-             "bench_b256", "bench_b1024", "bench_evals_only", "bench_with_upload_u8_pinned_overlap"):
+             "bench_b256", "bench_b1024", "bench_evals_only", "bench_with_upload_u8_pinned_overlap", "bench_r02_workload", "bench_compact0",
+             "bench_coarse9216", "bench_init_constant_motion", "bench_fixed3"):
     f = os.path.join(src, name + ".log")
     if os.path.exists(f):
         json.dump(last_json(f), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
@@ -52,11 +53,11 @@ l0 = [k for k in cfg["pose_eval_kernels_by_level"] if k["lvl"] == 0][0]
 if trace:
     iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0])) if L0 in r["Kernel_Name"])
     d = [e - s0 for s0, e in iv]
-    work = [x for x in d if x > 20000]
+    work = [x for x in d if x > 5000]
     # the batch is split into stream groups whose level-0 kernels overlap: time = union of the intervals
     busy, cs, ce = 0, None, None
     for s0, e in iv:
-        if e - s0 <= 20000:
+        if e - s0 <= 5000:
             continue
         if cs is None:
             cs, ce = s0, e
