@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__
     }
     __syncthreads();
     if (q < nq) {
+#pragma unroll 4 // (four keys' LDS reads in flight per wait: the loop is VALU-bound -- 59 unfused operations per pair -- once the reads are covered)
       for (int t = 0; t < tn; t++) {
         const float *kp = tile + t * dim;
         float result = 0.f;
@@ -184,6 +185,88 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const floa
   }
 }
 
+// The same scan with FOUR consecutive keys per thread and iteration: one 16-byte load per plane and thread, i.e. 1 KiB
+// contiguous per plane and wave instead of 256 bytes -- twenty interleaved streams of 256-byte pieces reach 4.5 TB/s on
+// this memory system, 1 KiB pieces more (round 3: DESIGN.md section 4.5).  For groups of one or two queries (the registers
+// hold 80 key values); same distances, same packed candidates: bit-identical.
+typedef float rk_fvec4 __attribute__((ext_vector_type(4)));
+template <int DIM, int K, int QG>
+__global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq4_kernel(const float *__restrict__ keysT, long long cap, long long n_local,
+                                                                       float thres, int shard_rank, int shard_count,
+                                                                       const float *__restrict__ queries, int nq, int n_slices,
+                                                                       unsigned long long *__restrict__ scratch) {
+  static_assert(DIM % 4 == 0, "flann::L2 main loop only");
+  __shared__ __attribute__((aligned(16))) float qs[QG][DIM];
+  __shared__ unsigned long long wtop[kRkThreads / 64][QG][K];
+  const int slice = blockIdx.x, q0 = blockIdx.y * QG;
+  const int nqg = nq - q0 < QG ? nq - q0 : QG;
+  const long long per = (((n_local + n_slices - 1) / n_slices) + 3) & ~3ll; // slices start on 16-byte boundaries of the planes
+  const long long k0 = (long long)slice * per;
+  const long long k1 = k0 + per < n_local ? k0 + per : n_local;
+  for (int e = threadIdx.x; e < QG * DIM; e += kRkThreads) {
+    const int qq = e / DIM, j = e % DIM;
+    qs[qq][j] = qq < nqg ? queries[(size_t)(q0 + qq) * DIM + j] : 0.f;
+  }
+  __syncthreads();
+  unsigned long long best[QG][K];
+#pragma unroll
+  for (int qq = 0; qq < QG; qq++)
+#pragma unroll
+    for (int j = 0; j < K; j++) best[qq][j] = kNoCand;
+  for (long long i = k0 + 4 * threadIdx.x; i < k1; i += 4 * kRkThreads) {
+    rk_fvec4 kv[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; j++) kv[j] = __builtin_nontemporal_load((const rk_fvec4 *)(keysT + (size_t)j * cap + i));
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const unsigned long long g = (unsigned long long)(i + e) * shard_count + shard_rank;
+#pragma unroll
+      for (int qq = 0; qq < QG; qq++) {
+        float result = 0.f;
+#pragma unroll
+        for (int j = 0; j < DIM; j += 4) { // flann::L2 main loop
+          const float d0 = qs[qq][j] - kv[j][e], d1 = qs[qq][j + 1] - kv[j + 1][e], d2 = qs[qq][j + 2] - kv[j + 2][e],
+                      d3 = qs[qq][j + 3] - kv[j + 3][e];
+          result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        if (qq < nqg && i + e < k1 && result < thres) topk_insert<K>(best[qq], ((unsigned long long)__float_as_uint(result) << 32) | g);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int qq = 0; qq < QG; qq++) {
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+      unsigned long long m = best[qq][0];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o < m ? o : m;
+      }
+      if (lane == 0) wtop[wave][qq][r] = m;
+      if (m != kNoCand && best[qq][0] == m) {
+#pragma unroll
+        for (int j = 0; j + 1 < K; j++) best[qq][j] = best[qq][j + 1];
+        best[qq][K - 1] = kNoCand;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nqg) {
+    const int qq = threadIdx.x;
+    unsigned long long t[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) t[j] = kNoCand;
+    for (int w = 0; w < kRkThreads / 64; w++)
+#pragma unroll
+      for (int j = 0; j < K; j++)
+        if (wtop[w][qq][j] != kNoCand) topk_insert<K>(t, wtop[w][qq][j]);
+#pragma unroll
+    for (int j = 0; j < K; j++) scratch[((size_t)slice * nq + q0 + qq) * K + j] = t[j];
+  }
+}
+
 // one wave per query merges the per-slice candidates
 template <int K>
 __global__ __launch_bounds__(64) void ringkey_merge_kernel(const unsigned long long *__restrict__ scratch, int nq,
@@ -257,7 +340,14 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
 #define DSM_FEWQ(QG)                                                                                                   \
   hipLaunchKernelGGL((ringkey_knn_fewq_kernel<20, K, QG>), dim3(n_slices, (nq + QG - 1) / QG), block, 0, s, keysT, (long long)cap,       \
                      (long long)n_local, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch)
-    if (nq == 1)
+#define DSM_FEWQ4(QG)                                                                                                  \
+  hipLaunchKernelGGL((ringkey_knn_fewq4_kernel<20, K, QG>), dim3(n_slices, (nq + QG - 1) / QG), block, 0, s, keysT, (long long)cap,      \
+                     (long long)n_local, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch)
+    if (nq == 1 && (cap & 3) == 0)
+      DSM_FEWQ4(1);
+    else if (nq == 2 && (cap & 3) == 0)
+      DSM_FEWQ4(2);
+    else if (nq == 1) // (groups of four / eight queries with four keys per thread: 408 us against 274 for eight queries over 10^7 keys -- registers)
       DSM_FEWQ(1);
     else if (nq == 2)
       DSM_FEWQ(2);
@@ -266,6 +356,7 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
     else
       DSM_FEWQ(kRkQG);
 #undef DSM_FEWQ
+#undef DSM_FEWQ4
   } else if (dim == 20)
     hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
                        thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);

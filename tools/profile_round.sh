@@ -21,6 +21,19 @@ timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-sec
 timeout 300 python $R/bench.py --batch 1 --scenes 1 --steps 50 --no-cpu --no-second-leg --no-fixed-leg --config S1 > $OUT/bench_b1_S1.log 2>&1
 timeout 300 python $R/bench.py --ringkey --no-cpu --rk-q 1 --rk-n 10000000 --steps 50 > $OUT/bench_ringkey_q1.log 2>&1
 timeout 300 python $R/bench.py --ringkey --no-cpu > $OUT/bench_ringkey.log 2>&1
+# the scan kernel alone (the bench's step time includes the merge launch and the host synchronisation of every step)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rk_trace -- python $R/bench.py --ringkey --no-cpu --rk-q 1 --rk-n 10000000 --steps 50 > $OUT/rk_trace.log 2>&1
+python - "$OUT" "$R/gpurun_out/${TAG}_ringkey_q1_kernel.json" <<'PY'
+import csv, glob, json, sys
+f = sorted(glob.glob(sys.argv[1] + "/rk_trace/*/*kernel_stats.csv"))
+out = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --ringkey --no-cpu --rk-q 1 --rk-n 10000000 --steps 50"}
+if f:
+    for r in csv.DictReader(open(f[-1])):
+        if "ringkey_knn_fewq" in r["Name"]:
+            avg = float(r["AverageNs"])
+            out.update(kernel=r["Name"][:80], calls=int(r["Calls"]), average_ns=avg, sweep_bytes=80 * 10_000_000, GBps=80e7 / avg, frac_of_8TBps=80e7 / avg / 8000.0)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+PY
 timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --config S3 --batch 256 > $OUT/bench_cfg_S3.log 2>&1
 timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --template sparse > $OUT/bench_cfg_sparse.log 2>&1
 timeout 400 python $R/bench.py --no-cpu --no-second-leg --no-fixed-leg --queue 2 > $OUT/bench_queue.log 2>&1
@@ -44,4 +57,5 @@ python $R/tools/summarize_profiles.py $OUT $TAG $R/gpurun_out/${TAG}_profiles > 
 tail -5 $OUT/summary.log
 cp $OUT/summary.log $R/gpurun_out/${TAG}_profiles/${TAG}_summary.log
 cp $R/gpurun_out/${TAG}_profiles_chain.txt $R/gpurun_out/${TAG}_profiles/${TAG}_chain_timeline.txt
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/chain
+cp $R/gpurun_out/${TAG}_ringkey_q1_kernel.json $R/gpurun_out/${TAG}_profiles/
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/chain $OUT/rk_trace
