@@ -15,7 +15,8 @@
 // reference's "first one wins ties") and the output order, ascending voxel index, is a stream compaction of the grid: no
 // sort, no hash collisions, deterministic.  The polar bins are 1200 atomic-max cells.  Every per-point value is computed
 // with the host form's operation order in double precision (-ffp-contract=off), the PCA moments are summed in point order
-// by one lane per moment, the 3x3 eigen-decomposition stays on the host (9 doubles down, 12 up): results are
+// by one lane per moment, the 3x3 eigen-decomposition runs the host form's cyclic Jacobi (one function for both,
+// loopdet_internal.hpp) in sc_pca_kernel between the two halves -- nothing leaves the device mid-batch: results are
 // bit-identical to dsm_generate_spherical_points / dsm_scancontext_generate wherever libm agrees (atan2, within 1 ulp of a
 // sector boundary, is the one place it may not).
 #include <algorithm>
@@ -65,7 +66,8 @@ struct JobDev {             // one keyframe
   int *n_out;
   // ScanContext
   double *moments;            // [0..2] mean, [3..8] cov (xx, xy, xz, yy, yz, zz)
-  double mean[3], V[9];       // filled by the host between the two halves
+  double mean[3], V[9];       // sc_pca_kernel: centroid and eigenvectors (ScanContext.cpp:41-47)
+  double tfm[16];             // ... and tfm_pca_rig (:55-64)
   unsigned long long *bins;   // num_s * num_r order-preserving keys of max_height
   float *ringkey;             // num_r
   int *sig_idx;               // num_s * num_r capacity
@@ -282,6 +284,27 @@ int dev_alloc(std::vector<void *> &owned, T **p, size_t n) {
 
 } // namespace
 
+// ScanContext::generate, between the halves (ScanContext.cpp:41-64): 3 x 3 eigen-decomposition of the covariance (the host
+// form's cyclic Jacobi, same operations in the same order: loopdet_internal.hpp), centroid, eigenvectors and tfm_pca_rig
+// of every job -- one thread per job, on the device since round 3 (the moments used to travel to the host and back).
+__global__ void sc_pca_kernel(JobDev *jobs, int n_jobs) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
+  JobDev &J = jobs[j];
+  if (!J.ringkey || *J.n_out < 1) return;
+  const double *m = J.moments;
+  const double cov[9] = {m[3], m[4], m[5], m[4], m[6], m[7], m[5], m[7], m[8]};
+  double ev[3], V[9];
+  dsm::eig3_sym(cov, ev, V);
+  for (int i = 0; i < 3; i++) J.mean[i] = m[i];
+  for (int i = 0; i < 9; i++) J.V[i] = V[i];
+  double *tfm = J.tfm;
+  for (int i = 0; i < 16; i++) tfm[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) tfm[r * 4 + c] = V[c * 3 + r];
+  for (int r = 0; r < 3; r++) tfm[r * 4 + 3] = -(tfm[r * 4 + 0] * m[0] + tfm[r * 4 + 1] * m[1] + tfm[r * 4 + 2] * m[2]);
+}
+
 extern "C" {
 
 int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r) {
@@ -370,14 +393,20 @@ int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job 
   // ---- ScanContext::generate, first half: PCA moments
   bool any_sc = false;
   for (int j = 0; j < n_jobs; j++) any_sc = any_sc || jobs[j].ringkey;
-  if (any_sc) hipLaunchKernelGGL(sc_moments_kernel, dim3(n_jobs), dim3(64), 0, st, dj);
+  if (any_sc) {
+    hipLaunchKernelGGL(sc_moments_kernel, dim3(n_jobs), dim3(64), 0, st, dj);
+    // ---- the eigen-decomposition (:41-47) and tfm_pca_rig (:55-64), then the second half (binning, ring key, signature):
+    // nothing leaves the device between the halves (jobs without points are skipped by every kernel and reported below)
+    hipLaunchKernelGGL(sc_pca_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, st, dj, n_jobs);
+    hipLaunchKernelGGL(sc_clear_kernel, dim3((nbins + kLdThreads - 1) / kLdThreads, n_jobs), dim3(kLdThreads), 0, st, dj, nbins, lidar_range);
+    hipLaunchKernelGGL(sc_bin_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, num_s, num_r);
+    hipLaunchKernelGGL(sc_finish_kernel, dim3(n_jobs), dim3(kLdThreads), sizeof(double) * num_s, st, dj, lidar_range, num_s, num_r);
+  }
   DSM_HIP(hipGetLastError());
   std::vector<int> n_out(n_jobs);
-  std::vector<double> mom((size_t)9 * n_jobs);
-  for (int j = 0; j < n_jobs; j++) {
-    DSM_HIP(hipMemcpyAsync(&n_out[j], hj[j].n_out, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (any_sc) DSM_HIP(hipMemcpyAsync(&mom[9 * j], hj[j].moments, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
-  }
+  std::vector<JobDev> back(any_sc ? n_jobs : 0);
+  for (int j = 0; j < n_jobs; j++) DSM_HIP(hipMemcpyAsync(&n_out[j], hj[j].n_out, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (any_sc) DSM_HIP(hipMemcpyAsync(back.data(), dj, sizeof(JobDev) * n_jobs, hipMemcpyDeviceToHost, st)); // tfm of every job
   DSM_HIP(hipStreamSynchronize(st));
   for (int j = 0; j < n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
@@ -391,29 +420,15 @@ int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job 
     DSM_HIP(hipStreamSynchronize(st));
     return DSM_OK;
   }
-  // ---- 3x3 eigen-decomposition on the host (:41-47), tfm_pca_rig (:55-64)
   for (int j = 0; j < n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
     if (!J.ringkey) continue;
-    if (n_out[j] < 1) return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set");
-    const double *m = &mom[9 * j];
-    const double cov[9] = {m[3], m[4], m[5], m[4], m[6], m[7], m[5], m[7], m[8]};
-    double ev[3], V[9];
-    eig3_sym(cov, ev, V);
-    memcpy(hj[j].mean, m, sizeof(double) * 3);
-    memcpy(hj[j].V, V, sizeof V);
-    double *tfm = J.tfm_pca_rig;
-    for (int i = 0; i < 16; i++) tfm[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) tfm[r * 4 + c] = V[c * 3 + r];
-    for (int r = 0; r < 3; r++) tfm[r * 4 + 3] = -(tfm[r * 4 + 0] * m[0] + tfm[r * 4 + 1] * m[1] + tfm[r * 4 + 2] * m[2]);
+    if (n_out[j] < 1) {
+      DSM_HIP(hipStreamSynchronize(st));
+      return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set");
+    }
+    memcpy(J.tfm_pca_rig, back[j].tfm, sizeof(double) * 16);
   }
-  DSM_HIP(hipMemcpyAsync(dj, hj.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
-  // ---- second half: binning, ring key, signature
-  hipLaunchKernelGGL(sc_clear_kernel, dim3((nbins + kLdThreads - 1) / kLdThreads, n_jobs), dim3(kLdThreads), 0, st, dj, nbins, lidar_range);
-  hipLaunchKernelGGL(sc_bin_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, num_s, num_r);
-  hipLaunchKernelGGL(sc_finish_kernel, dim3(n_jobs), dim3(kLdThreads), sizeof(double) * num_s, st, dj, lidar_range, num_s, num_r);
-  DSM_HIP(hipGetLastError());
   std::vector<int> n_sig(n_jobs);
   for (int j = 0; j < n_jobs; j++) DSM_HIP(hipMemcpyAsync(&n_sig[j], hj[j].n_sig, sizeof(int), hipMemcpyDeviceToHost, st));
   DSM_HIP(hipStreamSynchronize(st));

@@ -98,3 +98,43 @@ def test_bench_spawns_its_own_ranks():
     d = _line(out)
     assert d["n_gpus"] == 2 and d["config"]["replicas"] == 2 and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_frames_are_distinct_and_round_2s_workload_is_reproducible(monkeypatch):
+    """bench.build_frames: every frame in flight has its own motion, noise and initial guess (textures repeat); with
+    `--scenes 8 --textures converging` the frames are round 2's eight (same seeds, same draws)"""
+    import numpy as np
+
+    m = _bench()
+    from direct_stereo_slam_amd import synth as S
+
+    w, h, K = 312, 96, (179.7, 179.7, 152.6, 47.3)  # a quarter-size geometry keeps the rendering short
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "40"])
+    a = m.parse()
+    tex, frames = m.build_frames(a, w, h, K, S.KITTI_T_STEREO)
+    assert len(tex) == 18 and len(frames) == 40 and m.frame_seeds(a) == tuple(range(18))
+    gts = np.array([f[2] for f in frames])
+    assert len({tuple(np.round(g, 12)) for g in gts}) == 40  # 40 distinct motions
+    assert not np.array_equal(frames[0][1], frames[18][1])  # same texture, another motion and noise: another image
+    assert all(np.array_equal(f[3], S.IDENTITY_POSE) for f in frames)  # SURVEY.md 8d: identity guess
+    m._FRAMES.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "16", "--scenes", "8", "--textures", "converging"])
+    a = m.parse()
+    tex8, frames8 = m.build_frames(a, w, h, K, S.KITTI_T_STEREO)
+    assert len(frames8) == 8 and m.frame_seeds(a) == m.SCENE_SEEDS
+    # round 2 drew, per scene: reference image, motion, new image, right image from ONE generator seeded by the scene
+    seed = 0x5EED0000 + m.SCENE_SEEDS[3]
+    scene, rng = S.PlaneScene(seed=seed), np.random.default_rng(seed)
+    ref = scene.render(K, w, h, noise=2.0, rng=rng)
+    R, t = S.random_motion(rng)
+    new = scene.render(K, w, h, R, t, a=0.02, b=3.0, noise=2.0, rng=rng)
+    np.testing.assert_array_equal(tex8[3][1], ref)
+    np.testing.assert_array_equal(frames8[3][1], new)
+    np.testing.assert_array_equal(frames8[3][2], S.pose_from_Rt(R, t))
+    # the constant-motion guess is the true motion up to a bounded error
+    m._FRAMES.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "6", "--init", "constant-motion"])
+    a = m.parse()
+    _, fr = m.build_frames(a, w, h, K, S.KITTI_T_STEREO)
+    assert all(0 < np.abs(f[3][4:] - f[2][4:]).max() < 0.3 for f in fr)
+    m._FRAMES.clear()
