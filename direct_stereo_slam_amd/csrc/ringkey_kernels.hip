@@ -30,8 +30,23 @@ __device__ __forceinline__ void topk_insert(unsigned long long (&t)[K], unsigned
   }
 }
 
-// one thread = one query; key tiles are staged through LDS and broadcast to all lanes
-template <int DIM, int K>
+// A thread visits its keys in ascending index order, so a candidate at the distance of the list's K-th entry can never
+// displace it (same distance, larger index): once the list is full only a STRICTLY smaller distance gets in.  `cut` is
+// that bound -- thres while the list has room, the K-th distance after -- and the per-pair test `result < cut` replaces
+// `result < thres`: the same lists, but the 64-bit compare-and-swap chain (20 vector instructions) runs for the handful of
+// candidates that change a list instead of for every pair under the threshold (a third of all pairs on keys of similar
+// scenes, where it was a quarter of the many-query kernel's instructions).
+template <int K>
+__device__ __forceinline__ void topk_insert_cut(unsigned long long (&t)[K], float &cut, float result, unsigned long long g) {
+  topk_insert<K>(t, ((unsigned long long)__float_as_uint(result) << 32) | g);
+  if (t[K - 1] != kNoCand) cut = __uint_as_float((unsigned)(t[K - 1] >> 32));
+}
+
+// one thread = QPT queries; key tiles are staged through LDS and broadcast to all lanes.  QPT = 2 (large query counts, dim
+// 20): every broadcast read of a key element feeds two subtractions -- a ds_read_b128 costs the CU's one LDS four cycles
+// per wave whatever the lanes read, five of them per key and wave against 118 vector cycles per SIMD for the 59 operations of
+// a pair: with one query per thread the LDS is two thirds busy and the vector pipes wait on it.
+template <int DIM, int K, int QPT = 1>
 __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__restrict__ keysT, long long cap,
                                                                  long long n_local, int dim_rt, float thres,
                                                                  int shard_rank, int shard_count,
@@ -39,22 +54,32 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__
                                                                  int n_slices,
                                                                  unsigned long long *__restrict__ scratch) {
   constexpr int DMAX = DIM > 0 ? DIM : 32;
+  static_assert(QPT == 1 || DIM > 0, "several queries per thread: fixed dimension only");
   const int dim = DIM > 0 ? DIM : dim_rt;
   __shared__ __attribute__((aligned(16))) float tile[kRkTile * DMAX];
-  const int q = blockIdx.x * kRkThreads + threadIdx.x;
+  int q[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; i++) q[i] = (blockIdx.x * QPT + i) * kRkThreads + threadIdx.x;
   const int slice = blockIdx.y;
   const long long per = (n_local + n_slices - 1) / n_slices;
   const long long k0 = (long long)slice * per;
   const long long k1 = k0 + per < n_local ? k0 + per : n_local;
 
-  float qv[DMAX];
+  float qv[QPT][DMAX];
   if (DIM > 0) {
 #pragma unroll
-    for (int j = 0; j < DMAX; j++) qv[j] = q < nq ? queries[(size_t)q * DIM + j] : 0.f;
-  }
-  unsigned long long best[K];
+    for (int i = 0; i < QPT; i++)
 #pragma unroll
-  for (int j = 0; j < K; j++) best[j] = kNoCand;
+      for (int j = 0; j < DMAX; j++) qv[i][j] = q[i] < nq ? queries[(size_t)q[i] * DIM + j] : 0.f;
+  }
+  unsigned long long best[QPT][K];
+  float cut[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; i++) {
+    cut[i] = q[i] < nq ? thres : -1.0f; // (a thread without a query never passes the test)
+#pragma unroll
+    for (int j = 0; j < K; j++) best[i][j] = kNoCand;
+  }
 
   for (long long base = k0; base < k1; base += kRkTile) {
     const int tn = (int)(k1 - base < kRkTile ? k1 - base : kRkTile);
@@ -64,42 +89,48 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_kernel(const float *__
       if (t < tn) tile[t * dim + j] = keysT[(size_t)j * cap + base + t];
     }
     __syncthreads();
-    if (q < nq) {
-#pragma unroll 4 // (four keys' LDS reads in flight per wait: the loop is VALU-bound -- 59 unfused operations per pair -- once the reads are covered)
+    if (q[0] < nq) {
+#pragma unroll 4 // (four keys' LDS reads in flight per wait)
       for (int t = 0; t < tn; t++) {
         const float *kp = tile + t * dim;
-        float result = 0.f;
+        float result[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; i++) result[i] = 0.f;
         if (DIM > 0) {
 #pragma unroll
           for (int j = 0; j < DMAX; j += 4) { // flann::L2 main loop
-            const float d0 = qv[j] - kp[j], d1 = qv[j + 1] - kp[j + 1], d2 = qv[j + 2] - kp[j + 2],
-                        d3 = qv[j + 3] - kp[j + 3];
-            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            const float k0v = kp[j], k1v = kp[j + 1], k2v = kp[j + 2], k3v = kp[j + 3];
+#pragma unroll
+            for (int i = 0; i < QPT; i++) {
+              const float d0 = qv[i][j] - k0v, d1 = qv[i][j + 1] - k1v, d2 = qv[i][j + 2] - k2v, d3 = qv[i][j + 3] - k3v;
+              result[i] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
           }
         } else {
-          const float *qp = queries + (size_t)q * dim;
+          const float *qp = queries + (size_t)q[0] * dim;
           int j = 0;
           for (; j + 3 < dim; j += 4) {
             const float d0 = qp[j] - kp[j], d1 = qp[j + 1] - kp[j + 1], d2 = qp[j + 2] - kp[j + 2],
                         d3 = qp[j + 3] - kp[j + 3];
-            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            result[0] += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
           }
           for (; j < dim; j++) { // flann::L2 tail loop
             const float d0 = qp[j] - kp[j];
-            result += d0 * d0;
+            result[0] += d0 * d0;
           }
         }
-        if (result < thres) {
-          const unsigned long long g = (unsigned long long)(base + t) * shard_count + shard_rank;
-          topk_insert<K>(best, ((unsigned long long)__float_as_uint(result) << 32) | g);
-        }
+#pragma unroll
+        for (int i = 0; i < QPT; i++)
+          if (result[i] < cut[i]) topk_insert_cut<K>(best[i], cut[i], result[i], (unsigned long long)(base + t) * shard_count + shard_rank);
       }
     }
   }
-  if (q < nq) {
 #pragma unroll
-    for (int j = 0; j < K; j++) scratch[((size_t)slice * nq + q) * K + j] = best[j];
-  }
+  for (int i = 0; i < QPT; i++)
+    if (q[i] < nq) {
+#pragma unroll
+      for (int j = 0; j < K; j++) scratch[((size_t)slice * nq + q[i]) * K + j] = best[i][j];
+    }
 }
 
 // Few queries (the SLAM case: one ring key per keyframe, a handful with several concurrent sequences): one thread =
@@ -128,10 +159,13 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const floa
   }
   __syncthreads();
   unsigned long long best[QG][K];
+  float cut[QG];
 #pragma unroll
-  for (int qq = 0; qq < QG; qq++)
+  for (int qq = 0; qq < QG; qq++) {
+    cut[qq] = qq < nqg ? thres : -1.0f;
 #pragma unroll
     for (int j = 0; j < K; j++) best[qq][j] = kNoCand;
+  }
   for (long long i = k0 + threadIdx.x; i < k1; i += kRkThreads) {
     float kv[DIM];
 #pragma unroll
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq_kernel(const floa
                     d3 = qs[qq][j + 3] - kv[j + 3];
         result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
       }
-      if (qq < nqg && result < thres) topk_insert<K>(best[qq], ((unsigned long long)__float_as_uint(result) << 32) | g);
+      if (result < cut[qq]) topk_insert_cut<K>(best[qq], cut[qq], result, g);
     }
   }
   // per wave and query: K rounds of wave-min extraction (the winner lane pops its head) -> LDS; then one thread per
@@ -209,10 +243,13 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq4_kernel(const flo
   }
   __syncthreads();
   unsigned long long best[QG][K];
+  float cut[QG];
 #pragma unroll
-  for (int qq = 0; qq < QG; qq++)
+  for (int qq = 0; qq < QG; qq++) {
+    cut[qq] = qq < nqg ? thres : -1.0f;
 #pragma unroll
     for (int j = 0; j < K; j++) best[qq][j] = kNoCand;
+  }
   for (long long i = k0 + 4 * threadIdx.x; i < k1; i += 4 * kRkThreads) {
     rk_fvec4 kv[DIM];
 #pragma unroll
@@ -229,7 +266,7 @@ __global__ __launch_bounds__(kRkThreads) void ringkey_knn_fewq4_kernel(const flo
                       d3 = qs[qq][j + 3] - kv[j + 3][e];
           result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
-        if (qq < nqg && i + e < k1 && result < thres) topk_insert<K>(best[qq], ((unsigned long long)__float_as_uint(result) << 32) | g);
+        if (i + e < k1 && result < cut[qq]) topk_insert_cut<K>(best[qq], cut[qq], result, g);
       }
     }
   }
@@ -310,6 +347,7 @@ __global__ void ringkey_insert_kernel(float *keysT, long long cap, long long pos
   }
 }
 
+constexpr int kRkTwoPerThread = 512; // from here on a thread of ringkey_knn_kernel carries two queries
 constexpr int kRkFewQueries = 32; // up to here the thread-per-key kernel is used (dim 20 only)
 static bool ringkey_use_fewq(int dim, int nq) { return dim == 20 && nq <= kRkFewQueries; }
 
@@ -321,8 +359,12 @@ int ringkey_num_slices(int64_t n_local, int nq, int dim) {
     return (int)(s < 1 ? 1 : s);
   }
   // enough workgroups to fill 256 CUs, at least one key tile per slice
-  const int qblocks = (nq + kRkThreads - 1) / kRkThreads;
-  int64_t want = 2048 / (qblocks > 0 ? qblocks : 1);
+  const int per_block = dim == 20 && nq >= kRkTwoPerThread ? 2 * kRkThreads : kRkThreads;
+  const int qblocks = (nq + per_block - 1) / per_block;
+  // one full round of resident workgroups: 8 per CU for the one-query-per-thread kernel (54 VGPRs), 5 for two per thread (88):
+  // 1.6 rounds cost two
+  const int resident = per_block == kRkThreads ? 2048 : 1280;
+  int64_t want = resident / (qblocks > 0 ? qblocks : 1);
   if (want < 1) want = 1;
   const int64_t max_by_keys = (n_local + kRkTile - 1) / kRkTile;
   int64_t s = want < max_by_keys ? want : max_by_keys;
@@ -357,7 +399,10 @@ static void launch_knn_k(hipStream_t s, const float *keysT, int64_t cap, int64_t
       DSM_FEWQ(kRkQG);
 #undef DSM_FEWQ
 #undef DSM_FEWQ4
-  } else if (dim == 20)
+  } else if (dim == 20 && nq >= kRkTwoPerThread)
+    hipLaunchKernelGGL((ringkey_knn_kernel<20, K, 2>), dim3((nq + 2 * kRkThreads - 1) / (2 * kRkThreads), n_slices), block, 0, s, keysT,
+                       (long long)cap, (long long)n_local, dim, thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
+  else if (dim == 20)
     hipLaunchKernelGGL((ringkey_knn_kernel<20, K>), grid, block, 0, s, keysT, (long long)cap, (long long)n_local, dim,
                        thres, shard_rank, shard_count, d_queries, nq, n_slices, d_scratch);
   else

@@ -274,9 +274,75 @@ __global__ __launch_bounds__(256) void k7(const fvec4 *__restrict__ pts, const f
   }
   if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
 }
+// modes 32-34 (round 3): the LDS TILE form of the intensity-plane gathers.  The chunk's 4096 template entries cover a 64 x 64
+// tile of the reference image (tile-ordered list), the workgroup first copies the 72 x 72 target window around it into LDS with
+// coalesced 16-byte loads (one barrier), and the twelve intensities of every point then come from LDS (ds_read2_b32 pairs)
+// instead of four global gathers.  LDS arena 9216 floats = four workgroups per CU, as the eval kernel has.  GB/s on the same
+// 16 + 12 bytes per point.  32: 200 FMAs per point, 33: none, 34: 216.
+typedef float fvec4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float fvec2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int WORK, bool PK = false>
+__global__ __launch_bounds__(256) void k8(const fvec4 *__restrict__ pts, const float *__restrict__ img, int w, int npts_per_frame, int npx_per_frame, float *out, int chunks_per_frame) {
+  constexpr int PITCH = 72, ROWS = 72;
+  __shared__ float tile[9216];
+  float c[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
+  const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const fvec4 *p = pts + (size_t)frame * npts_per_frame + (size_t)chunk * 4096;
+  const float *ib = img + (size_t)frame * npx_per_frame;
+  fvec4 q[3];
+  q[0] = __builtin_nontemporal_load(p + tid), q[1] = __builtin_nontemporal_load(p + 256 + tid), q[2] = __builtin_nontemporal_load(p + 512 + tid);
+  // window origin from the chunk's first entry (wave-uniform): tile origin - 4 columns (keeps 16-byte alignment), - 2 rows
+  const int first = (int)__builtin_amdgcn_readfirstlane(__float_as_int(p[0].x));
+  const int fi = (int)__int_as_float(first);
+  const int x0 = (fi % w) & ~3, y0 = fi / w;
+  const int wx0 = x0 - 4, wy0 = y0 - 2;
+  for (int e = tid; e < ROWS * (PITCH / 4); e += 256) {
+    const int r = e / (PITCH / 4), cx = e % (PITCH / 4);
+    *(fvec4 *)&tile[r * PITCH + 4 * cx] = *(const fvec4 *)(ib + (size_t)(wy0 + r) * w + wx0 + 4 * cx);
+  }
+  __syncthreads();
+  float acc = 0.f;
+  struct T12 { fvec4u r1, r2; fvec2u r0, r3; };
+  auto issue = [&](const fvec4 &pt, T12 &t) {
+    const int lin = (int)pt.x;
+    const int y = lin / w, x = lin - y * w; // (the eval kernel gets x, y from the warp; a division stands in for that arithmetic)
+    const int o = (y - wy0) * PITCH + (x - wx0);
+    t.r1 = *(const fvec4u *)&tile[o - 1], t.r2 = *(const fvec4u *)&tile[o + PITCH - 1];
+    t.r0 = *(const fvec2u *)&tile[o - PITCH], t.r3 = *(const fvec2u *)&tile[o + 2 * PITCH];
+  };
+  T12 T;
+  issue(q[0], T);
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) {
+    const int inext = (kk + 3) * 256 + tid;
+    const fvec4 qn = __builtin_nontemporal_load(p + (inext < 4096 ? inext : tid));
+    T12 Tn;
+    issue(q[1], Tn);
+    const T12 &t = T;
+    const float a0 = t.r1.y + t.r0.x, a1 = t.r2.z + t.r3.y, a2 = t.r1.w - t.r1.x, a3 = t.r2.w - t.r2.x;
+    acc += (a0 + a1) + (a2 + a3) + q[0].w;
+    if (PK) { // the same 8 chains as four v_pk_fma_f32 chains
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 *c2 = (f2 *)c;
+      const f2 aa = {a0, a0};
+#pragma unroll
+      for (int j = 0; j < WORK; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) c2[e] = __builtin_elementwise_fma(c2[e], aa, (f2){a1 + (float)(2 * e), a1 + (float)(2 * e + 1)});
+    } else {
+#pragma unroll
+    for (int j = 0; j < WORK; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) c[e] = __builtin_fmaf(c[e], a0, a1 + (float)e);
+    }
+    T = Tn;
+    q[0] = q[1], q[1] = q[2], q[2] = qn;
+  }
+  if (acc + c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] == 123456.789f) out[0] = acc;
+}
 int main(int argc, char **argv) {
   const int w = 1232, h = 368, npx = w * h, npts = 1228 * 364, frames = argc > 1 ? atoi(argv[1]) : 96;
-  const int mode_lo = argc > 2 ? atoi(argv[2]) : 0, mode_hi = argc > 3 ? atoi(argv[3]) : 31;
+  const int mode_lo = argc > 2 ? atoi(argv[2]) : 0, mode_hi = argc > 3 ? atoi(argv[3]) : 35;
   const int chunks = (npts - 4096) / 4096; // whole chunks only, rows stay inside the image
   fvec4 *pts; float *img, *out;
   hipMalloc(&pts, (size_t)frames * npts * 16); hipMalloc(&img, (size_t)frames * npx * 12 + 65536); hipMalloc(&out, 64);
@@ -294,6 +360,15 @@ int main(int argc, char **argv) {
     hipMalloc(&pts_tab, frames * 8); hipMalloc(&img_tab, frames * 8);
     hipMemcpy(pts_tab, hp.data(), frames * 8, hipMemcpyHostToDevice); hipMemcpy(img_tab, hi.data(), frames * 8, hipMemcpyHostToDevice);
   }
+  // modes 32-34: tile-ordered template (chunk c = the 64 x 64 tile (c % tiles_x, c / tiles_x), row-major inside the tile)
+  const int tiles_x = (w - 8) / 64, tiles_y = (h - 8) / 64, tchunks = tiles_x * tiles_y;
+  fvec4 *tpts; hipMalloc(&tpts, (size_t)frames * tchunks * 4096 * 16);
+  { std::vector<float> hp((size_t)tchunks * 4096 * 4, 0.f);
+    for (int cch = 0; cch < tchunks; cch++) for (int j = 0; j < 4096; j++) {
+      const int x = 4 + (cch % tiles_x) * 64 + j % 64, y = 4 + (cch / tiles_x) * 64 + j / 64;
+      hp[4 * ((size_t)cch * 4096 + j)] = (float)(y * w + x);
+    }
+    for (int f = 0; f < frames; f++) hipMemcpy((char *)tpts + (size_t)f * tchunks * 4096 * 16, hp.data(), hp.size() * 4, hipMemcpyHostToDevice); }
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int mode = mode_lo; mode <= mode_hi; mode++) {
     for (int rep = 0; rep < 2; rep++) {
@@ -330,11 +405,15 @@ int main(int argc, char **argv) {
         if (mode == 29) hipLaunchKernelGGL((k7<3, 25, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 30) hipLaunchKernelGGL((k7<2, 0, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
         if (mode == 31) hipLaunchKernelGGL((k7<2, 27, 9216>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
+        if (mode == 32) hipLaunchKernelGGL((k8<25>), dim3(tchunks, frames), dim3(256), 0, 0, tpts, img, w, tchunks * 4096, npx, out, tchunks);
+        if (mode == 33) hipLaunchKernelGGL((k8<0>), dim3(tchunks, frames), dim3(256), 0, 0, tpts, img, w, tchunks * 4096, npx, out, tchunks);
+        if (mode == 34) hipLaunchKernelGGL((k8<27>), dim3(tchunks, frames), dim3(256), 0, 0, tpts, img, w, tchunks * 4096, npx, out, tchunks);
+        if (mode == 35) hipLaunchKernelGGL((k8<25, true>), dim3(tchunks, frames), dim3(256), 0, 0, tpts, img, w, tchunks * 4096, npx, out, tchunks);
         if (mode == 6) hipLaunchKernelGGL((k3<25, 4096>), dim3(chunks, frames), dim3(256), 0, 0, pts, img, w, npts, npx, out);
       }
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
-      const double bytes = 5.0 * frames * chunks * 4096.0 * (16.0 + (mode ? 12.0 : 0.0)); // algorithmic: 16 B template + 12 B image per point
+      const double bytes = 5.0 * frames * (mode >= 32 ? tchunks : chunks) * 4096.0 * (16.0 + (mode ? 12.0 : 0.0)); // algorithmic: 16 B template + 12 B image per point
       if (rep) printf("mode %d: %.3f ms per launch, %.0f GB/s algorithmic (16 + %d B per point)\n", mode, ms / 5, bytes / (ms * 1e-3) / 1e9, mode ? 12 : 0);
     }
   }
