@@ -16,9 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_adaptor_matches_python_mirror(ctx, tmp_path):
-    sc = make_scene("small", seed=17)
-    path = tmp_path / "fixture.bin"
+def write_fixture(sc, path):
     with open(path, "wb") as f:
         f.write(struct.pack("iii", sc.w, sc.h, sc.nl))
         f.write(np.asarray(sc.K, np.float32).tobytes())
@@ -30,10 +28,34 @@ def test_cpp_adaptor_matches_python_mirror(ctx, tmp_path):
         for pyr in (sc.new_p, sc.right_p):
             for l in range(sc.nl):
                 f.write(np.ascontiguousarray(pyr[l], np.float32).tobytes())
-    exe = os.path.join(ROOT, "direct_stereo_slam_amd", "host", "_build", "host_adaptor_demo")
+
+
+def run_host(exe_name, path):
+    exe = os.path.join(ROOT, "direct_stereo_slam_amd", "host", "_build", exe_name)
     out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    return out.stdout.strip().splitlines()[-1]
+
+
+def test_reference_binding_through_standin_types_equals_the_plain_adaptor(ctx, tmp_path):
+    """host/ReferenceBinding.hpp -- the bodies a maintainer puts behind dso::TrackerAndScaler's public methods, a template over
+    the reference's types -- instantiated with stand-ins that carry the member names it touches on Sophus::SE3, dso::AffLight,
+    Eigen vectors, dso::FrameHessian and dso::CalibHessian (host/reference_binding_check.cpp), driven like FrontEnd.cpp: the
+    FrameHessian -> dIp / exposure / shell id hand-over, the SE3 and AffLight round trips and the Vec5 residuals must give, bit
+    for bit, what the plain adaptor gives on the same fixture"""
+    sc = make_scene("small", seed=23)
+    path = tmp_path / "fixture.bin"
+    write_fixture(sc, path)
+    plain, bound = run_host("host_adaptor_demo", path), run_host("reference_binding_check", path)
+    assert json.loads(plain)["good"] == 1
+    assert plain == bound
+
+
+def test_cpp_adaptor_matches_python_mirror(ctx, tmp_path):
+    sc = make_scene("small", seed=17)
+    path = tmp_path / "fixture.bin"
+    write_fixture(sc, path)
+    res = json.loads(run_host("host_adaptor_demo", path))
     trk = hip_tracker(ctx, sc)
     good, pose, aff, last = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     err, s = trk.optimizeScale(1.0, sc.nl - 1)
