@@ -756,6 +756,40 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
             "shards": world, "merge": "dsm_ringdb_merge_topk (C ABI, librccl)" if world > 1 else "one shard: no merge", **res}
 
 
+def line_guard(res):
+    """The sharded ring-key leg is this bench's first contact with several RCCL ranks on a box; a process that dies inside a
+    native library (SIGSEGV, abort) prints nothing.  Before the leg, rank 0 parks its finished bench line with a forked
+    helper that touches neither the GPU nor torch: it waits on a pipe and, if rank 0 goes away without calling the returned
+    function, prints the line (with the leg marked as lost) to the inherited stdout -- still exactly ONE JSON line."""
+    import copy
+
+    parked = copy.deepcopy(res)
+    parked["config"]["ringkey_sharded"] = {"error": "rank 0 ended inside the sharded ring-key leg (the bench line is the one measured before it)"}
+    text = (json.dumps(parked) + "\n").encode()
+    r, w = os.pipe()
+    sys.stdout.flush()
+    pid = os.fork()
+    if pid == 0:  # helper: plain system calls only
+        try:
+            os.close(w)
+            done = os.read(r, 1)  # b"" = the writer is gone without a word
+            if not done:
+                os.write(1, text)
+        finally:
+            os._exit(0)
+    os.close(r)
+
+    def release():
+        try:
+            os.write(w, b"1")
+            os.close(w)
+            os.waitpid(pid, 0)
+        except OSError:
+            pass
+
+    return release
+
+
 def run_with_deadline(fn, seconds, device):
     """fn() on a worker thread bound to this rank's device; returns (result, still_running).  Exceptions and a missed
     deadline become {"error": ...}."""
@@ -849,7 +883,10 @@ def bench_tracking(args):
     if world > 1 and not args.no_ringkey_leg and args.device_override < 0:  # (RCCL refuses two ranks on one device)
         # A reported extra must never cost the bench line: the leg runs under a deadline (a collective that one rank never
         # enters would otherwise hold every rank until the driver's own limit), and a rank whose leg is stuck prints and leaves.
+        guard = line_guard(res) if rank == 0 else None
         res["config"]["ringkey_sharded"], stuck = run_with_deadline(lambda: ringkey_sharded_leg(args, ctx, rank, world), args.ringkey_leg_seconds, local)
+        if guard is not None:
+            guard()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if stuck:

@@ -138,3 +138,23 @@ def test_frames_are_distinct_and_round_2s_workload_is_reproducible(monkeypatch):
     _, fr = m.build_frames(a, w, h, K, S.KITTI_T_STEREO)
     assert all(0 < np.abs(f[3][4:] - f[2][4:]).max() < 0.3 for f in fr)
     m._FRAMES.clear()
+
+
+def test_line_guard_prints_the_parked_line_only_when_rank0_dies():
+    """bench.line_guard: the finished bench line is parked with a forked helper before the multi-rank RCCL leg; a rank 0 that
+    dies inside a native library still yields exactly one JSON line, an orderly one prints its own"""
+    import json
+    import subprocess
+    import sys
+
+    prog = ("import os, sys, json; sys.path.insert(0, %r); import bench; "
+            "g = bench.line_guard({'value': 1.0, 'config': {}}); "
+            "%s")
+    died = subprocess.run([sys.executable, "-c", prog % (ROOT, "os.kill(os.getpid(), 9)")], capture_output=True, text=True, timeout=120)
+    lines = [l for l in died.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and "error" in d["config"]["ringkey_sharded"]
+    fine = subprocess.run([sys.executable, "-c", prog % (ROOT, "g(); print(json.dumps({'value': 2.0}))")], capture_output=True, text=True, timeout=120)
+    lines = [l for l in fine.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["value"] == 2.0
