@@ -64,7 +64,7 @@ def parse():
                     help="initial pose guess of every track: 'identity' = SURVEY.md 8d's setting (default); 'constant-motion' = the front end's first "
                          "try (FrontEnd.cpp:147-150: last inter-frame motion), modelled as the true motion perturbed by N(0; --init-err x the "
                          "motion's sigma).  Measured on the CPU path (DESIGN.md section 6): neither the evaluations per frame nor the share of "
-                         "frames that end in a wrong minimum (6-11 %) depend on it")
+                         "frames that end in a wrong minimum (6-11 %%) depend on it")
     ap.add_argument("--init-err", type=float, default=0.25, help="sigma of the constant-motion guess's error as a fraction of the motion's sigma")
     ap.add_argument("--textures", default="all", choices=["all", "converging"],
                     help="'all' (default): textures 0 .. 17, nothing left out; 'converging': round 2's hand-picked list (SCENE_SEEDS: the "
@@ -86,6 +86,12 @@ def parse():
                     help="dsm_params.work_queue (default: the library's, dsm_params_default): 0 launch-per-step form; 1 the library's automatic rule "
                          "(single calls of 32 ... ~200 dense frames run as one persistent launch; the one-call-per-step form used here is "
                          "always the launch form); 2 the whole call as one launch of persistent workgroups (two calls per step; its roofline is the whole-call figure)")
+    ap.add_argument("--stream", type=int, default=0, choices=[0, 1],
+                    help="1: the streaming form of the step (dsm_stream_*): every step SUBMITS its B frames (+ keyframe scale problems) to a pool of B resident "
+                         "problems and runs one pass; problems are admitted as slots free up, carried over when they need more rounds than most, and retire "
+                         "individually; after the K-th step the pool is drained inside the timed region.  0: one synchronous dsm_track_and_scale_batch call per step")
+    ap.add_argument("--stream-quantile", default=None, help="with --stream: rounds per level of a pass = this quantile of what retired problems needed (library default 0.75)")
+    ap.add_argument("--stream-rounds", default=None, help="with --stream: fixed rounds per level of a pass, comma separated from level 0 (e.g. 5,6,8,12,16,16)")
     ap.add_argument("--separate-calls", action="store_true", help="dsm_track_batch then dsm_optimize_scale_batch instead of the one dsm_track_and_scale_batch call per step")
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--compact", type=int, default=None, help="dsm_params.compact_tail (default: library default)")
@@ -388,6 +394,179 @@ def one_step(ctx, wl, kf_idx, with_upload=False):
     return good, poses, err, sc, st_track, st_scale
 
 
+class StreamRunner:
+    """bench.py --stream: the steps of the workload through one dsm_stream (B track slots + the keyframes' scale slots)"""
+
+    def __init__(self, args, ctx, wl, kf_idx):
+        from direct_stereo_slam_amd.tracker import Stream
+
+        self.ctx, self.wl, self.kf_idx = ctx, wl, kf_idx
+        self.B = len(wl["trackers"])
+        self.kf = [wl["trackers"][i] for i in kf_idx]
+        self.st = Stream(ctx, self.B, max(1, len(kf_idx)))
+        if args.stream_quantile is not None:
+            q = [float(x) for x in str(args.stream_quantile).split(",")]
+            self.st.set_quantile(q[0] if len(q) == 1 else q)
+        if args.stream_rounds:
+            r = [int(x) for x in args.stream_rounds.split(",")]
+            self.st.set_rounds(0, r)
+        self.owner = {}
+        self.out = {}
+        self.passes = 0
+        self.acc = None  # accumulated statistics of the passes since reset_stats()
+
+    def reset_stats(self):
+        self.acc = dict(evals=np.zeros(6, np.int64), ro=np.zeros(6, np.int64), bytes=0, bytes_scale=0, ms=0.0, l_ms=np.zeros(6), l_sum_ms=np.zeros(6),
+                        dispatches=np.zeros(6, np.int64), launches=np.zeros(6, np.int64), passes=0, retired=0, wall=0.0)
+
+    def _collect(self):
+        n_track = 0
+        for r in self.st.results():
+            self.out[r.ticket] = r
+            n_track += r.kind == 0
+        self.passes += 1
+        if self.acc is not None:
+            self.acc["retired"] += n_track
+            a, b = self.st.stats()
+            acc = self.acc
+            acc["evals"] += np.array(a.evals, np.int64)
+            acc["ro"] += np.array(a.evals_residual_only, np.int64)
+            acc["bytes"] += a.algorithmic_bytes
+            acc["bytes_scale"] += b.algorithmic_bytes
+            acc["ms"] += a.total_ms
+            acc["l_ms"] += np.array(a.eval_kernel_union_ms)
+            acc["l_sum_ms"] += np.array(a.eval_kernel_ms)
+            acc["dispatches"] += np.array(a.eval_dispatches, np.int64)
+            acc["launches"] += np.array(a.launches, np.int64) + np.array(b.launches, np.int64)
+            acc["passes"] += 1
+
+    def step(self, tag):
+        wl, B = self.wl, self.B
+        tk = self.st.submit_track(wl["trackers"], wl["poses0"], np.zeros((B, 2)), wl["nl"] - 1)
+        ts = self.st.submit_scale(self.kf, np.ones(len(self.kf), np.float32), wl["nl"] - 1) if self.kf else []
+        self.owner[tag] = (tk, ts)
+        self.st.advance()
+        self._collect()
+
+    def drain(self):
+        while True:
+            resident, waiting, _ = self.st.counts()
+            if resident == 0 and waiting == 0:
+                return
+            self.st.advance()
+            self._collect()
+
+    def results_of(self, tag):
+        """(good, poses, err, scales) of the step `tag`, in the order of the workload's trackers"""
+        tk, ts = self.owner[tag]
+        good = np.array([bool(self.out[t].good) for t in tk])
+        poses = np.array([list(self.out[t].pose) for t in tk])
+        err = np.array([self.out[t].err for t in ts], np.float32)
+        sc = np.array([self.out[t].scale for t in ts], np.float32)
+        return good, poses, err, sc
+
+    def close(self):
+        self.st.close()
+
+
+def measure_stream(args, ctx, wl, steps, warmup, world):
+    """--stream: W warmup steps + drain, then the timed region = K steps (each: B frames submitted, one pass) + the drain of
+    everything they submitted, bracketed by barrier + synchronize (max over ranks); then instrumented passes in steady state
+    for the roofline of the dominant kernel."""
+    B = len(wl["trackers"])
+    kf_idx = list(range(0, B, args.kf_every))
+    run = StreamRunner(args, ctx, wl, kf_idx)
+    for i in range(warmup):
+        run.step(("w", i))
+    run.drain()
+    ctx.sync()
+    barrier_sync(world)
+    run.reset_stats()
+    p0 = run.passes
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run.step(("t", i))
+    run.drain()
+    ctx.sync()
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    timed = run.acc
+    run.acc = None
+    timed_passes = run.passes - p0
+    good, poses, err, sc = run.results_of(("t", steps - 1))
+    sched = run.st.schedule(0)
+    # roofline of the dominant kernel: steady-state passes (the pool refilled every pass) with HIP events around every eval dispatch
+    for i in range(4):
+        run.step(("r", i))
+    run.reset_stats()
+    ctx.sync()
+    ts0 = time.perf_counter()
+    for i in range(8):  # steady state without instrumentation: frames retired per second while the pool is kept full
+        run.step(("s", i))
+    ctx.sync()
+    steady = dict(run.acc, wall=time.perf_counter() - ts0)
+    ctx.set_timing(True)
+    run.reset_stats()
+    for i in range(4):
+        run.step(("i", i))
+    ctx.set_timing(False)
+    inst = run.acc
+    run.acc = None
+    run.drain()
+    run.close()
+    n0 = len(wl["trackers"][0].get_template(0)[0])
+    bytes_eval0 = 16 * n0 + min(12 * wl["w"] * wl["h"], 48 * n0)
+    layout_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 48 * n0)
+    ro_bytes_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 16 * n0)
+    l0_ms, l0_evals, l0_ro = float(inst["l_ms"][0]), int(inst["evals"][0]), int(inst["ro"][0])
+    l0_launches, l0_disp = int(inst["launches"][0]), int(inst["dispatches"][0])
+    l0_bytes = l0_evals * bytes_eval0
+    achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    achieved_ro_priced = ((l0_evals - l0_ro) * bytes_eval0 + l0_ro * ro_bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    ratio, src, why_not = pmc_traffic_ratio(wl["config"])
+    all_bytes = int(timed["bytes"] + timed["bytes_scale"])
+    whole = all_bytes / dt / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_whole_step": whole / HBM_PEAK_GBS,
+                "frac_full_evals": achieved_ro_priced / HBM_PEAK_GBS,
+                "frac_hbm_actual": achieved * ratio / HBM_PEAK_GBS if ratio is not None else None,
+                "traffic": ratio * l0_bytes / max(1, l0_launches) if ratio is not None else None,
+                "traffic_source": f"{src}: stored rocprofv3 --pmc summary of this command on these kernel sources, scaled to this run's bytes per launch (not re-measured here)" if src else why_not,
+                "kernel": "eval_kernel<pose, LVL0>", "bytes_per_eval": int(bytes_eval0), "bytes_per_residual_only_eval": int(ro_bytes_eval0),
+                "layout_bytes_per_eval": int(layout_eval0), "achieved_on_layout_bytes": achieved * layout_eval0 / bytes_eval0,
+                "evals": l0_evals, "residual_only_evals": l0_ro, "bytes_per_launch": l0_bytes / max(1, l0_launches),
+                "avg_launch_us": 1e3 * float(inst["l_sum_ms"][0]) / max(1, l0_disp), "launches": l0_launches, "dispatches": l0_disp,
+                "stream_groups": args.streams, "kernel_busy_us_per_launch": 1e3 * l0_ms / max(1, l0_launches),
+                "measured_over": "4 steady-state passes of the stream after the timed region (pool refilled before every pass)"}
+    per_level = []
+    for l in range(wl["nl"]):
+        nl_ = len(wl["trackers"][0].get_template(l)[0])
+        by = 16 * nl_ + min(12 * (wl["w"] >> l) * (wl["h"] >> l), 48 * nl_)
+        ms = float(inst["l_ms"][l])
+        per_level.append({"lvl": l, "evals": int(inst["evals"][l]), "residual_only": int(inst["ro"][l]), "launches": int(inst["launches"][l]),
+                          "kernel_ms": round(ms, 4), "GBps": round(int(inst["evals"][l]) * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+    terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
+    frames = B * steps
+    detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": 0, "adaptive_schedule": True, "persistent_coarse": int(wl["params"].persistent_coarse),
+              "streams": args.streams, "form": "stream (dsm_stream_*: continuous admission, one pass per step + drain)",
+              "stream": {"track_slots": B, "scale_slots": max(1, len(kf_idx)), "passes_in_timed_region": int(timed_passes),
+                         "rounds_per_level_of_a_pass": sched["rounds"][:wl["nl"]], "quantile": args.stream_quantile if args.stream_quantile is not None else "library default",
+                         "frames_submitted": frames, "ms_per_pass": 1e3 * dt / max(1, timed_passes),
+                         "steady_state": {"frames_per_s": steady["retired"] / steady["wall"], "passes": int(steady["passes"]), "frames_retired": int(steady["retired"]),
+                                          "ms_per_pass": 1e3 * steady["wall"] / max(1, steady["passes"]),
+                                          "what": "8 passes after the timed region with the pool refilled before every pass: frames retired / wall time (no ramp-up, no drain)"}},
+              "launch_pairs_per_step": int(timed["launches"].sum() / max(1, steps)), "readbacks_per_step": timed_passes / max(1, steps),
+              "evals_per_frame_by_level": [float(timed["evals"][l]) / frames for l in range(wl["nl"])],
+              "algorithmic_MB_per_frame": all_bytes / frames / 1e6,
+              "whole_step_GBps": whole,
+              "pose_eval_kernels_by_level": per_level, "max_abs_translation_error_m": float(terr_all.max()),
+              "distinct_frames": int(wl["distinct_frames"]), "textures": int(wl["textures"]),
+              "initial_guess": args.init if args.init == "identity" else f"constant-motion (error sigma {args.init_err} x motion sigma)", "texture_list": args.textures,
+              "fixed_schedule": int(wl["params"].fixed_schedule), "work_queue": int(wl["params"].work_queue),
+              "frames_with_translation_error_above_1cm": int((terr_all > 0.01).sum()), "all_tracked": bool(good.all())}
+    return dict(dt=dt, value=world * frames / dt, ms_per_step=1e3 * dt / steps, good=good, poses=poses, roofline=roofline, detail=detail, n0=n0)
+
+
 def kernel_source_sha():
     """sha256 over the sources the eval kernels are built from: a stored PMC profile only speaks for the kernel it profiled"""
     import hashlib
@@ -425,6 +604,8 @@ def pmc_traffic_ratio(config):
 def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
     """W warmup steps, then exactly `steps` timed steps bracketed by barrier + synchronize on both sides (max over ranks),
     then ONE extra instrumented step for the per-dispatch roofline of the dominant kernel."""
+    if args.stream and not with_upload:
+        return measure_stream(args, ctx, wl, steps, warmup, world)
     B = len(wl["trackers"])
     kf_idx = list(range(0, B, args.kf_every))
     for _ in range(warmup):
@@ -494,6 +675,7 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
         per_level.append({"lvl": l, "evals": int(stt.evals[l]), "residual_only": int(stt.evals_residual_only[l]), "launches": int(stt.launches[l]),
                           "kernel_ms": round(ms, 4), "GBps": round(stt.evals[l] * by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
     all_bytes = stt.algorithmic_bytes + sts.algorithmic_bytes
+    roofline["frac_whole_step"] = all_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS  # every evaluation of the step on SURVEY.md 8d's bytes / the timed step
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": int(stt.queue_blocks), "adaptive_schedule": not args.no_adaptive,
               "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams,

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSM_HOTPATH_LIB: developer override used for A/B builds of the same sources (e.g. other compiler flags)
 LIB_PATH = os.environ.get("DSM_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libdsm_hotpath.so")
 MAX_LEVELS = 6
-ABI_VERSION = 2  # DSM_ABI_VERSION of the header the structures below mirror
+ABI_VERSION = 3  # DSM_ABI_VERSION of the header the structures below mirror
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -64,6 +64,23 @@ class Stats(C.Structure):
     ]
 
 
+class StreamResult(C.Structure):
+    _fields_ = [
+        ("ticket", C.c_uint64),
+        ("kind", C.c_int),
+        ("good", C.c_int),
+        ("status", C.c_int),
+        ("passes", C.c_int),
+        ("pose", C.c_double * 7),
+        ("aff", C.c_double * 2),
+        ("last_residuals", C.c_double * MAX_LEVELS),
+        ("flow", C.c_double * 3),
+        ("scale", C.c_float),
+        ("err", C.c_float),
+        ("evals", C.c_int64 * MAX_LEVELS),
+    ]
+
+
 class LoopJob(C.Structure):
     _fields_ = [
         ("n_kf", C.c_int), ("kf_ids", c_int_p), ("kf_pose_wc", c_double_p), ("cur_cw", c_double_p),
@@ -87,6 +104,19 @@ SYMBOLS = {
     "dsm_abi_version": (C.c_int, []),
     "dsm_tracker_upload_intensity": (C.c_int, [_vp, C.c_int, _pp_f, C.c_float]),
     "dsm_params_default": (None, [C.POINTER(Params)]),
+    "dsm_params_default_sized": (C.c_int, [C.POINTER(Params), C.c_size_t]),
+    "dsm_stream_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dsm_stream_destroy": (C.c_int, [_vp]),
+    "dsm_stream_submit_track": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_double_p, c_double_p, C.c_int, c_double_p, C.POINTER(C.c_uint64)]),
+    "dsm_stream_submit_scale": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_float_p, C.c_int, C.POINTER(C.c_uint64)]),
+    "dsm_stream_advance": (C.c_int, [_vp]),
+    "dsm_stream_drain": (C.c_int, [_vp]),
+    "dsm_stream_results": (C.c_int, [_vp, C.c_int, C.POINTER(StreamResult), c_int_p]),
+    "dsm_stream_counts": (C.c_int, [_vp, c_int_p, c_int_p, c_int_p]),
+    "dsm_stream_set_quantile": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "dsm_stream_set_rounds": (C.c_int, [_vp, C.c_int, c_int_p]),
+    "dsm_stream_get_stats": (C.c_int, [_vp, C.POINTER(Stats), C.POINTER(Stats)]),
+    "dsm_stream_get_schedule": (C.c_int, [_vp, C.c_int, c_int_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dsm_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "dsm_context_destroy": (C.c_int, [_vp]),
     "dsm_context_sync": (C.c_int, [_vp]),

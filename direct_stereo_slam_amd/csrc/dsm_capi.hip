@@ -206,6 +206,19 @@ extern "C" {
 const char *dsm_last_error(void) { return g_err.c_str(); }
 int dsm_abi_version(void) { return DSM_ABI_VERSION; }
 
+int dsm_params_default_sized(dsm_params *p, size_t caller_size) {
+  if (!p || caller_size < sizeof(size_t)) return invalid("dsm_params_default_sized: null struct or a size below its first member");
+  dsm_params d;
+  dsm_params_default(&d);
+  memcpy(p, &d, caller_size < sizeof d ? caller_size : sizeof d); // never past the end of the caller's struct
+  p->struct_size = caller_size;
+  if (caller_size != sizeof d) {
+    set_error("dsm_params: the caller was built against another version of dsm_hotpath.h (sizeof(dsm_params) differs)");
+    return DSM_ERR_INVALID;
+  }
+  return DSM_OK;
+}
+
 void dsm_params_default(dsm_params *p) {
   memset(p, 0, sizeof *p);
   p->struct_size = sizeof(dsm_params);
@@ -894,7 +907,9 @@ int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pt
 }
 
 // ---- common batch plumbing ------------------------------------------------------------------
-static int check_ready(dsm_tracker *t, int mode) {
+} // extern "C"
+namespace dsm {
+int check_ready(dsm_tracker *t, int mode) {
   if (!t->have_k || !t->have_ref || !t->have_frame[mode == 1 ? 1 : 0]) {
     set_error(mode ? "optimize_scale needs make_k, set_ref and the right frame (slot 1)"
                    : "track needs make_k, set_ref and the new left frame (slot 0)");
@@ -902,6 +917,8 @@ static int check_ready(dsm_tracker *t, int mode) {
   }
   return DSM_OK;
 }
+} // namespace dsm
+extern "C" {
 
 // ts: n trackers of a call in mode `mode`, followed by n2 trackers of the companion segment in mode `mode2`
 static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mode, int n2 = 0, int mode2 = 1) {
@@ -927,7 +944,9 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
   return DSM_OK;
 }
 
-static hipEvent_t get_event(dsm_context *ctx, size_t idx) {
+} // extern "C"
+namespace dsm {
+hipEvent_t get_event(dsm_context *ctx, size_t idx) {
   while (ctx->ev_pool.size() <= idx) {
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;
@@ -935,6 +954,57 @@ static hipEvent_t get_event(dsm_context *ctx, size_t idx) {
   }
   return ctx->ev_pool[idx];
 }
+
+// streams of the segments of a launch schedule: `ng` stream groups (the context's stream + ng - 1 extra ones) and, on
+// request, the companion stream
+int ensure_streams(dsm_context *ctx, int ng, bool companion) {
+  if (companion && !ctx->companion_stream) {
+    DSM_HIP(hipStreamCreateWithFlags(&ctx->companion_stream, hipStreamNonBlocking));
+    DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
+  }
+  while ((int)ctx->extra_streams.size() < ng - 1) {
+    hipStream_t st;
+    DSM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->extra_streams.push_back(st);
+    hipEvent_t ev;
+    DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->join_events.push_back(ev);
+  }
+  return DSM_OK;
+}
+
+// timing enabled: per-level sums and interval unions of the eval dispatches bracketed by ev_pool[2 i], ev_pool[2 i + 1]
+// (level ev_lvl[i]), relative to ev_total[0] (the stream groups' dispatches overlap; the union is the time during which the
+// level's kernel ran at all)
+void collect_eval_timing(dsm_context *ctx, const std::vector<int> &ev_lvl, int nlevels, dsm_stats &st) {
+  std::vector<std::pair<float, float>> iv[DSM_MAX_LEVELS];
+  for (size_t i = 0; i < ev_lvl.size(); i++) {
+    float m = 0, a = 0;
+    if (hipEventElapsedTime(&m, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&a, ctx->ev_total[0], ctx->ev_pool[2 * i]) == hipSuccess) {
+      st.eval_kernel_ms[ev_lvl[i]] += m;
+      st.eval_dispatches[ev_lvl[i]]++;
+      iv[ev_lvl[i]].push_back(std::make_pair(a, a + m));
+    }
+  }
+  for (int l = 0; l < nlevels; l++) {
+    std::sort(iv[l].begin(), iv[l].end());
+    double busy = 0, cs = 0, ce = -1;
+    for (auto &p : iv[l]) {
+      if (ce < 0) {
+        cs = p.first, ce = p.second;
+      } else if (p.first > ce) {
+        busy += ce - cs;
+        cs = p.first, ce = p.second;
+      } else if (p.second > ce)
+        ce = p.second;
+    }
+    if (ce >= 0) busy += ce - cs;
+    st.eval_kernel_union_ms[l] = busy;
+  }
+}
+} // namespace dsm
+extern "C" {
 
 // runs the device LM state machine for a batch (mode 0 = trackNewestCoarse, 1 = optimizeScale, 2 = loop-closure pose).
 // n2 > 0: problems [n, n + n2) form a COMPANION segment in mode2 (dsm_track_and_scale_batch: the keyframes' scale
@@ -1044,19 +1114,11 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   }
   int *sched = ctx->sched[mode], *sched2 = ctx->sched[mode2];
   const int *bulk = ctx->sched_bulk[mode], *bulk2 = ctx->sched_bulk[mode2];
-  if (n2 > 0 && !ctx->companion_stream) {
-    DSM_HIP(hipStreamCreateWithFlags(&ctx->companion_stream, hipStreamNonBlocking));
-    DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
-  }
   int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
   if (ng > n) ng = n;
-  while ((int)ctx->extra_streams.size() < ng - 1) {
-    hipStream_t st;
-    DSM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    ctx->extra_streams.push_back(st);
-    hipEvent_t ev;
-    DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    ctx->join_events.push_back(ev);
+  {
+    const int rc = ensure_streams(ctx, ng, n2 > 0);
+    if (rc) return rc;
   }
   int top = coarsest, top2 = n2 > 0 ? coarsest : -1;
   if (!use_queue && P.persistent_coarse > 0) {
@@ -1272,35 +1334,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   float ms = 0;
   DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
   ctx->stats.total_ms = ms;
-  if (ctx->timing) {
-    // per dispatch: duration, and [start, end] relative to the start of the call for the per-level union
-    // (the stream groups' dispatches overlap; the union is the time during which the level's kernel ran at all)
-    std::vector<std::pair<float, float>> iv[DSM_MAX_LEVELS];
-    for (size_t i = 0; i < ev_lvl.size(); i++) {
-      float m = 0, a = 0;
-      if (hipEventElapsedTime(&m, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]) == hipSuccess &&
-          hipEventElapsedTime(&a, ctx->ev_total[0], ctx->ev_pool[2 * i]) == hipSuccess) {
-        ctx->stats.eval_kernel_ms[ev_lvl[i]] += m;
-        ctx->stats.eval_dispatches[ev_lvl[i]]++;
-        iv[ev_lvl[i]].push_back(std::make_pair(a, a + m));
-      }
-    }
-    for (int l = 0; l < nlevels; l++) {
-      std::sort(iv[l].begin(), iv[l].end());
-      double busy = 0, cs = 0, ce = -1;
-      for (auto &p : iv[l]) {
-        if (ce < 0) {
-          cs = p.first, ce = p.second;
-        } else if (p.first > ce) {
-          busy += ce - cs;
-          cs = p.first, ce = p.second;
-        } else if (p.second > ce)
-          ce = p.second;
-      }
-      if (ce >= 0) busy += ce - cs;
-      ctx->stats.eval_kernel_union_ms[l] = busy;
-    }
-  }
+  if (ctx->timing) collect_eval_timing(ctx, ev_lvl, nlevels, ctx->stats);
   int need[DSM_MAX_LEVELS] = {0}, need2[DSM_MAX_LEVELS] = {0};
   ctx->stats2.total_ms = ms;
   for (int i = 0; i < N; i++) {

@@ -109,4 +109,8 @@ int ensure_batch_capacity(dsm_context *ctx, int nprob, int partial_stride);
 int ensure_stage(dsm_context *ctx, size_t floats);
 int sync_desc(dsm_tracker *t);
 int sync_descs(dsm_context *ctx, dsm_tracker *const *ts, int n);
+int check_ready(dsm_tracker *t, int mode);
+hipEvent_t get_event(dsm_context *ctx, size_t idx);
+int ensure_streams(dsm_context *ctx, int ng, bool companion);
+void collect_eval_timing(dsm_context *ctx, const std::vector<int> &ev_lvl, int nlevels, dsm_stats &st);
 } // namespace dsm

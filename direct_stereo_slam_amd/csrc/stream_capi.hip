@@ -1,0 +1,569 @@
+// stream_capi.hip -- the streaming (continuous-admission) form of the batched track / scale calls (dsm_stream_*).
+//
+// dsm_track_and_scale_batch is a synchronous call: every problem of the batch is taken from its first evaluation to its
+// last before the call returns, so the lock-step launch schedule runs as many (evaluate, step) rounds per level as the
+// SLOWEST problem needs -- 52 rounds on levels 2 and 3 of 512 distinct frames where the median problem needs 6 and 10 --
+// and a third of the call is the dependency chain of a few dozen stragglers with the chip nearly idle.  The
+// LM loop of a frame is sequential (TrackerAndScaler.cpp:505-593); frames of different sequences are independent
+// (FrontEnd.cpp:585-686): the only parallelism there is lies ACROSS frames, and nothing says they must start and end together.
+//
+// A dsm_stream is a pool of resident LM problems (slots) advanced in PASSES.  One pass = one sweep down the pyramid,
+// coarsest level first, with a fixed number of rounds per level -- the rounds MOST problems need (a quantile of what
+// recently retired problems took).  A problem that has not finished its level when the pass moves on simply stays where it
+// is -- its LMState is resident in device memory and resumable by construction -- and is CARRIED: in the next pass it
+// rides with the newly admitted problems' launches at that level, so a straggler's extra rounds cost no launches of their
+// own.  Problems retire individually at the end of the pass in which they finish; the slots they free are refilled from the
+// waiting queue before the next pass.  No launch in a pass depends on a host read-back (the launch list is fixed when the
+// pass starts), the state is read back once per pass.
+//
+// Same evaluations, same LM steps, same partial order per problem as the batch form: results are bit-identical
+// (tests/test_stream.py).  The work-queue kernel -- every problem at its own pace inside one launch -- was the other
+// candidate for this; measured with the tail amortised over 2048 frames it runs at 42.7 k frames/s against 48.5 k for the
+// launch form (profiles/r04_queue_form_b2048.json, r04_launch_form_b2048.json): its per-item cost is there in steady
+// state too, so the streaming form is built on the launches.
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <limits>
+#include <vector>
+
+#include "dsm_internal.hpp"
+
+using namespace dsm;
+
+namespace {
+
+enum { SLOT_FREE = 0, SLOT_NEW = 1, SLOT_RUNNING = 2 };
+
+struct Slot {
+  int state = SLOT_FREE;
+  uint64_t ticket = 0;
+  dsm_tracker *trk = nullptr;
+  int lvl = 0;    // NEW: coarsest level; RUNNING: the level the problem stood at after the last pass
+  int passes = 0; // passes it has been resident for
+  double pose0[7] = {0, 0, 0, 1, 0, 0, 0}, aff0[2] = {0, 0};
+  long long seen_evals[DSM_MAX_LEVELS] = {}, seen_ro[DSM_MAX_LEVELS] = {}; // evaluations already counted in the statistics
+};
+
+struct Waiting {
+  uint64_t ticket;
+  dsm_tracker *trk;
+  StartInfo start;
+};
+
+struct Seg {
+  hipStream_t st;
+  int i0, i1, mode;
+  bool companion;
+  int rows[DSM_MAX_LEVELS];
+};
+
+template <typename T>
+int alloc_dev(T **p, size_t n) {
+  *p = nullptr;
+  DSM_HIP(hipMalloc(p, n * sizeof(T)));
+  return DSM_OK;
+}
+template <typename T>
+int alloc_pinned(T **p, size_t n) {
+  *p = nullptr;
+  DSM_HIP(hipHostMalloc(p, n * sizeof(T), hipHostMallocDefault));
+  return DSM_OK;
+}
+
+int invalid(const char *msg) {
+  set_error(msg);
+  return DSM_ERR_INVALID;
+}
+
+constexpr size_t kHistCap = 4096; // retired problems whose round counts the schedule looks at
+
+} // namespace
+
+struct dsm_stream {
+  dsm_context *ctx = nullptr;
+  int cap[2] = {0, 0}; // slots of mode 0 (trackNewestCoarse) / mode 1 (optimizeScale); track slots come first
+  int N = 0;
+  int w = 0, h = 0, nlevels = 0; // geometry of the first tracker submitted; every tracker of the stream must share it
+  int partial_stride = 0;
+  TrackerDev **d_tracker_ptrs = nullptr, **h_tracker_ptrs = nullptr;
+  LMState *d_states = nullptr, *h_states = nullptr;
+  float *d_partials = nullptr;
+  StartInfo *d_start = nullptr, *h_start = nullptr;
+  int *d_status = nullptr;
+  int *d_tickets = nullptr;
+  int *d_rowmap = nullptr, *h_rowmap = nullptr; // [DSM_MAX_LEVELS + 1][N]: rows per level (relative to their segment), then the new slots (relative to their mode's base)
+  std::vector<Slot> slots;
+  std::deque<Waiting> waiting[2];
+  std::deque<dsm_stream_result> done;
+  uint64_t next_ticket = 1;
+  double quantile[DSM_MAX_LEVELS] = {0.75, 0.75, 0.75, 0.75, 0.75, 0.75};
+  int fixed_rounds[2][DSM_MAX_LEVELS] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}}; // > 0: overrides the learnt schedule
+  std::vector<int> hist[2][DSM_MAX_LEVELS];
+  size_t hist_pos[2] = {0, 0};
+  int rounds[2][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}};
+  int rounds_max[2][DSM_MAX_LEVELS] = {{12, 22, 52, 52, 52, 52}, {8, 8, 8, 8, 8, 8}}; // the most any retired problem needed (+ 1)
+  dsm_stats stats[2]{};
+  long long passes = 0, retired[2] = {0, 0}, carried_slot_passes = 0;
+};
+
+static void stream_free(dsm_stream *s) {
+  hipFree(s->d_tracker_ptrs);
+  if (s->h_tracker_ptrs) hipHostFree(s->h_tracker_ptrs);
+  hipFree(s->d_states);
+  if (s->h_states) hipHostFree(s->h_states);
+  hipFree(s->d_partials);
+  hipFree(s->d_start);
+  if (s->h_start) hipHostFree(s->h_start);
+  hipFree(s->d_status);
+  hipFree(s->d_tickets);
+  hipFree(s->d_rowmap);
+  if (s->h_rowmap) hipHostFree(s->h_rowmap);
+  delete s;
+}
+
+// the partials need the trackers' geometry: allocated on the first submission
+static int stream_bind_geometry(dsm_stream *s, dsm_tracker *t) {
+  if (s->partial_stride) {
+    if (t->w != s->w || t->h != s->h || t->nlevels != s->nlevels) return invalid("dsm_stream: all trackers of a stream must share image size and levels");
+    return DSM_OK;
+  }
+  DSM_HIP(hipSetDevice(s->ctx->device));
+  s->w = t->w, s->h = t->h, s->nlevels = t->nlevels;
+  const int ps = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
+  int rc = alloc_dev(&s->d_partials, (size_t)s->N * ps);
+  if (rc) return rc;
+  s->partial_stride = ps;
+  return DSM_OK;
+}
+
+extern "C" {
+
+int dsm_stream_create(dsm_context *ctx, int track_slots, int scale_slots, dsm_stream **out) {
+  if (!ctx || !out || track_slots < 0 || scale_slots < 0 || track_slots + scale_slots < 1) return invalid("dsm_stream_create: bad argument");
+  *out = nullptr;
+  DSM_HIP(hipSetDevice(ctx->device));
+  dsm_stream *s = new dsm_stream();
+  s->ctx = ctx;
+  s->cap[0] = track_slots, s->cap[1] = scale_slots;
+  const int N = s->N = track_slots + scale_slots;
+  s->slots.resize(N);
+  int rc = DSM_OK;
+  if (!rc) rc = alloc_dev(&s->d_tracker_ptrs, N);
+  if (!rc) rc = alloc_pinned(&s->h_tracker_ptrs, N);
+  if (!rc) rc = alloc_dev(&s->d_states, N);
+  if (!rc) rc = alloc_pinned(&s->h_states, N);
+  if (!rc) rc = alloc_dev(&s->d_start, N);
+  if (!rc) rc = alloc_pinned(&s->h_start, N);
+  if (!rc) rc = alloc_dev(&s->d_status, 2 * (size_t)N);
+  if (!rc) rc = alloc_dev(&s->d_tickets, N);
+  if (!rc) rc = alloc_dev(&s->d_rowmap, (size_t)(DSM_MAX_LEVELS + 1) * N);
+  if (!rc) rc = alloc_pinned(&s->h_rowmap, (size_t)(DSM_MAX_LEVELS + 1) * N);
+  if (!rc) {
+    hipError_t e = hipMemsetAsync(s->d_tickets, 0, sizeof(int) * N, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_states, 0, sizeof(LMState) * N, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "dsm_stream_create: clearing the slot arrays", __FILE__, __LINE__);
+  }
+  if (rc) {
+    stream_free(s);
+    return rc;
+  }
+  memset(s->h_tracker_ptrs, 0, sizeof(TrackerDev *) * N);
+  memset(s->h_start, 0, sizeof(StartInfo) * N);
+  *out = s;
+  return DSM_OK;
+}
+
+int dsm_stream_destroy(dsm_stream *s) {
+  if (!s) return DSM_OK;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  stream_free(s);
+  return DSM_OK;
+}
+
+int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q) {
+  if (!s || !(q > 0.0 && q <= 1.0) || lvl >= DSM_MAX_LEVELS) return invalid("dsm_stream_set_quantile: level < DSM_MAX_LEVELS (negative: all), 0 < q <= 1");
+  for (int l = 0; l < DSM_MAX_LEVELS; l++)
+    if (lvl < 0 || l == lvl) s->quantile[l] = q;
+  return DSM_OK;
+}
+
+int dsm_stream_set_rounds(dsm_stream *s, int mode, const int *rounds_per_level) {
+  if (!s || mode < 0 || mode > 1) return invalid("dsm_stream_set_rounds: bad argument");
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) s->fixed_rounds[mode][l] = rounds_per_level ? rounds_per_level[l] : 0;
+  return DSM_OK;
+}
+
+static int submit_common(dsm_stream *s, int mode, int n, dsm_tracker *const *ts, int coarsest, uint64_t *tickets_out) {
+  if (!s || n < 0 || (n && !ts)) return invalid("dsm_stream_submit: bad argument");
+  if (s->cap[mode] == 0 && n) return invalid("dsm_stream_submit: the stream has no slots of this kind");
+  for (int i = 0; i < n; i++) {
+    dsm_tracker *t = ts[i];
+    if (!t || t->ctx != s->ctx) return invalid("dsm_stream_submit: tracker does not belong to the stream's context");
+    int rc = stream_bind_geometry(s, t);
+    if (rc) return rc;
+    if (coarsest < 0 || coarsest >= t->nlevels) return invalid("coarsest level out of range"); // :457 / :856
+    rc = check_ready(t, mode);
+    if (rc) return rc;
+  }
+  (void)tickets_out;
+  return DSM_OK;
+}
+
+int dsm_stream_submit_track(dsm_stream *s, int n, dsm_tracker *const *ts, const double *pose0, const double *aff0, int coarsest_lvl,
+                            const double *min_res_for_abort, uint64_t *tickets_out) {
+  if (n && (!pose0 || !aff0)) return invalid("dsm_stream_submit_track: null pose/aff");
+  int rc = submit_common(s, 0, n, ts, coarsest_lvl, tickets_out);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    Waiting wq;
+    wq.ticket = s->next_ticket++;
+    wq.trk = ts[i];
+    StartInfo &I = wq.start;
+    memset(&I, 0, sizeof I);
+    memcpy(I.pose, pose0 + 7 * i, sizeof I.pose);
+    memcpy(I.aff, aff0 + 2 * i, sizeof I.aff);
+    for (int l = 0; l < DSM_MAX_LEVELS; l++)
+      I.min_res[l] = min_res_for_abort ? min_res_for_abort[DSM_MAX_LEVELS * i + l] : std::numeric_limits<double>::quiet_NaN();
+    I.scale = 1.0f;
+    I.coarsest = coarsest_lvl;
+    if (tickets_out) tickets_out[i] = wq.ticket;
+    s->waiting[0].push_back(wq);
+  }
+  return DSM_OK;
+}
+
+int dsm_stream_submit_scale(dsm_stream *s, int n, dsm_tracker *const *ts, const float *scale0, int coarsest_lvl, uint64_t *tickets_out) {
+  if (n && !scale0) return invalid("dsm_stream_submit_scale: null scale");
+  int rc = submit_common(s, 1, n, ts, coarsest_lvl, tickets_out);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    Waiting wq;
+    wq.ticket = s->next_ticket++;
+    wq.trk = ts[i];
+    StartInfo &I = wq.start;
+    memset(&I, 0, sizeof I);
+    I.pose[3] = 1.0;
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) I.min_res[l] = std::numeric_limits<double>::quiet_NaN();
+    I.scale = scale0[i];
+    I.coarsest = coarsest_lvl;
+    if (tickets_out) tickets_out[i] = wq.ticket;
+    s->waiting[1].push_back(wq);
+  }
+  return DSM_OK;
+}
+
+int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *results_out) {
+  if (!s) return invalid("null stream");
+  int r = 0;
+  for (const Slot &sl : s->slots) r += sl.state != SLOT_FREE;
+  if (resident_out) *resident_out = r;
+  if (waiting_out) *waiting_out = (int)(s->waiting[0].size() + s->waiting[1].size());
+  if (results_out) *results_out = (int)s->done.size();
+  return DSM_OK;
+}
+
+int dsm_stream_results(dsm_stream *s, int max_results, dsm_stream_result *out, int *n_out) {
+  if (!s || max_results < 0 || (max_results && !out) || !n_out) return invalid("dsm_stream_results: bad argument");
+  int k = 0;
+  while (k < max_results && !s->done.empty()) {
+    out[k++] = s->done.front();
+    s->done.pop_front();
+  }
+  *n_out = k;
+  return DSM_OK;
+}
+
+int dsm_stream_get_stats(dsm_stream *s, dsm_stats *track_out, dsm_stats *scale_out) {
+  if (!s) return invalid("null stream");
+  if (track_out) *track_out = s->stats[0];
+  if (scale_out) *scale_out = s->stats[1];
+  return DSM_OK;
+}
+
+int dsm_stream_get_schedule(dsm_stream *s, int mode, int *rounds_out, long long *passes_out, long long *retired_out, long long *carried_out) {
+  if (!s || mode < 0 || mode > 1) return invalid("dsm_stream_get_schedule: bad argument");
+  if (rounds_out)
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) rounds_out[l] = s->rounds[mode][l];
+  if (passes_out) *passes_out = s->passes;
+  if (retired_out) *retired_out = s->retired[mode];
+  if (carried_out) *carried_out = s->carried_slot_passes;
+  return DSM_OK;
+}
+
+// One pass.  (i) waiting problems are admitted into free slots, (ii) their state machines are started, (iii) every level
+// from the coarsest a resident problem stands on down to level 0 gets its rounds -- compact launches over the slots that
+// can be at that level in this pass: the new ones and the carried ones standing at or above it -- (iv) the states are read
+// back once; problems that terminated retire (dsm_stream_results), the others are carried.
+int dsm_stream_advance(dsm_stream *s) {
+  if (!s) return invalid("null stream");
+  dsm_context *ctx = s->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  const int N = s->N, cap0 = s->cap[0];
+  int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
+  if (ng > cap0) ng = cap0 > 0 ? cap0 : 1;
+  // ---- (i) admission: a free slot of the problem's kind, in the stream group with the fewest resident problems ----
+  std::vector<Seg> segs;
+  if (cap0 > 0)
+    for (int g = 0; g < ng; g++) {
+      const int g0 = (int)((long long)cap0 * g / ng), g1 = (int)((long long)cap0 * (g + 1) / ng);
+      if (g1 > g0) segs.push_back(Seg{nullptr, g0, g1, 0, false, {}});
+    }
+  const int n_track_segs = (int)segs.size();
+  if (s->cap[1] > 0) segs.push_back(Seg{nullptr, cap0, N, 1, true, {}});
+  std::vector<dsm_tracker *> fresh;
+  int n_new[2] = {0, 0};
+  for (int mode = 0; mode < 2; mode++) {
+    std::deque<Waiting> &wq = s->waiting[mode];
+    if (wq.empty()) continue;
+    const int sg0 = mode == 0 ? 0 : n_track_segs, sg1 = mode == 0 ? n_track_segs : (int)segs.size();
+    std::vector<int> live(segs.size(), 0), cursor(segs.size(), 0);
+    for (int si = sg0; si < sg1; si++) {
+      cursor[si] = segs[si].i0;
+      for (int i = segs[si].i0; i < segs[si].i1; i++) live[si] += s->slots[i].state != SLOT_FREE;
+    }
+    while (!wq.empty()) {
+      int best = -1;
+      for (int si = sg0; si < sg1; si++)
+        if (live[si] < segs[si].i1 - segs[si].i0 && (best < 0 || live[si] < live[best])) best = si;
+      if (best < 0) break; // every slot of this kind is taken
+      int &c = cursor[best];
+      while (s->slots[c].state != SLOT_FREE) c++;
+      const Waiting &wt = wq.front();
+      Slot &sl = s->slots[c];
+      sl = Slot();
+      sl.state = SLOT_NEW;
+      sl.ticket = wt.ticket;
+      sl.trk = wt.trk;
+      sl.lvl = wt.start.coarsest;
+      memcpy(sl.pose0, wt.start.pose, sizeof sl.pose0);
+      memcpy(sl.aff0, wt.start.aff, sizeof sl.aff0);
+      s->h_start[c] = wt.start;
+      s->h_tracker_ptrs[c] = wt.trk->d_desc;
+      s->h_rowmap[(size_t)DSM_MAX_LEVELS * N + (mode == 0 ? 0 : cap0) + n_new[mode]] = c - (mode == 0 ? 0 : cap0);
+      n_new[mode]++;
+      fresh.push_back(wt.trk);
+      live[best]++;
+      wq.pop_front();
+    }
+  }
+  int n_live = 0, top = -1, top2 = -1;
+  const dsm_params *P = nullptr;
+  for (int i = 0; i < N; i++) {
+    const Slot &sl = s->slots[i];
+    if (sl.state == SLOT_FREE) continue;
+    n_live++;
+    if (!P) P = &sl.trk->params;
+    if (i < cap0)
+      top = sl.lvl > top ? sl.lvl : top;
+    else
+      top2 = sl.lvl > top2 ? sl.lvl : top2;
+  }
+  memset(&s->stats[0], 0, sizeof(dsm_stats));
+  memset(&s->stats[1], 0, sizeof(dsm_stats));
+  if (n_live == 0) return DSM_OK;
+  // Nothing is waiting and the pool is at most a quarter full: what is resident is the END of the job -- nothing rides with
+  // the stragglers any more, so a pass gives every level the rounds the slowest retired problem needed (they finish in one or
+  // two passes instead of one level per pass) and evaluates and steps in one fused launch per round.
+  const bool draining = s->waiting[0].empty() && s->waiting[1].empty() && 4 * n_live <= N;
+  const int nlevels = s->nlevels;
+  int rc = ensure_streams(ctx, ng, s->cap[1] > 0);
+  if (rc) return rc;
+  for (int si = 0; si < (int)segs.size(); si++) // (a stream without track slots runs its scale segment on the context's stream)
+    segs[si].st = si == 0 ? ctx->stream : segs[si].companion ? ctx->companion_stream : ctx->extra_streams[si - 1];
+  if (!fresh.empty()) {
+    rc = sync_descs(ctx, fresh.data(), (int)fresh.size());
+    if (rc) return rc;
+  }
+  DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
+  // ---- row maps: level L of segment sg = its slots that can stand on level L during this pass ----
+  int grid_x[DSM_MAX_LEVELS], level_pts[DSM_MAX_LEVELS];
+  for (int L = 0; L < nlevels; L++) {
+    int max_chunks = 1, max_n = 0;
+    for (int i = 0; i < N; i++) {
+      const Slot &sl = s->slots[i];
+      if (sl.state == SLOT_FREE) continue;
+      const int n_l = sl.trk->desc.lv[L].n, c = num_chunks(n_l);
+      if (c > max_chunks) max_chunks = c;
+      if (n_l > max_n) max_n = n_l;
+    }
+    grid_x[L] = max_chunks < 8 ? max_chunks : (max_chunks + 7) & ~7;
+    level_pts[L] = max_n;
+    for (Seg &sg : segs) {
+      int r = 0;
+      for (int i = sg.i0; i < sg.i1; i++)
+        if (s->slots[i].state != SLOT_FREE && s->slots[i].lvl >= L) s->h_rowmap[(size_t)L * N + sg.i0 + r++] = i - sg.i0;
+      sg.rows[L] = r;
+    }
+  }
+  DSM_HIP(hipMemcpyAsync(s->d_rowmap, s->h_rowmap, sizeof(int) * (size_t)(DSM_MAX_LEVELS + 1) * N, hipMemcpyHostToDevice, ctx->stream));
+  // ---- (ii) start the admitted problems (LM_OP_START over the list of new slots of each kind) ----
+  if (n_new[0] + n_new[1] > 0) {
+    DSM_HIP(hipMemcpyAsync(s->d_tracker_ptrs, s->h_tracker_ptrs, sizeof(TrackerDev *) * N, hipMemcpyHostToDevice, ctx->stream));
+    DSM_HIP(hipMemcpyAsync(s->d_start, s->h_start, sizeof(StartInfo) * N, hipMemcpyHostToDevice, ctx->stream));
+    for (int mode = 0; mode < 2; mode++) {
+      if (!n_new[mode]) continue;
+      const int base = mode == 0 ? 0 : cap0;
+      launch_lm(ctx->stream, mode, LM_OP_START, 0, n_new[mode], s->d_tracker_ptrs + base, s->d_states + base,
+                s->d_partials + (size_t)base * s->partial_stride, s->partial_stride, s->d_start + base, nullptr, s->d_status + 2 * base, false,
+                s->d_rowmap + (size_t)DSM_MAX_LEVELS * N + base);
+    }
+  }
+  // ---- (iii) the pass ----
+  size_t ev_used = 0;
+  std::vector<int> ev_lvl;
+  auto launch_round = [&](const Seg &sg, int L, int k) -> int {
+    const int rows = sg.rows[L];
+    if (rows == 0) return DSM_OK;
+    const int *rowmap = s->d_rowmap + (size_t)L * N + sg.i0;
+    // the speculative second candidate, the fused LM step and the split of the residual-only evaluations: the rules of
+    // run_lm_batch (dsm_capi.hip), applied to this launch's rows
+    const bool spec = P->fixed_schedule <= 0 && (P->speculate >= 2 || (P->speculate == 1 && level_pts[L] <= 8192 && (long long)rows * level_pts[L] <= 1000000ll));
+    const bool fused = L > 0 && (P->fuse_lm >= 2 || (P->fuse_lm == 1 && (rows <= 8 || (draining && rows <= 128))));
+    const bool split_ro = !sg.companion && !fused && k > 0 && level_pts[L] >= 100000 && (long long)rows * level_pts[L] >= 8000000ll;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (ctx->timing && !sg.companion) {
+      ea = get_event(ctx, ev_used++);
+      eb = get_event(ctx, ev_used++);
+      ev_lvl.push_back(L);
+      if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
+    }
+    float *part = s->d_partials + (size_t)sg.i0 * s->partial_stride;
+    launch_eval(sg.st, sg.mode, L, grid_x[L], rows, s->d_tracker_ptrs + sg.i0, s->d_states + sg.i0, part, s->partial_stride,
+                fused ? s->d_tickets + sg.i0 : nullptr, s->d_status + 2 * sg.i0, spec, split_ro, rowmap);
+    if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
+    if (!fused)
+      launch_lm(sg.st, sg.mode, LM_OP_STEP, L, rows, s->d_tracker_ptrs + sg.i0, s->d_states + sg.i0, part, s->partial_stride, nullptr, nullptr,
+                s->d_status + 2 * sg.i0, spec, rowmap);
+    return DSM_OK;
+  };
+  if (segs.size() > 1) { // fork: the other segments' streams start behind the uploads and the START launches
+    DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+    for (size_t si = 1; si < segs.size(); si++) DSM_HIP(hipStreamWaitEvent(segs[si].st, ctx->fork_event, 0));
+  }
+  for (int L = top > top2 ? top : top2; L >= 0; L--) {
+    auto seg_rounds = [&](const Seg &sg) {
+      int r = s->fixed_rounds[sg.mode][L] > 0 ? s->fixed_rounds[sg.mode][L] : draining ? s->rounds_max[sg.mode][L] : s->rounds[sg.mode][L];
+      if (P->fixed_schedule > 0) r = 1 + P->fixed_schedule; // the benchmark schedule: every problem needs exactly 1 + K rounds
+      return r < 1 ? 1 : r;
+    };
+    int kmax = 0;
+    for (const Seg &sg : segs)
+      if (sg.rows[L] > 0 && seg_rounds(sg) > kmax) kmax = seg_rounds(sg);
+    for (int k = 0; k < kmax; k++)
+      for (int si = (int)segs.size() - 1; si >= 0; si--) { // (the companion's round first, as in run_lm_batch)
+        const Seg &sg = segs[si];
+        if (k < seg_rounds(sg)) {
+          rc = launch_round(sg, L, k);
+          if (rc) return rc;
+        }
+      }
+    for (const Seg &sg : segs)
+      if (sg.rows[L] > 0) s->stats[sg.mode].launches[L] = seg_rounds(sg);
+  }
+  DSM_HIP(hipGetLastError());
+  for (size_t si = 1; si < segs.size(); si++) { // join
+    hipEvent_t ev = segs[si].companion ? ctx->companion_event : ctx->join_events[si - 1];
+    DSM_HIP(hipEventRecord(ev, segs[si].st));
+    DSM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+  }
+  // ---- (iv) one read-back ----
+  DSM_HIP(hipMemcpyAsync(s->h_states, s->d_states, sizeof(LMState) * N, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  s->passes++;
+  float ms = 0;
+  DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
+  s->stats[0].total_ms = s->stats[1].total_ms = ms;
+  s->stats[0].polls = 1;
+  if (ctx->timing) collect_eval_timing(ctx, ev_lvl, nlevels, s->stats[0]);
+  for (int i = 0; i < N; i++) {
+    Slot &sl = s->slots[i];
+    if (sl.state == SLOT_FREE) continue;
+    const int mode = i < cap0 ? 0 : 1;
+    const LMState &S = s->h_states[i];
+    dsm_stats &st = s->stats[mode];
+    sl.passes++;
+    for (int l = 0; l < nlevels; l++) { // what THIS pass evaluated
+      const long long de = S.evals[l] - sl.seen_evals[l], dr = S.evals_ro[l] - sl.seen_ro[l];
+      sl.seen_evals[l] = S.evals[l], sl.seen_ro[l] = S.evals_ro[l];
+      st.evals[l] += de;
+      st.evals_residual_only[l] += dr;
+      const long long nl = sl.trk->desc.lv[l].n, img = 12ll * (sl.trk->w >> l) * (sl.trk->h >> l);
+      st.algorithmic_bytes += de * (16ll * nl + (48ll * nl < img ? 48ll * nl : img)); // SURVEY.md 8d, as run_lm_batch
+    }
+    if (S.status == ST_RUNNING) {
+      if (sl.passes > 4096) {
+        set_error("internal: a resident problem did not terminate within 4096 passes");
+        return DSM_ERR_STATE;
+      }
+      sl.state = SLOT_RUNNING;
+      sl.lvl = S.lvl;
+      s->carried_slot_passes++;
+      continue;
+    }
+    dsm_stream_result r;
+    memset(&r, 0, sizeof r);
+    r.ticket = sl.ticket;
+    r.kind = mode;
+    r.status = S.status;
+    r.passes = sl.passes;
+    if (mode == 0) {
+      // the reference writes lastToNew_out / aff_g2l_out at :612-613, i.e. also when the later affine plausibility checks
+      // (:615-626) fail, but not when a level aborts (:598): as dsm_track_batch
+      const bool wrote = S.status == ST_GOOD || S.status == ST_BAD_AFFINE;
+      memcpy(r.pose, wrote ? S.cur : sl.pose0, sizeof r.pose);
+      memcpy(r.aff, wrote ? S.aff_cur : sl.aff0, sizeof r.aff);
+      r.good = S.status == ST_GOOD ? 1 : 0;
+      memcpy(r.flow, S.flow, sizeof r.flow);
+      r.scale = 1.0f;
+    } else {
+      r.good = 1;
+      r.scale = S.scale_cur;                    // :954
+      r.err = (float)S.last_residuals[0];       // :963
+      r.pose[3] = 1.0;
+    }
+    memcpy(r.last_residuals, S.last_residuals, sizeof r.last_residuals);
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) r.evals[l] = S.evals[l];
+    s->done.push_back(r);
+    s->retired[mode]++;
+    for (int l = 0; l < nlevels; l++) {
+      std::vector<int> &hv = s->hist[mode][l];
+      if (hv.size() < kHistCap)
+        hv.push_back((int)S.rounds[l]);
+      else
+        hv[s->hist_pos[mode] % kHistCap] = (int)S.rounds[l];
+    }
+    s->hist_pos[mode]++;
+    sl = Slot();
+  }
+  // ---- the next pass's rounds per level: the quantile of what the recently retired problems needed ----
+  for (int mode = 0; mode < 2; mode++) {
+    if (s->hist[mode][0].size() < 16) continue;
+    std::vector<int> r;
+    for (int l = 0; l < nlevels; l++) {
+      r = s->hist[mode][l];
+      size_t k = (size_t)(s->quantile[l] * (double)(r.size() - 1) + 0.5);
+      if (k >= r.size()) k = r.size() - 1;
+      std::nth_element(r.begin(), r.begin() + k, r.end());
+      s->rounds[mode][l] = r[k] < 1 ? 1 : r[k];
+      s->rounds_max[mode][l] = *std::max_element(r.begin(), r.end()) + 1;
+    }
+  }
+  return DSM_OK;
+}
+
+int dsm_stream_drain(dsm_stream *s) {
+  if (!s) return invalid("null stream");
+  for (;;) {
+    int resident = 0, waiting = 0;
+    dsm_stream_counts(s, &resident, &waiting, nullptr);
+    if (resident == 0 && waiting == 0) return DSM_OK;
+    const int rc = dsm_stream_advance(s);
+    if (rc) return rc;
+  }
+}
+
+} // extern "C"

@@ -43,7 +43,7 @@ public:
   ReferenceTracker(dsm_context *ctx, int ww, int hh, const std::vector<double> &tfm_vec, const Mat33fr &K1)
       : lastRef(nullptr), refFrameID(-1), lastRef_aff_g2l(0, 0), firstCoarseRMSE(-1) {
     dsm_params p;
-    dsm_params_default(&p);
+    if (DSM_PARAMS_INIT(&p) != DSM_OK) throw std::runtime_error(dsm_last_error()); // (the size this host was compiled with)
     R::fill_params(p);
     const float k1[4] = {K1(0, 0), K1(1, 1), K1(0, 2), K1(1, 2)}; // fx1_, fy1_, cx1_, cy1_ (:89-98)
     impl_.reset(new TrackerAndScaler(ctx, ww, hh, R::levels(), tfm_vec, k1, &p));

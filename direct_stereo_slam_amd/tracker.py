@@ -64,7 +64,7 @@ _PINNED_OWNERS = {}
 
 def default_params():
     p = Params()
-    _lib.load().dsm_params_default(C.byref(p))
+    check(_lib.load().dsm_params_default_sized(C.byref(p), C.sizeof(Params)))  # (a layout drift of this mirror fails here)
     return p
 
 
@@ -206,6 +206,89 @@ class Context:
         err = np.zeros(n, np.float32)
         check(self.L.dsm_optimize_scale_batch(self.h, n, hs, _fp(sc), coarsest, _fp(err)))
         return err, sc
+
+
+class Stream:
+    """Streaming form of Context.track_and_scale_batch (dsm_stream_*): a pool of resident problems advanced in passes; problems
+    are admitted as slots free up and retire individually.  Results are bit-identical to the batch calls."""
+
+    def __init__(self, ctx, track_slots, scale_slots=0):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        check(self.L.dsm_stream_create(ctx.h, int(track_slots), int(scale_slots), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dsm_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def submit_track(self, trackers, poses, affs, coarsest, min_res=None):
+        n = len(trackers)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        poses = np.ascontiguousarray(poses, np.float64).reshape(n, 7)
+        affs = np.ascontiguousarray(affs, np.float64).reshape(n, 2)
+        mr = None if min_res is None else np.ascontiguousarray(min_res, np.float64).reshape(n, MAX_LEVELS)
+        tk = (C.c_uint64 * n)()
+        check(self.L.dsm_stream_submit_track(self.h, n, hs, _dp(poses), _dp(affs), int(coarsest), None if mr is None else _dp(mr), tk))
+        return list(tk)
+
+    def submit_scale(self, trackers, scales, coarsest):
+        n = len(trackers)
+        hs = (C.c_void_p * n)(*[t.h for t in trackers])
+        sc = np.ascontiguousarray(scales, np.float32).reshape(n)
+        tk = (C.c_uint64 * n)()
+        check(self.L.dsm_stream_submit_scale(self.h, n, hs, _fp(sc), int(coarsest), tk))
+        return list(tk)
+
+    def advance(self):
+        check(self.L.dsm_stream_advance(self.h))
+
+    def drain(self):
+        check(self.L.dsm_stream_drain(self.h))
+
+    def counts(self):
+        """(resident, waiting, results ready)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.L.dsm_stream_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def results(self, max_results=None):
+        """retired problems, oldest first: list of _lib.StreamResult"""
+        if max_results is None:
+            max_results = self.counts()[2]
+        if max_results <= 0:
+            return []
+        buf = (_lib.StreamResult * max_results)()
+        n = C.c_int()
+        check(self.L.dsm_stream_results(self.h, max_results, buf, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def set_quantile(self, q, lvl=-1):
+        """q: one value (level lvl, or every level when lvl < 0) or a list from level 0"""
+        if np.ndim(q) == 0:
+            check(self.L.dsm_stream_set_quantile(self.h, int(lvl), float(q)))
+        else:
+            for l, v in enumerate(q):
+                check(self.L.dsm_stream_set_quantile(self.h, l, float(v)))
+
+    def set_rounds(self, mode, rounds):
+        arr = None if rounds is None else (C.c_int * MAX_LEVELS)(*(list(rounds) + [0] * MAX_LEVELS)[:MAX_LEVELS])
+        check(self.L.dsm_stream_set_rounds(self.h, int(mode), arr))
+
+    def stats(self):
+        a, b = Stats(), Stats()
+        check(self.L.dsm_stream_get_stats(self.h, C.byref(a), C.byref(b)))
+        return a, b
+
+    def schedule(self, mode=0):
+        r = (C.c_int * MAX_LEVELS)()
+        p, q, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        check(self.L.dsm_stream_get_schedule(self.h, int(mode), r, C.byref(p), C.byref(q), C.byref(c)))
+        return dict(rounds=list(r), passes=p.value, retired=q.value, carried_slot_passes=c.value)
 
 
 class TrackerAndScaler:

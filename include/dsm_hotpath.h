@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 2 /* 2: dsm_params.struct_size / fixed_schedule / frame_check / frame_grad_tol, dsm_stats.evals_residual_only */
+#define DSM_ABI_VERSION 3 /* 2: dsm_params.struct_size / fixed_schedule / frame_check / frame_grad_tol, dsm_stats.evals_residual_only;
+                             3: dsm_params_default_sized / DSM_PARAMS_INIT, dsm_stream_* (streaming form of the batched calls) */
 #define DSM_MAX_LEVELS 6 /* DSO PYR_LEVELS; the reference tracker uses <= 5 (TrackerAndScaler.cpp:457,463) */
 
 typedef enum dsm_status {
@@ -55,11 +56,12 @@ typedef struct dsm_pose_estimator dsm_pose_estimator; /* loop-closure direct ali
  * written by dsm_params_default() are the upstream DSO defaults as used by the
  * reference's default `mode=1` (src/main.cpp:117-121). */
 typedef struct dsm_params {
-  size_t struct_size;                 /* sizeof(dsm_params) of the header the CALLER was built with (dsm_params_default sets
-                                         it); every entry point that takes parameters returns DSM_ERR_INVALID on a mismatch,
-                                         so a host built against another version of this header fails loudly instead of
-                                         handing over a shorter struct.  Hosts should also compare dsm_abi_version() with
-                                         DSM_ABI_VERSION once (the Python and C++ adaptors in this repository do). */
+  size_t struct_size;                 /* sizeof(dsm_params) of the header the CALLER was built with: set by DSM_PARAMS_INIT /
+                                         dsm_params_default_sized from the size the caller's compiler sees; every entry point
+                                         that takes parameters returns DSM_ERR_INVALID on a mismatch, so a host built against
+                                         another version of this header fails loudly instead of handing over a shorter
+                                         struct.  Hosts should also compare dsm_abi_version() with DSM_ABI_VERSION once (the
+                                         Python and C++ adaptors in this repository do). */
   float huber_th;                     /* setting_huberTH            (TrackerAndScaler.cpp:727,795)   9    */
   float coarse_cutoff_th;             /* setting_coarseCutoffTH     (TrackerAndScaler.cpp:476)       20   */
   float scale_xi_rot;                 /* SCALE_XI_ROT               (TrackerAndScaler.cpp:542,685)   1    */
@@ -143,6 +145,14 @@ typedef struct dsm_stats {
 
 const char *dsm_last_error(void);
 int dsm_abi_version(void);
+/* Defaults into the CALLER's struct: caller_size = sizeof(dsm_params) as the caller's compiler sees it.  The library
+ * writes min(caller_size, its own sizeof) bytes -- never past the end of the caller's struct -- records caller_size in
+ * struct_size, and returns DSM_ERR_INVALID when the two sizes differ (the caller was built against another header; every
+ * entry point taking the struct would refuse it too).  Use the macro. */
+int dsm_params_default_sized(dsm_params *p, size_t caller_size);
+#define DSM_PARAMS_INIT(p) dsm_params_default_sized((p), sizeof(dsm_params))
+/* the same without the size: ONLY for callers known to be built with this very header (the Python binding checks
+ * dsm_abi_version() first): it writes the library's sizeof(dsm_params) bytes */
 void dsm_params_default(dsm_params *p);
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -285,6 +295,55 @@ int dsm_track_and_scale_batch(dsm_context *ctx, int n, dsm_tracker *const *track
                               const double *min_res_for_abort, double *last_residuals, double *flow_out, int *good, int n_scale,
                               dsm_tracker *const *scale_trackers, float *scale_io, float *err_out);
 int dsm_context_get_stats2(dsm_context *ctx, dsm_stats *out);
+
+/* ---- streaming form of the batched calls: continuous admission ------------------------------
+ * dsm_track_and_scale_batch takes every problem of a batch from its first evaluation to its last before it returns, so
+ * its lock-step launches run as many rounds per level as the SLOWEST problem needs.  The per-frame chain
+ * (TrackerAndScaler.cpp:505-593) is sequential, frames of different sequences are independent (FrontEnd.cpp:585-686):
+ * nothing requires them to start and end together.  A dsm_stream is a pool of resident problems (slots) advanced in
+ * PASSES: one pass sweeps the pyramid once, coarsest level first, with the rounds per level that MOST problems need (a
+ * quantile of what recently retired problems took); a problem that needs more rounds at a level simply stays there
+ * (its state is device-resident and resumable) and rides with the next pass's launches at that level; problems retire
+ * individually and their slots are refilled from the waiting queue.  One state read-back per pass, none inside it.
+ * Results are bit-identical to the batch calls (same evaluations, steps and summation order per problem).
+ *   submit_* queue problems (host copies are taken; the trackers' templates and frames must stay untouched until the
+ *   problem's result has been returned; the same tracker may be resident several times -- it is only read);
+ *   advance  admits waiting problems into free slots, runs one pass, retires what finished (synchronous);
+ *   results  hands back retired problems in retirement order;  drain = advance until nothing is resident or waiting. */
+typedef struct dsm_stream dsm_stream;
+typedef struct dsm_stream_result {
+  uint64_t ticket;   /* from dsm_stream_submit_* */
+  int kind;          /* 0 trackNewestCoarse, 1 optimizeScale */
+  int good;          /* track: the reference's bool return value; scale: 1 */
+  int status;        /* raw end state: 2 good, 3 aborted (:598), 4 implausible affine parameters (:615-626) */
+  int passes;        /* passes the problem was resident for */
+  double pose[7];    /* track: lastToNew_out as dsm_track_batch leaves pose_io (the initial guess after an abort) */
+  double aff[2];     /* track: aff_g2l_out, likewise */
+  double last_residuals[DSM_MAX_LEVELS];
+  double flow[3];    /* track: lastFlowIndicators */
+  float scale, err;  /* scale: optimizeScale's scale (:954) and return value (:963) */
+  int64_t evals[DSM_MAX_LEVELS]; /* evaluations executed per level (equal to the batch form's) */
+} dsm_stream_result;
+int dsm_stream_create(dsm_context *ctx, int track_slots, int scale_slots, dsm_stream **out);
+int dsm_stream_destroy(dsm_stream *s);
+/* arguments as dsm_track_batch / dsm_optimize_scale_batch; tickets_out (may be NULL): n tickets */
+int dsm_stream_submit_track(dsm_stream *s, int n, dsm_tracker *const *trackers, const double *pose0, const double *aff0,
+                            int coarsest_lvl, const double *min_res_for_abort, uint64_t *tickets_out);
+int dsm_stream_submit_scale(dsm_stream *s, int n, dsm_tracker *const *trackers, const float *scale0, int coarsest_lvl,
+                            uint64_t *tickets_out);
+int dsm_stream_advance(dsm_stream *s);
+int dsm_stream_drain(dsm_stream *s);
+int dsm_stream_results(dsm_stream *s, int max_results, dsm_stream_result *out, int *n_out);
+int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *results_out);
+/* rounds per level of a pass = this quantile (default 0.75) of the rounds recently retired problems needed there;
+ * lvl < 0: every level */
+int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q);
+/* ... or fixed: rounds_per_level[DSM_MAX_LEVELS] for problems of `mode` (0 track, 1 scale); entries <= 0 / NULL = learnt */
+int dsm_stream_set_rounds(dsm_stream *s, int mode, const int *rounds_per_level);
+/* statistics of the LAST pass (evaluations, algorithmic bytes, launches = rounds per level, timing as dsm_context_set_timing) */
+int dsm_stream_get_stats(dsm_stream *s, dsm_stats *track_out, dsm_stats *scale_out);
+/* the schedule in force and the stream's counters: passes run, problems retired (of `mode`), slot-passes spent carrying */
+int dsm_stream_get_schedule(dsm_stream *s, int mode, int *rounds_out, long long *passes_out, long long *retired_out, long long *carried_out);
 
 /* Batched forms: n independent trackers of one context advance in lock-step launches
  * (SURVEY.md section 7 "throughput mode").  Arrays are n x 7 / n x 2 / n x DSM_MAX_LEVELS / n x 3. */
