@@ -86,10 +86,12 @@ def parse():
                     help="dsm_params.work_queue (default: the library's, dsm_params_default): 0 launch-per-step form; 1 the library's automatic rule "
                          "(single calls of 32 ... ~200 dense frames run as one persistent launch; the one-call-per-step form used here is "
                          "always the launch form); 2 the whole call as one launch of persistent workgroups (two calls per step; its roofline is the whole-call figure)")
-    ap.add_argument("--stream", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--stream", type=int, default=1, choices=[0, 1],
                     help="1: the streaming form of the step (dsm_stream_*): every step SUBMITS its B frames (+ keyframe scale problems) to a pool of B resident "
                          "problems and runs one pass; problems are admitted as slots free up, carried over when they need more rounds than most, and retire "
                          "individually; after the K-th step the pool is drained inside the timed region.  0: one synchronous dsm_track_and_scale_batch call per step")
+    ap.add_argument("--stream-engine", type=int, default=1, choices=[0, 1], help="with --stream: 0 passes with carried stragglers, 1 ticks (one LM round per resident problem and tick, admission and retirement on the device)")
+    ap.add_argument("--stream-ticks", type=int, default=0, help="with --stream-engine 1: ticks per advance (0: the library's default)")
     ap.add_argument("--stream-quantile", default=None, help="with --stream: rounds per level of a pass = this quantile of what retired problems needed (library default 0.75)")
     ap.add_argument("--stream-rounds", default=None, help="with --stream: fixed rounds per level of a pass, comma separated from level 0 (e.g. 5,6,8,12,16,16)")
     ap.add_argument("--separate-calls", action="store_true", help="dsm_track_batch then dsm_optimize_scale_batch instead of the one dsm_track_and_scale_batch call per step")
@@ -403,7 +405,7 @@ class StreamRunner:
         self.ctx, self.wl, self.kf_idx = ctx, wl, kf_idx
         self.B = len(wl["trackers"])
         self.kf = [wl["trackers"][i] for i in kf_idx]
-        self.st = Stream(ctx, self.B, max(1, len(kf_idx)))
+        self.st = Stream(ctx, self.B, max(1, len(kf_idx)), args.stream_engine, args.stream_ticks)
         if args.stream_quantile is not None:
             q = [float(x) for x in str(args.stream_quantile).split(",")]
             self.st.set_quantile(q[0] if len(q) == 1 else q)
@@ -496,7 +498,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     good, poses, err, sc = run.results_of(("t", steps - 1))
     sched = run.st.schedule(0)
     # roofline of the dominant kernel: steady-state passes (the pool refilled every pass) with HIP events around every eval dispatch
-    for i in range(4):
+    for i in range(10):
         run.step(("r", i))
     run.reset_stats()
     ctx.sync()
@@ -515,14 +517,23 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     run.drain()
     run.close()
     n0 = len(wl["trackers"][0].get_template(0)[0])
-    bytes_eval0 = 16 * n0 + min(12 * wl["w"] * wl["h"], 48 * n0)
-    layout_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 48 * n0)
-    ro_bytes_eval0 = 16 * n0 + min(4 * wl["w"] * wl["h"], 16 * n0)
-    l0_ms, l0_evals, l0_ro = float(inst["l_ms"][0]), int(inst["evals"][0]), int(inst["ro"][0])
-    l0_launches, l0_disp = int(inst["launches"][0]), int(inst["dispatches"][0])
-    l0_bytes = l0_evals * bytes_eval0
+    n_l = [len(wl["trackers"][0].get_template(l)[0]) for l in range(wl["nl"])]
+    px_l = [(wl["w"] >> l) * (wl["h"] >> l) for l in range(wl["nl"])]
+    by_l = [16 * n + min(12 * px, 48 * n) for n, px in zip(n_l, px_l)]      # the reference's data per evaluation of level l
+    lay_l = [16 * n + min(4 * px, 48 * n) for n, px in zip(n_l, px_l)]      # what this implementation keeps in HBM for it (intensity planes)
+    ro_l = [16 * n + min(4 * px, 16 * n) for n, px in zip(n_l, px_l)]       # a residual-only evaluation priced at what it reads
+    bytes_eval0, layout_eval0, ro_bytes_eval0 = by_l[0], lay_l[0], ro_l[0]
+    ticks = args.stream_engine == 1
+    # engine 1: ONE evaluation kernel per tick covers every level (its dispatches are booked under index 0); engine 0: the level-0 kernel
+    lv = range(wl["nl"]) if ticks else [0]
+    l0_ms = float(inst["l_ms"][0])
+    l0_evals, l0_ro = int(sum(inst["evals"][l] for l in lv)), int(sum(inst["ro"][l] for l in lv))
+    l0_launches = int(inst["launches"][0]) if not ticks else int(inst["dispatches"][0] // max(1, min(args.streams, len(wl["trackers"]))))
+    l0_disp = int(inst["dispatches"][0])
+    l0_bytes = int(sum(int(inst["evals"][l]) * by_l[l] for l in lv))
     achieved = l0_bytes / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
-    achieved_ro_priced = ((l0_evals - l0_ro) * bytes_eval0 + l0_ro * ro_bytes_eval0) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    achieved_ro_priced = sum((int(inst["evals"][l]) - int(inst["ro"][l])) * by_l[l] + int(inst["ro"][l]) * ro_l[l] for l in lv) / (l0_ms * 1e-3) / 1e9 if l0_ms > 0 else 0.0
+    lay_bytes = int(sum(int(inst["evals"][l]) * lay_l[l] for l in lv))
     ratio, src, why_not = pmc_traffic_ratio(wl["config"])
     all_bytes = int(timed["bytes"] + timed["bytes_scale"])
     whole = all_bytes / dt / 1e9
@@ -532,12 +543,15 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
                 "frac_hbm_actual": achieved * ratio / HBM_PEAK_GBS if ratio is not None else None,
                 "traffic": ratio * l0_bytes / max(1, l0_launches) if ratio is not None else None,
                 "traffic_source": f"{src}: stored rocprofv3 --pmc summary of this command on these kernel sources, scaled to this run's bytes per launch (not re-measured here)" if src else why_not,
-                "kernel": "eval_kernel<pose, LVL0>", "bytes_per_eval": int(bytes_eval0), "bytes_per_residual_only_eval": int(ro_bytes_eval0),
-                "layout_bytes_per_eval": int(layout_eval0), "achieved_on_layout_bytes": achieved * layout_eval0 / bytes_eval0,
-                "evals": l0_evals, "residual_only_evals": l0_ro, "bytes_per_launch": l0_bytes / max(1, l0_launches),
+                "kernel": "tick_eval_kernel<pose> (one launch per tick and stream group: the staged evaluations of EVERY pyramid level)" if ticks else "eval_kernel<pose, LVL0>",
+                "bytes_per_eval": int(bytes_eval0), "bytes_per_residual_only_eval": int(ro_bytes_eval0),
+                "bytes_per_eval_by_level": [int(b) for b in by_l],
+                "layout_bytes_per_eval": int(layout_eval0), "achieved_on_layout_bytes": achieved * lay_bytes / max(1, l0_bytes),
+                "evals": l0_evals, "residual_only_evals": l0_ro, "evals_by_level": [int(inst["evals"][l]) for l in range(wl["nl"])],
+                "bytes_per_launch": l0_bytes / max(1, l0_launches),
                 "avg_launch_us": 1e3 * float(inst["l_sum_ms"][0]) / max(1, l0_disp), "launches": l0_launches, "dispatches": l0_disp,
                 "stream_groups": args.streams, "kernel_busy_us_per_launch": 1e3 * l0_ms / max(1, l0_launches),
-                "measured_over": "4 steady-state passes of the stream after the timed region (pool refilled before every pass)"}
+                "measured_over": "4 steady-state advances of the stream after the timed region (pool refilled before each), HIP events around every dispatch of the kernel on the stream it is launched on; time = union of the stream groups' overlapping dispatch intervals"}
     per_level = []
     for l in range(wl["nl"]):
         nl_ = len(wl["trackers"][0].get_template(l)[0])
@@ -548,13 +562,17 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     frames = B * steps
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": 0, "adaptive_schedule": True, "persistent_coarse": int(wl["params"].persistent_coarse),
-              "streams": args.streams, "form": "stream (dsm_stream_*: continuous admission, one pass per step + drain)",
-              "stream": {"track_slots": B, "scale_slots": max(1, len(kf_idx)), "passes_in_timed_region": int(timed_passes),
-                         "rounds_per_level_of_a_pass": sched["rounds"][:wl["nl"]], "quantile": args.stream_quantile if args.stream_quantile is not None else "library default",
+              "streams": args.streams,
+              "form": ("stream, tick engine (dsm_stream_*: every resident problem advances one LM round per tick, admission and retirement on the device; "
+                       "a step submits its frames and runs one advance, the pool is drained after the last step)") if ticks else
+                      "stream, pass engine (dsm_stream_*: one sweep of the pyramid per step with carried stragglers + drain)",
+              "stream": {"engine": "ticks" if ticks else "passes", "track_slots": B, "scale_slots": max(1, len(kf_idx)), "advances_in_timed_region": int(timed_passes),
+                         "ticks_per_advance": (args.stream_ticks or 32) if ticks else None,
+                         "rounds_per_level_of_a_pass": None if ticks else sched["rounds"][:wl["nl"]], "quantile": args.stream_quantile if args.stream_quantile is not None else "library default",
                          "frames_submitted": frames, "ms_per_pass": 1e3 * dt / max(1, timed_passes),
                          "steady_state": {"frames_per_s": steady["retired"] / steady["wall"], "passes": int(steady["passes"]), "frames_retired": int(steady["retired"]),
                                           "ms_per_pass": 1e3 * steady["wall"] / max(1, steady["passes"]),
-                                          "what": "8 passes after the timed region with the pool refilled before every pass: frames retired / wall time (no ramp-up, no drain)"}},
+                                          "what": "8 advances after the timed region with waiting frames at hand all the time: frames retired / wall time (no ramp-up, no drain)"}},
               "launch_pairs_per_step": int(timed["launches"].sum() / max(1, steps)), "readbacks_per_step": timed_passes / max(1, steps),
               "evals_per_frame_by_level": [float(timed["evals"][l]) / frames for l in range(wl["nl"])],
               "algorithmic_MB_per_frame": all_bytes / frames / 1e6,

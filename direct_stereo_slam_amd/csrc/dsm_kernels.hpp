@@ -66,6 +66,51 @@ int queue_kernel_blocks_per_cu(int mode);
 void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const TrackerDev *const *trackers, LMState *states,
                   float *partials, int partial_stride, int *tickets, WorkQueue *q, unsigned long long *items, unsigned qmask);
 
+// ---- tick engine of the streaming form (dsm_stream_*, stream_capi.hip) --------------------------------------------
+// One TICK advances every resident problem by one LM round, whatever level it stands on: ONE evaluation launch over a
+// device-built list of (problem, chunk) items of all levels mixed, then ONE LM launch (a workgroup per slot) that steps the
+// problems, builds the next tick's list, retires finished problems into a result array and refills their slots from the
+// waiting list -- no host round trip inside an advance of many ticks.
+constexpr unsigned kTickNoop = 0x80000000u, kTickCand = 0x40000000u; // item = flags | problem << 12 | chunk
+constexpr int kTickChunkBits = 12;
+struct TickSegCtl { // one per segment (stream group / companion): item counts of the two lists (tick parity)
+  int count[2];
+  int overflow; // an item list ran over (cannot happen by construction: checked by the host)
+  int pad[29];
+};
+struct TickModeCtl { // one per problem kind, shared by the kind's segments
+  int pending_head, pending_count; // waiting problems: next to admit / uploaded by the host
+  int retired, results_cap;        // results written / capacity of the result array
+  long long sched_evals[DSM_MAX_LEVELS], sched_ro[DSM_MAX_LEVELS]; // evaluations staged (they run in the next tick)
+  long long sched_items[DSM_MAX_LEVELS];
+};
+struct TickPending { // a waiting problem (host -> device)
+  StartInfo start;
+  const TrackerDev *trk;
+  unsigned long long ticket;
+};
+struct TickResult { // a retired problem (device -> host)
+  unsigned long long ticket;
+  int status, pad;
+  double cur[7], aff_cur[2];
+  double last_residuals[DSM_MAX_LEVELS];
+  double flow[3];
+  float scale_cur, pad1;
+  long long evals[DSM_MAX_LEVELS], evals_ro[DSM_MAX_LEVELS], rounds[DSM_MAX_LEVELS];
+};
+// positions a problem's evaluation occupies in an item list: its chunks, rounded so that every XCD owns a contiguous band
+__host__ __device__ inline int tick_positions(int n) {
+  const int nch = num_chunks(n);
+  return nch < 8 ? nch : 8 * ((nch + 7) >> 3);
+}
+void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket);
+void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
+                      TickSegCtl *seg, int buf);
+void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,
+                    unsigned *items_next, TickSegCtl *seg, int buf_next, int items_cap, TickModeCtl *mc, const TickPending *pending,
+                    TickResult *results, unsigned long long *slot_ticket, int speculate);
+
 // persistent LM loop of the small levels on LDS-resident data (levels whose target plane has at most max_px pixels, capped
 // by the kernel's LDS arena): coarse_level_fits tells whether a level of w x h pixels and n template points qualifies
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,

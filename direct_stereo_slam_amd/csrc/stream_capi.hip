@@ -25,6 +25,7 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <unordered_map>
 #include <vector>
 
 #include "dsm_internal.hpp"
@@ -105,6 +106,29 @@ struct dsm_stream {
   int rounds_max[2][DSM_MAX_LEVELS] = {{12, 22, 52, 52, 52, 52}, {8, 8, 8, 8, 8, 8}}; // the most any retired problem needed (+ 1)
   dsm_stats stats[2]{};
   long long passes = 0, retired[2] = {0, 0}, carried_slot_passes = 0;
+  // ---- tick engine (engine 1): every resident problem advances one LM round per tick, admission and retirement on the device ----
+  int engine = 1;
+  int ticks = 32; // ticks per advance (one host read-back per advance)
+  bool tick_ready = false;
+  std::vector<Seg> tsegs;
+  TickSegCtl *d_segctl = nullptr, *h_segctl = nullptr;
+  TickModeCtl *d_modectl = nullptr, *h_modectl = nullptr;
+  std::vector<unsigned *> d_items; // [segment][2]
+  std::vector<int> items_cap, last_count;
+  TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr};
+  int pending_cap[2] = {0, 0};
+  TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};
+  int results_cap[2] = {0, 0};
+  unsigned long long *d_slot_ticket = nullptr;
+  int parity = 0;
+  int resident[2] = {0, 0};
+  struct Origin {
+    dsm_tracker *trk;
+    double pose0[7], aff0[2];
+    long long admitted_at; // advance in which the problem was handed to the device (-1: still waiting)
+  };
+  std::unordered_map<uint64_t, Origin> origin;
+  long long advances = 0, total_ticks = 0;
 };
 
 static void stream_free(dsm_stream *s) {
@@ -119,6 +143,18 @@ static void stream_free(dsm_stream *s) {
   hipFree(s->d_tickets);
   hipFree(s->d_rowmap);
   if (s->h_rowmap) hipHostFree(s->h_rowmap);
+  hipFree(s->d_segctl);
+  if (s->h_segctl) hipHostFree(s->h_segctl);
+  hipFree(s->d_modectl);
+  if (s->h_modectl) hipHostFree(s->h_modectl);
+  for (unsigned *p : s->d_items) hipFree(p);
+  for (int m = 0; m < 2; m++) {
+    hipFree(s->d_pending[m]);
+    if (s->h_pending[m]) hipHostFree(s->h_pending[m]);
+    hipFree(s->d_results[m]);
+    if (s->h_results[m]) hipHostFree(s->h_results[m]);
+  }
+  hipFree(s->d_slot_ticket);
   delete s;
 }
 
@@ -136,6 +172,8 @@ static int stream_bind_geometry(dsm_stream *s, dsm_tracker *t) {
   s->partial_stride = ps;
   return DSM_OK;
 }
+
+static int tick_advance(dsm_stream *s);
 
 extern "C" {
 
@@ -190,6 +228,16 @@ int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q) {
   return DSM_OK;
 }
 
+int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance) {
+  if (!s || engine < 0 || engine > 1 || ticks_per_advance < 0 || ticks_per_advance > 4096) return invalid("dsm_stream_set_engine: engine 0 / 1, ticks 0 (keep) .. 4096");
+  int resident = 0;
+  dsm_stream_counts(s, &resident, nullptr, nullptr);
+  if (resident && engine != s->engine) return invalid("dsm_stream_set_engine: problems are resident");
+  s->engine = engine;
+  if (ticks_per_advance > 0) s->ticks = ticks_per_advance;
+  return DSM_OK;
+}
+
 int dsm_stream_set_rounds(dsm_stream *s, int mode, const int *rounds_per_level) {
   if (!s || mode < 0 || mode > 1) return invalid("dsm_stream_set_rounds: bad argument");
   for (int l = 0; l < DSM_MAX_LEVELS; l++) s->fixed_rounds[mode][l] = rounds_per_level ? rounds_per_level[l] : 0;
@@ -230,6 +278,11 @@ int dsm_stream_submit_track(dsm_stream *s, int n, dsm_tracker *const *ts, const 
     I.scale = 1.0f;
     I.coarsest = coarsest_lvl;
     if (tickets_out) tickets_out[i] = wq.ticket;
+    dsm_stream::Origin og;
+    og.trk = ts[i], og.admitted_at = -1;
+    memcpy(og.pose0, I.pose, sizeof og.pose0);
+    memcpy(og.aff0, I.aff, sizeof og.aff0);
+    s->origin[wq.ticket] = og;
     s->waiting[0].push_back(wq);
   }
   return DSM_OK;
@@ -250,6 +303,10 @@ int dsm_stream_submit_scale(dsm_stream *s, int n, dsm_tracker *const *ts, const 
     I.scale = scale0[i];
     I.coarsest = coarsest_lvl;
     if (tickets_out) tickets_out[i] = wq.ticket;
+    dsm_stream::Origin og;
+    memset(&og, 0, sizeof og);
+    og.trk = ts[i], og.admitted_at = -1;
+    s->origin[wq.ticket] = og;
     s->waiting[1].push_back(wq);
   }
   return DSM_OK;
@@ -259,6 +316,7 @@ int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *r
   if (!s) return invalid("null stream");
   int r = 0;
   for (const Slot &sl : s->slots) r += sl.state != SLOT_FREE;
+  if (s->engine == 1) r = s->resident[0] + s->resident[1];
   if (resident_out) *resident_out = r;
   if (waiting_out) *waiting_out = (int)(s->waiting[0].size() + s->waiting[1].size());
   if (results_out) *results_out = (int)s->done.size();
@@ -299,6 +357,7 @@ int dsm_stream_get_schedule(dsm_stream *s, int mode, int *rounds_out, long long 
 // back once; problems that terminated retire (dsm_stream_results), the others are carried.
 int dsm_stream_advance(dsm_stream *s) {
   if (!s) return invalid("null stream");
+  if (s->engine == 1) return tick_advance(s);
   dsm_context *ctx = s->ctx;
   DSM_HIP(hipSetDevice(ctx->device));
   const int N = s->N, cap0 = s->cap[0];
@@ -528,6 +587,7 @@ int dsm_stream_advance(dsm_stream *s) {
     memcpy(r.last_residuals, S.last_residuals, sizeof r.last_residuals);
     for (int l = 0; l < DSM_MAX_LEVELS; l++) r.evals[l] = S.evals[l];
     s->done.push_back(r);
+    s->origin.erase(sl.ticket);
     s->retired[mode]++;
     for (int l = 0; l < nlevels; l++) {
       std::vector<int> &hv = s->hist[mode][l];
@@ -554,6 +614,262 @@ int dsm_stream_advance(dsm_stream *s) {
   }
   return DSM_OK;
 }
+
+
+} // extern "C"
+
+// ---- tick engine -------------------------------------------------------------------------------------------------------
+template <typename T>
+static int regrow_dev(T **p, size_t n) {
+  if (*p) DSM_HIP(hipFree(*p));
+  return alloc_dev(p, n);
+}
+template <typename T>
+static int regrow_pinned(T **p, size_t n) {
+  if (*p) DSM_HIP(hipHostFree(*p));
+  return alloc_pinned(p, n);
+}
+
+static int tick_setup(dsm_stream *s) {
+  dsm_context *ctx = s->ctx;
+  const int cap0 = s->cap[0], N = s->N;
+  int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;
+  if (ng > cap0) ng = cap0 > 0 ? cap0 : 1;
+  s->tsegs.clear();
+  if (cap0 > 0)
+    for (int g = 0; g < ng; g++) {
+      const int g0 = (int)((long long)cap0 * g / ng), g1 = (int)((long long)cap0 * (g + 1) / ng);
+      if (g1 > g0) s->tsegs.push_back(Seg{nullptr, g0, g1, 0, false, {}});
+    }
+  if (s->cap[1] > 0) s->tsegs.push_back(Seg{nullptr, cap0, N, 1, true, {}});
+  const int nseg = (int)s->tsegs.size();
+  int rc = alloc_dev(&s->d_segctl, nseg);
+  if (!rc) rc = alloc_pinned(&s->h_segctl, nseg);
+  if (!rc) rc = alloc_dev(&s->d_modectl, 2);
+  if (!rc) rc = alloc_pinned(&s->h_modectl, 2);
+  if (!rc) rc = alloc_dev(&s->d_slot_ticket, N);
+  if (rc) return rc;
+  // an item list holds at most one evaluation (+ its speculative twin) per slot of the segment
+  const int maxpos = 8 * ((max_chunks_upto(s->w * s->h) + 7) / 8);
+  if (maxpos >= (1 << kTickChunkBits)) return invalid("dsm_stream (tick engine): a level has too many chunks for the item encoding");
+  if (N >= (1 << (30 - kTickChunkBits))) return invalid("dsm_stream (tick engine): too many slots for the item encoding");
+  s->d_items.assign(2 * nseg, nullptr);
+  s->items_cap.assign(nseg, 0);
+  s->last_count.assign(nseg, 0);
+  for (int si = 0; si < nseg; si++) {
+    const int cap = (s->tsegs[si].i1 - s->tsegs[si].i0) * 2 * maxpos + 64;
+    s->items_cap[si] = cap;
+    for (int b = 0; b < 2; b++)
+      if ((rc = alloc_dev(&s->d_items[2 * si + b], cap))) return rc;
+  }
+  DSM_HIP(hipMemsetAsync(s->d_segctl, 0, sizeof(TickSegCtl) * nseg, ctx->stream));
+  DSM_HIP(hipMemsetAsync(s->d_modectl, 0, sizeof(TickModeCtl) * 2, ctx->stream));
+  DSM_HIP(hipMemsetAsync(s->d_slot_ticket, 0, sizeof(unsigned long long) * N, ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  s->tick_ready = true;
+  return DSM_OK;
+}
+
+// One advance of the tick engine: the waiting problems go to the device (at most one per slot), free slots take them, then
+// `ticks` ticks -- evaluate every staged item, step every resident problem; finished problems retire into the result array
+// and their slots take the next waiting problem on the spot -- and ONE read-back: control blocks, then the results.
+static int tick_advance(dsm_stream *s) {
+  dsm_context *ctx = s->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  memset(&s->stats[0], 0, sizeof(dsm_stats));
+  memset(&s->stats[1], 0, sizeof(dsm_stats));
+  if (s->resident[0] + s->resident[1] == 0 && s->waiting[0].empty() && s->waiting[1].empty()) return DSM_OK;
+  if (!s->partial_stride) return invalid("dsm_stream: nothing was ever submitted");
+  int rc;
+  if (!s->tick_ready && (rc = tick_setup(s))) return rc;
+  const int nseg = (int)s->tsegs.size();
+  const int n_track_segs = s->cap[1] > 0 ? nseg - 1 : nseg;
+  rc = ensure_streams(ctx, n_track_segs < 1 ? 1 : n_track_segs, s->cap[1] > 0 && n_track_segs > 0);
+  if (rc) return rc;
+  for (int si = 0; si < nseg; si++)
+    s->tsegs[si].st = si == 0 ? ctx->stream : s->tsegs[si].companion ? ctx->companion_stream : ctx->extra_streams[si - 1];
+  // ---- the waiting problems of each kind, at most one per slot and advance ----
+  int n_pend[2] = {0, 0};
+  std::vector<dsm_tracker *> fresh;
+  const dsm_params *P = nullptr;
+  for (int mode = 0; mode < 2; mode++) {
+    const int n = (int)std::min<size_t>(s->waiting[mode].size(), (size_t)s->cap[mode]);
+    n_pend[mode] = n;
+    if (n > s->pending_cap[mode]) {
+      const int want = n > 2 * s->pending_cap[mode] ? n : 2 * s->pending_cap[mode];
+      if ((rc = regrow_dev(&s->d_pending[mode], want)) || (rc = regrow_pinned(&s->h_pending[mode], want))) return rc;
+      s->pending_cap[mode] = want;
+    }
+    for (int i = 0; i < n; i++) {
+      const Waiting &wt = s->waiting[mode][i];
+      TickPending &pd = s->h_pending[mode][i];
+      pd.start = wt.start;
+      pd.trk = wt.trk->d_desc;
+      pd.ticket = wt.ticket;
+      fresh.push_back(wt.trk);
+      if (!P) P = &wt.trk->params;
+    }
+    const int rcap = s->resident[mode] + n + 1;
+    if (rcap > s->results_cap[mode]) {
+      const int want = rcap > 2 * s->results_cap[mode] ? rcap : 2 * s->results_cap[mode];
+      if ((rc = regrow_dev(&s->d_results[mode], want)) || (rc = regrow_pinned(&s->h_results[mode], want))) return rc;
+      s->results_cap[mode] = want;
+    }
+    TickModeCtl &mc = s->h_modectl[mode];
+    memset(&mc, 0, sizeof mc);
+    mc.pending_count = n;
+    mc.results_cap = s->results_cap[mode];
+  }
+  if (!P)
+    for (auto &kv : s->origin)
+      if (kv.second.admitted_at >= 0) {
+        P = &kv.second.trk->params;
+        break;
+      }
+  if (!P) return invalid("dsm_stream: internal: no resident or waiting problem");
+  if (!fresh.empty() && (rc = sync_descs(ctx, fresh.data(), (int)fresh.size()))) return rc;
+  DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
+  for (int mode = 0; mode < 2; mode++)
+    if (n_pend[mode]) DSM_HIP(hipMemcpyAsync(s->d_pending[mode], s->h_pending[mode], sizeof(TickPending) * n_pend[mode], hipMemcpyHostToDevice, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(s->d_modectl, s->h_modectl, sizeof(TickModeCtl) * 2, hipMemcpyHostToDevice, ctx->stream));
+  if (nseg > 1) {
+    DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+    for (int si = 1; si < nseg; si++) DSM_HIP(hipStreamWaitEvent(s->tsegs[si].st, ctx->fork_event, 0));
+  }
+  const int T = s->ticks;
+  size_t ev_used = 0;
+  std::vector<int> ev_lvl;
+  const int speculate = P->fixed_schedule > 0 ? 0 : P->speculate;
+  auto seg_args = [&](int si, int &i0, int &ns, int &mode) {
+    const Seg &sg = s->tsegs[si];
+    i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
+  };
+  for (int si = nseg - 1; si >= 0; si--) {
+    int i0, ns, mode;
+    seg_args(si, i0, ns, mode);
+    if (n_pend[mode])
+      launch_tick_admit(s->tsegs[si].st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, s->d_items[2 * si + s->parity],
+                        s->d_segctl + si, s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0);
+  }
+  for (int t = 0; t < T; t++) {
+    const int buf = (s->parity + t) & 1;
+    for (int si = nseg - 1; si >= 0; si--) {
+      int i0, ns, mode;
+      seg_args(si, i0, ns, mode);
+      const Seg &sg = s->tsegs[si];
+      // grid: what the segment's list held at the end of the last advance plus slack (the kernel strides over a longer list)
+      long long grid = (long long)s->last_count[si] * 5 / 4 + 256;
+      if (s->last_count[si] == 0) grid = (long long)ns * 16;
+      if (grid > s->items_cap[si]) grid = s->items_cap[si];
+      float *part = s->d_partials + (size_t)i0 * s->partial_stride;
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (ctx->timing && !sg.companion) {
+        ea = get_event(ctx, ev_used++);
+        eb = get_event(ctx, ev_used++);
+        ev_lvl.push_back(0); // (all levels in one launch: booked under index 0)
+        if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
+      }
+      launch_tick_eval(sg.st, mode, (int)grid, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + buf], s->d_segctl + si, buf);
+      if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
+      launch_tick_lm(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, part, s->partial_stride,
+                     s->d_items[2 * si + (buf ^ 1)], s->d_segctl + si, buf ^ 1, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode],
+                     s->d_results[mode], s->d_slot_ticket + i0, speculate);
+    }
+  }
+  s->parity = (s->parity + T) & 1;
+  DSM_HIP(hipGetLastError());
+  for (int si = 1; si < nseg; si++) {
+    hipEvent_t ev = s->tsegs[si].companion ? ctx->companion_event : ctx->join_events[si - 1];
+    DSM_HIP(hipEventRecord(ev, s->tsegs[si].st));
+    DSM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+  }
+  // ---- one read-back: the control blocks, then as many results as were written ----
+  DSM_HIP(hipMemcpyAsync(s->h_modectl, s->d_modectl, sizeof(TickModeCtl) * 2, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(s->h_segctl, s->d_segctl, sizeof(TickSegCtl) * nseg, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  for (int mode = 0; mode < 2; mode++) {
+    const int nr = s->h_modectl[mode].retired;
+    if (nr > s->results_cap[mode]) {
+      set_error("internal: the tick engine retired more problems than its result array holds");
+      return DSM_ERR_STATE;
+    }
+    if (nr) DSM_HIP(hipMemcpyAsync(s->h_results[mode], s->d_results[mode], sizeof(TickResult) * nr, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  s->advances++;
+  s->total_ticks += T;
+  s->passes++;
+  float ms = 0;
+  DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
+  s->stats[0].total_ms = s->stats[1].total_ms = ms;
+  s->stats[0].polls = 1;
+  if (ctx->timing) collect_eval_timing(ctx, ev_lvl, 1, s->stats[0]);
+  for (int si = 0; si < nseg; si++) {
+    if (s->h_segctl[si].overflow) {
+      set_error("internal: an item list of the tick engine ran over");
+      return DSM_ERR_STATE;
+    }
+    s->last_count[si] = s->h_segctl[si].count[s->parity];
+  }
+  for (int mode = 0; mode < 2; mode++) {
+    const TickModeCtl &mc = s->h_modectl[mode];
+    const int admitted = mc.pending_head < n_pend[mode] ? mc.pending_head : n_pend[mode];
+    for (int i = 0; i < admitted; i++) {
+      auto it = s->origin.find(s->waiting[mode].front().ticket);
+      if (it != s->origin.end()) it->second.admitted_at = s->advances;
+      s->waiting[mode].pop_front();
+    }
+    s->resident[mode] += admitted - mc.retired;
+    dsm_stats &st = s->stats[mode];
+    for (int l = 0; l < s->nlevels; l++) {
+      st.evals[l] = mc.sched_evals[l];
+      st.evals_residual_only[l] = mc.sched_ro[l];
+      st.launches[l] = T;
+    }
+    for (int i = 0; i < mc.retired; i++) {
+      const TickResult &R = s->h_results[mode][i];
+      auto it = s->origin.find(R.ticket);
+      if (it == s->origin.end()) {
+        set_error("internal: the tick engine returned an unknown ticket");
+        return DSM_ERR_STATE;
+      }
+      const dsm_stream::Origin &og = it->second;
+      dsm_stream_result r;
+      memset(&r, 0, sizeof r);
+      r.ticket = R.ticket;
+      r.kind = mode;
+      r.status = R.status;
+      r.passes = (int)(s->advances - og.admitted_at + 1);
+      if (mode == 0) {
+        const bool wrote = R.status == ST_GOOD || R.status == ST_BAD_AFFINE; // as dsm_track_batch (:612-613 / :598)
+        memcpy(r.pose, wrote ? R.cur : og.pose0, sizeof r.pose);
+        memcpy(r.aff, wrote ? R.aff_cur : og.aff0, sizeof r.aff);
+        r.good = R.status == ST_GOOD ? 1 : 0;
+        memcpy(r.flow, R.flow, sizeof r.flow);
+        r.scale = 1.0f;
+      } else {
+        r.good = 1;
+        r.scale = R.scale_cur;                  // :954
+        r.err = (float)R.last_residuals[0];     // :963
+        r.pose[3] = 1.0;
+      }
+      memcpy(r.last_residuals, R.last_residuals, sizeof r.last_residuals);
+      for (int l = 0; l < DSM_MAX_LEVELS; l++) {
+        r.evals[l] = R.evals[l];
+        // SURVEY.md 8d's bytes, booked when the problem retires (exact per problem; a long run's average equals the bytes moved)
+        const long long nl = og.trk->desc.lv[l].n, img = 12ll * (og.trk->w >> l) * (og.trk->h >> l);
+        if (l < s->nlevels) st.algorithmic_bytes += R.evals[l] * (16ll * nl + (48ll * nl < img ? 48ll * nl : img));
+      }
+      s->done.push_back(r);
+      s->retired[mode]++;
+      s->origin.erase(it);
+    }
+  }
+  return DSM_OK;
+}
+
+extern "C" {
 
 int dsm_stream_drain(dsm_stream *s) {
   if (!s) return invalid("null stream");

@@ -213,7 +213,9 @@ struct EvalConsts {
 // rows and store the partial -- the same additions in the same order by another wave; the other waves leave at once instead
 // of waiting for the slowest wave's gathers (measured: a mid-level workgroup spent a third of its life between the end of
 // its first wave's loop and the partial store).
-template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false>
+// DEEP: the two-points-per-trip loop with fixed register roles (level 0 always; the tick engine's kernel, which runs at four
+// waves per SIMD whatever the level, also uses it on the other large levels)
+template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                                 float *out, int *arrive = nullptr) {
   const int n = c.n;
@@ -391,7 +393,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       };
       const int i = chunk_start + tid;
       const fvec4 p0 = load_pt(i);
-      if (LVL0) {
+      if (DEEP) {
         // Level 0 (long loops, HBM-resident targets): two points per trip with FIXED register roles (sets a / b).
         // The taps of point k+1 are issued before the arithmetic of point k and awaited only after the taps of
         // point k+2 have been issued, so two points' gathers are in flight per wave; template entries are fetched
@@ -555,13 +557,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   }
 }
 
-template <int MODE, bool LVL0>
+template <int MODE, bool LVL0, bool DEEP = LVL0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                            float *out, int *arrive = nullptr) {
   if (c.residual_only) // wave-uniform
-    eval_chunk_impl<MODE, LVL0, true>(c, chunk, tid, active, red, out, arrive);
+    eval_chunk_impl<MODE, LVL0, true, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
   else
-    eval_chunk_impl<MODE, LVL0, false>(c, chunk, tid, active, red, out, arrive);
+    eval_chunk_impl<MODE, LVL0, false, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1548,6 +1550,32 @@ void launch_eval(hipStream_t s, int mode, int lvl, int grid_x, int nprob,
     launch_eval_ml<1>(s, lvl, grid, trackers, states, partials, partial_stride, tickets, status_out, spec_nprob, split_ro, rowmap);
 }
 
+// one thread: the state machine of a new problem at its coarsest level (:451-474 / :854-872), first evaluation staged
+__device__ __forceinline__ void lm_start_problem(const TrackerDev &T, LMState &S, int mode, const StartInfo &I) {
+  S.is_scale = mode;
+  S.coarsest = I.coarsest;
+  S.have_repeated = 0;
+  S.lambda = 0.01f;
+  S.inc_norm = 0;
+  S.inc_f = 0;
+  for (int i = 0; i < 7; i++) S.cur[i] = I.pose[i];
+  S.aff_cur[0] = I.aff[0];
+  S.aff_cur[1] = I.aff[1];
+  S.scale_cur = I.scale;
+  for (int i = 0; i < DSM_MAX_LEVELS; i++) {
+    S.last_residuals[i] = __builtin_nan(""); // :459 / :860
+    S.last_inners[i] = 0;
+    S.min_res[i] = I.min_res[i];
+    S.evals[i] = 0;
+    S.evals_ro[i] = 0;
+    S.rounds[i] = 0;
+  }
+  S.spec_valid = 0;
+  S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
+  S.status = ST_RUNNING;
+  begin_level(T, S, I.coarsest);
+}
+
 __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lvl,
                                                         const TrackerDev *const *__restrict__ trackers,
                                                         LMState *__restrict__ states,
@@ -1566,29 +1594,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
 
   if (op == LM_OP_START) {
     if (tid == 0) {
-      const StartInfo &I = start[prob];
-      S.is_scale = mode;
-      S.coarsest = I.coarsest;
-      S.have_repeated = 0;
-      S.lambda = 0.01f;
-      S.inc_norm = 0;
-      S.inc_f = 0;
-      for (int i = 0; i < 7; i++) S.cur[i] = I.pose[i];
-      S.aff_cur[0] = I.aff[0];
-      S.aff_cur[1] = I.aff[1];
-      S.scale_cur = I.scale;
-      for (int i = 0; i < DSM_MAX_LEVELS; i++) {
-        S.last_residuals[i] = __builtin_nan(""); // :459 / :860
-        S.last_inners[i] = 0;
-        S.min_res[i] = I.min_res[i];
-        S.evals[i] = 0;
-        S.evals_ro[i] = 0;
-        S.rounds[i] = 0;
-      }
-      S.spec_valid = 0;
-      S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
-      S.status = ST_RUNNING;
-      begin_level(T, S, I.coarsest);
+      lm_start_problem(T, S, mode, start[prob]);
       if (status_out) {
         status_out[2 * prob] = S.status;
         status_out[2 * prob + 1] = S.lvl;
@@ -1993,6 +1999,184 @@ void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const Tracker
   else
     DSM_QL(2);
 #undef DSM_QL
+}
+
+// ------------------------------------------------------------------------------------------
+// Tick engine of the streaming form (dsm_stream_*, stream_capi.hip).  A tick advances EVERY resident problem by one LM round,
+// whatever level it stands on: tick_eval_kernel evaluates a device-built list of (problem, chunk) items -- all levels mixed in
+// one grid, the small levels' chunks filling what the large ones leave --, tick_lm_kernel (one workgroup per slot) steps the
+// problems, stages the next tick's items, retires finished problems into a result array and refills their slots from the
+// waiting list.  Kernel boundaries order everything: no cross-workgroup protocol, no tickets, no host round trip inside an
+// advance.  Same chunks, same partials, same reduction order as every other form: bit-identical results.
+// ------------------------------------------------------------------------------------------
+// wave 0: the items of the evaluation(s) staged in `St` (the main candidate and, where staged, the speculative one)
+__device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, int lane) {
+  const int nch = num_chunks(St.in.n), per_xcd = (nch + 7) >> 3;
+  const int npos = nch < 8 ? nch : 8 * per_xcd;
+  const int total = St.spec_valid ? 2 * npos : npos;
+  if (total == 0) return; // an empty level: nothing to evaluate, the LM step runs anyway
+  int base = 0;
+  if (lane == 0) {
+    base = atomicAdd(&seg->count[buf], total);
+    if (base + total > cap) seg->overflow = 1;
+    const int lvl = St.lvl;
+    atomicAdd((unsigned long long *)&mc->sched_evals[lvl], 1ull);
+    if (St.in.residual_only) atomicAdd((unsigned long long *)&mc->sched_ro[lvl], 1ull);
+    atomicAdd((unsigned long long *)&mc->sched_items[lvl], (unsigned long long)total);
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+  for (int i = lane; i < total; i += 64) {
+    const bool cand = i >= npos;
+    const int p = cand ? i - npos : i;
+    // position p runs on XCD (base + p) % 8 (workgroup index = list position): XCD-contiguous bands of the template, as eval_kernel
+    const int chunk = nch < 8 ? p : (p & 7) * per_xcd + (p >> 3);
+    const unsigned item = chunk < nch ? (((unsigned)prob << kTickChunkBits) | (unsigned)chunk | (cand ? kTickCand : 0u)) : kTickNoop;
+    if (base + i < cap) items[base + i] = item;
+  }
+}
+
+// wave 0: take the next waiting problem (if any) into slot `prob`: tracker pointer, ticket, state machine started, first items staged.
+// st / trk: LDS scratch of the caller.
+__device__ __forceinline__ void tick_try_admit(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
+                                               unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc,
+                                               const TickPending *pending, unsigned long long *slot_ticket, int lane) {
+  int h = 0;
+  if (lane == 0) h = mc->pending_head < mc->pending_count ? atomicAdd(&mc->pending_head, 1) : 0x7FFFFFFF;
+  h = __builtin_amdgcn_readfirstlane(h);
+  if (h >= mc->pending_count) return;
+  const TickPending &Pn = pending[h];
+  const TrackerDev *tp = Pn.trk;
+  stage_in(trk, tp, lane, 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane == 0) {
+    trackers[prob] = tp;
+    slot_ticket[prob] = Pn.ticket;
+    lm_start_problem(trk, st, mode, Pn.start);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  stage_out(&states[prob], st, lane, 64);
+  tick_push(st, prob, items, seg, buf, cap, mc, lane);
+}
+
+// start of an advance: every free slot takes a waiting problem
+__global__ __launch_bounds__(64) void tick_admit_kernel(int mode, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
+                                                        int buf, int cap, TickModeCtl *mc, const TickPending *pending,
+                                                        unsigned long long *slot_ticket) {
+  const int prob = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) LMState st;
+  __shared__ __attribute__((aligned(16))) TrackerDev trk;
+  if (states[prob].status == ST_RUNNING) return;
+  stage_in(st, &states[prob], threadIdx.x, 64); // (fields the start does not write keep their old bits: none is read)
+  tick_try_admit(mode, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, threadIdx.x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void tick_eval_kernel(const LMState *__restrict__ states,
+                                                                                                  float *__restrict__ partials, int partial_stride,
+                                                                                                  const unsigned *__restrict__ items,
+                                                                                                  TickSegCtl *__restrict__ seg, int buf) {
+  __shared__ float red[16][kNumSlots];
+  const int n_items = ((const DSM_GLOBAL TickSegCtl *)seg)->count[buf];
+  // the other list was consumed by the previous tick's evaluation; this tick's LM launch appends to it
+  if (blockIdx.x == 0 && threadIdx.x == 0) seg->count[buf ^ 1] = 0;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const unsigned item = ((const DSM_GLOBAL unsigned *)items)[it];
+    if (item & kTickNoop) continue; // (workgroup-uniform)
+    const bool cand = (item & kTickCand) != 0;
+    const int prob = (int)((item & ~(kTickNoop | kTickCand)) >> kTickChunkBits), chunk = (int)(item & ((1u << kTickChunkBits) - 1u));
+    const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
+    const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
+    const int lvl = S.lvl;
+    EvalConsts c;
+    c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h;
+    c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
+    c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
+    c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
+    c.residual_only = in.residual_only;
+    c.lds_img = c.lds_pts = 0;
+    float *const out = partials + (size_t)prob * partial_stride + (cand ? (partial_stride >> 1) : 0) + (size_t)chunk * kPartialStride;
+    if (lvl == 0)
+      eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
+#ifdef DSM_TICK_DEEP_L1
+    else if (c.n >= 64 * 1024) // eight or more points per thread: the deep loop (this kernel runs at four waves per SIMD anyway)
+      eval_chunk<MODE, false, true>(c, chunk, threadIdx.x, true, red, out);
+#endif
+    else
+      eval_chunk<MODE, false>(c, chunk, threadIdx.x, true, red, out);
+    __syncthreads(); // red[] is reused by the next item
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **trackers, LMState *__restrict__ states, const float *__restrict__ partials,
+                                                             int partial_stride, unsigned *__restrict__ items_next, TickSegCtl *__restrict__ seg,
+                                                             int buf_next, int cap, TickModeCtl *__restrict__ mc, const TickPending *__restrict__ pending,
+                                                             TickResult *__restrict__ results, unsigned long long *__restrict__ slot_ticket, int speculate) {
+  const int prob = blockIdx.x, tid = threadIdx.x;
+  LMState &S = states[prob];
+  __shared__ LmShared sh;
+  __shared__ LmSpecShared sps;
+  if (!(S.status == ST_RUNNING && S.is_scale == MODE)) return; // a free slot (refilled by the next advance's admit launch)
+  const int lvl = S.lvl;
+  // the speculative second candidate (dsm_params.speculate): on the small levels, as in the launch form (a tick's launch is
+  // never bound by the doubled rows of a few small problems)
+  const bool spec_lvl = speculate >= 2 || (speculate == 1 && S.in.n <= 8192);
+  lm_step_block(MODE, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, nullptr, spec_lvl ? &sps : nullptr,
+                partial_stride >> 1);
+  if (tid >= 64) return;
+  const int lane = tid;
+  if (sh.st.status == ST_RUNNING) {
+    tick_push(sh.st, prob, items_next, seg, buf_next, cap, mc, lane);
+    return;
+  }
+  // the problem terminated: its result, then the slot takes the next waiting problem
+  if (lane == 0) {
+    const int r = atomicAdd(&mc->retired, 1);
+    if (r < mc->results_cap) {
+      TickResult &R = results[r];
+      const LMState &F = sh.st;
+      R.ticket = slot_ticket[prob];
+      R.status = F.status;
+      for (int i = 0; i < 7; i++) R.cur[i] = F.cur[i];
+      R.aff_cur[0] = F.aff_cur[0], R.aff_cur[1] = F.aff_cur[1];
+      R.flow[0] = F.flow[0], R.flow[1] = F.flow[1], R.flow[2] = F.flow[2];
+      R.scale_cur = F.scale_cur;
+      for (int l = 0; l < DSM_MAX_LEVELS; l++) {
+        R.last_residuals[l] = F.last_residuals[l];
+        R.evals[l] = F.evals[l], R.evals_ro[l] = F.evals_ro[l], R.rounds[l] = F.rounds[l];
+      }
+    }
+  }
+  tick_try_admit(MODE, prob, trackers, states, sh.st, sh.trk, items_next, seg, buf_next, cap, mc, pending, slot_ticket, lane);
+}
+
+void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket) {
+  hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, items, seg, buf, items_cap, mc, pending, slot_ticket);
+}
+void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
+                      TickSegCtl *seg, int buf) {
+  if (grid < 1) grid = 1;
+  if (mode == 0)
+    hipLaunchKernelGGL((tick_eval_kernel<0>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf);
+  else
+    hipLaunchKernelGGL((tick_eval_kernel<1>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf);
+}
+void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,
+                    unsigned *items_next, TickSegCtl *seg, int buf_next, int items_cap, TickModeCtl *mc, const TickPending *pending,
+                    TickResult *results, unsigned long long *slot_ticket, int speculate) {
+  if (mode == 0)
+    hipLaunchKernelGGL((tick_lm_kernel<0>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, items_next, seg,
+                       buf_next, items_cap, mc, pending, results, slot_ticket, speculate);
+  else
+    hipLaunchKernelGGL((tick_lm_kernel<1>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, items_next, seg,
+                       buf_next, items_cap, mc, pending, results, slot_ticket, speculate);
 }
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,

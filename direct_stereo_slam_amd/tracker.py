@@ -212,11 +212,17 @@ class Stream:
     """Streaming form of Context.track_and_scale_batch (dsm_stream_*): a pool of resident problems advanced in passes; problems
     are admitted as slots free up and retire individually.  Results are bit-identical to the batch calls."""
 
-    def __init__(self, ctx, track_slots, scale_slots=0):
+    def __init__(self, ctx, track_slots, scale_slots=0, engine=None, ticks=0):
         self.ctx, self.L = ctx, ctx.L
         h = C.c_void_p()
         check(self.L.dsm_stream_create(ctx.h, int(track_slots), int(scale_slots), C.byref(h)))
         self.h = h
+        if engine is not None:
+            self.set_engine(engine, ticks)
+
+    def set_engine(self, engine, ticks=0):
+        """0: passes with carried stragglers; 1 (the library's default): ticks (one LM round per resident problem and tick, device-side admission)"""
+        check(self.L.dsm_stream_set_engine(self.h, int(engine), int(ticks)))
 
     def close(self):
         if getattr(self, "h", None):

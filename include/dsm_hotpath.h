@@ -335,6 +335,15 @@ int dsm_stream_advance(dsm_stream *s);
 int dsm_stream_drain(dsm_stream *s);
 int dsm_stream_results(dsm_stream *s, int max_results, dsm_stream_result *out, int *n_out);
 int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *results_out);
+/* The engine behind advance (set before the first advance / while nothing is resident):
+ *   0  PASSES: one sweep down the pyramid per advance with a bounded number of lock-step rounds per level (below); problems
+ *      that need more are carried over to the next pass;
+ *   1  TICKS: every resident problem advances ONE LM round per tick whatever level it stands on -- one evaluation launch over
+ *      a device-built list of (problem, chunk) items of all levels mixed, one LM launch that steps the problems, stages the
+ *      next tick's items, retires finished problems and refills their slots from the waiting list ON THE DEVICE; an advance
+ *      runs ticks_per_advance ticks (0: keep; default 32) with one host read-back at its end.  The default.
+ * Both are scheduling only: results are bit-identical to the batch calls. */
+int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance);
 /* rounds per level of a pass = this quantile (default 0.75) of the rounds recently retired problems needed there;
  * lvl < 0: every level */
 int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q);

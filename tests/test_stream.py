@@ -19,11 +19,11 @@ def _batch_reference(ctx, trks, nl, scales):
     return good, poses, affs, last, flow, err, sc, ev_t, ev_s
 
 
-def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1):
+def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1, engine=0, ticks=0):  # noqa: PLR0913
     from direct_stereo_slam_amd.tracker import Stream
 
     n = len(trks)
-    st = Stream(ctx, track_slots, scale_slots)
+    st = Stream(ctx, track_slots, scale_slots, engine, ticks)
     if rounds is not None:
         st.set_rounds(0, rounds)
         st.set_rounds(1, rounds)
@@ -98,6 +98,13 @@ def test_stream_results_equal_the_batch_calls_bit_for_bit(ctx, streams):
             _check(res, ref, len(trks), nl)
             if rounds is not None:
                 assert max(r.passes for r in res.values()) > 1  # problems really were carried
+        # the tick engine: every resident problem advances one round per tick, admission and retirement on the device.
+        # (a) a pool as large as the job; (b) a small pool, few ticks per advance: slots are refilled inside an advance and
+        # across advances; (c) one tick per advance, submissions in waves; (d) many ticks: problems admitted AND retired
+        # inside one advance
+        for slots, sslots, ticks, waves in ((20, 20, 16, 1), (7, 5, 5, 1), (6, 4, 1, 3), (3, 2, 200, 2)):
+            res, passes, sched = _stream_run(ctx, trks, nl, scales.copy(), slots, sslots, None, None, waves, engine=1, ticks=ticks)
+            _check(res, ref, len(trks), nl)
     finally:
         ctx.set_streams(1)
 
@@ -113,36 +120,40 @@ def test_stream_with_fixed_schedule_and_mixed_coarsest_levels(ctx):
     trks = [hip_tracker(ctx, sc, p) for sc in scs]
     n = len(trks)
     ref = ctx.track_batch(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
-    st = Stream(ctx, 4, 0)
-    tk = st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
-    st.drain()
-    got = {r.ticket: r for r in st.results()}
-    for i, t in enumerate(tk):
-        assert np.array_equal(np.array(got[t].pose), ref[1][i]) and got[t].passes == 1  # exactly one pass per problem
-    st.close()
+    for engine in (0, 1):
+        st = Stream(ctx, 4, 0, engine)
+        tk = st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+        st.drain()
+        got = {r.ticket: r for r in st.results()}
+        for i, t in enumerate(tk):
+            assert np.array_equal(np.array(got[t].pose), ref[1][i])
+            assert engine == 1 or got[t].passes == 1  # passes: exactly one pass per problem
+        st.close()
     # different starting levels: each against its own single call
     trks = [hip_tracker(ctx, sc) for sc in scs]
-    st = Stream(ctx, 3, 0)
-    tks = []
-    for i, t in enumerate(trks):
-        tks += st.submit_track([t], [S.IDENTITY_POSE], np.zeros((1, 2)), nl - 1 - (i % 2))
-    st.drain()
-    got = {r.ticket: r for r in st.results()}
-    for i, t in enumerate(trks):
-        good, pose, aff, last = t.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], nl - 1 - (i % 2))
-        r = got[tks[i]]
-        assert bool(r.good) == bool(good) and np.array_equal(np.array(r.pose), pose)
-        assert np.array_equal(np.array(r.last_residuals), np.asarray(last), equal_nan=True)
-    st.close()
+    for engine in (0, 1):
+        st = Stream(ctx, 3, 0, engine)
+        tks = []
+        for i, t in enumerate(trks):
+            tks += st.submit_track([t], [S.IDENTITY_POSE], np.zeros((1, 2)), nl - 1 - (i % 2))
+        st.drain()
+        got = {r.ticket: r for r in st.results()}
+        for i, t in enumerate(trks):
+            good, pose, aff, last = t.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], nl - 1 - (i % 2))
+            r = got[tks[i]]
+            assert bool(r.good) == bool(good) and np.array_equal(np.array(r.pose), pose)
+            assert np.array_equal(np.array(r.last_residuals), np.asarray(last), equal_nan=True)
+        st.close()
 
 
-def test_stream_argument_checks(ctx):
+@pytest.mark.parametrize("engine", [0, 1])
+def test_stream_argument_checks(ctx, engine):
     from direct_stereo_slam_amd._lib import DsmError
     from direct_stereo_slam_amd.tracker import Stream
 
     sc = make_scene("small", seed=790)
     trk = hip_tracker(ctx, sc)
-    st = Stream(ctx, 2, 0)
+    st = Stream(ctx, 2, 0, engine)
     with pytest.raises(DsmError):
         st.submit_scale([trk], np.ones(1, np.float32), sc.nl - 1)  # no scale slots
     with pytest.raises(DsmError):
