@@ -112,7 +112,7 @@ def parse():
     ap.add_argument("--device-override", type=int, default=-1, help="testing: put every rank on this device")
     ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidths (two access patterns) and exit")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search alone instead")
-    ap.add_argument("--no-ringkey-leg", action="store_true", help="N > 1: skip the sharded ring-key leg of the default line")
+    ap.add_argument("--no-ringkey-leg", action="store_true", help="skip the ring-key leg of the default line (N = 1: config.ringkey; N > 1: config.ringkey_sharded)")
     ap.add_argument("--ringkey-leg-seconds", type=float, default=120.0, help="N > 1: deadline of the sharded ring-key leg; a rank that misses it reports an error in config.ringkey_sharded and the line is printed regardless")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
@@ -465,6 +465,7 @@ class StreamRunner:
         poses = np.array([list(self.out[t].pose) for t in tk])
         err = np.array([self.out[t].err for t in ts], np.float32)
         sc = np.array([self.out[t].scale for t in ts], np.float32)
+        self.last_evals = np.array([list(self.out[t].evals) for t in tk], np.int64)  # per frame and level
         return good, poses, err, sc
 
     def close(self):
@@ -496,6 +497,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     run.acc = None
     timed_passes = run.passes - p0
     good, poses, err, sc = run.results_of(("t", steps - 1))
+    last_evals = run.last_evals
     sched = run.st.schedule(0)
     # roofline of the dominant kernel: steady-state passes (the pool refilled every pass) with HIP events around every eval dispatch
     for i in range(10):
@@ -570,6 +572,8 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
                          "ticks_per_advance": (args.stream_ticks or 32) if ticks else None,
                          "rounds_per_level_of_a_pass": None if ticks else sched["rounds"][:wl["nl"]], "quantile": args.stream_quantile if args.stream_quantile is not None else "library default",
                          "frames_submitted": frames, "ms_per_pass": 1e3 * dt / max(1, timed_passes),
+                         "device_ms_per_advance": float(timed["ms"]) / max(1, timed_passes),
+                         "host_share_of_timed_region": 1.0 - float(timed["ms"]) * 1e-3 / dt,
                          "steady_state": {"frames_per_s": steady["retired"] / steady["wall"], "passes": int(steady["passes"]), "frames_retired": int(steady["retired"]),
                                           "ms_per_pass": 1e3 * steady["wall"] / max(1, steady["passes"]),
                                           "what": "8 advances after the timed region with waiting frames at hand all the time: frames retired / wall time (no ramp-up, no drain)"}},
@@ -582,7 +586,8 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
               "initial_guess": args.init if args.init == "identity" else f"constant-motion (error sigma {args.init_err} x motion sigma)", "texture_list": args.textures,
               "fixed_schedule": int(wl["params"].fixed_schedule), "work_queue": int(wl["params"].work_queue),
               "frames_with_translation_error_above_1cm": int((terr_all > 0.01).sum()), "all_tracked": bool(good.all())}
-    return dict(dt=dt, value=world * frames / dt, ms_per_step=1e3 * dt / steps, good=good, poses=poses, roofline=roofline, detail=detail, n0=n0)
+    return dict(dt=dt, value=world * frames / dt, ms_per_step=1e3 * dt / steps, good=good, poses=poses, roofline=roofline, detail=detail, n0=n0,
+                evals=last_evals)
 
 
 def kernel_source_sha():
@@ -802,7 +807,7 @@ def cpu_all_cores(args, wl, per_core=6):
                       f"together, {wall:.2f} s from the common start to the last finish"}
 
 
-def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
+def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None, gpu_evals=None):
     """the oracle with calcGSSSEPose / calcGSSSEScale in their SSE-intrinsics form (oracle/dsm_oracle_sse.c: the
     reference's own loop structure, TrackerAndScaler.cpp:640-697,966-1005) timed on this box's host cores: 1 thread, as
     the reference runs this path on the image-callback thread.  Built with -O3 -march=native like CMakeLists.txt:4-6."""
@@ -815,7 +820,7 @@ def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
     model, phys, logical = host_cpu_info()
     wlc = {**{k: wl[k] for k in ("nl", "w", "h", "T", "K")}, "fixed_schedule": int(wl["params"].fixed_schedule)}
     n_min = min(len(frames), args.cpu_min_frames)
-    cpu_poses, cpu_good = [], []
+    cpu_poses, cpu_good, cpu_evals = [], [], []
     dt = 0.0
     for i, fr in enumerate(frames):
         if i >= n_min and dt > args.cpu_seconds:  # at least cpu_min_frames distinct frames, then until the time budget is spent
@@ -823,6 +828,9 @@ def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
         orc = _oracle_tracker(wlc, fr)  # set-up (pyramids, template upload) is outside the timed region, as on the GPU
         t0 = time.perf_counter()
         r = orc.track(fr[3], [0, 0], nl - 1)
+        dt += time.perf_counter() - t0
+        cpu_evals.append(orc.eval_counts()[0])  # (outside the timed region)
+        t0 = time.perf_counter()
         if i % args.kf_every == 0:
             orc.optimize_scale(1.0, nl - 1)
         dt += time.perf_counter() - t0
@@ -849,9 +857,22 @@ def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None):
                                  "frames_cpu_path_ends_in_a_wrong_minimum": int((~ok).sum()),
                                  "of_which_gpu_path_too": int((np.abs(gp[~ok] - gt[~ok]).max(1) > 0.01).sum()),
                                  "all_frames": {"frames": n, "ate_gpu_m": ate(gp, gt), "ate_cpu_m": ate(cp, gt)},
+                                 # the same ratio over EVERY frame, next to the filtered one (rounds 1-2 reported this one as the headline;
+                                 # on frames both paths lose it compares two wrong minima)
+                                 "ate_ratio_gpu_over_cpu_all_frames": ate(gp, gt) / max(ate(cp, gt), 1e-30),
                                  "distinct_frames": n,
                                  "good_flags_equal": bool(np.array_equal(np.asarray(gpu_good)[:n].astype(bool), np.array(cpu_good))),
                                  "all_tracked_cpu": bool(all(cpu_good))}
+        if gpu_evals is not None:
+            # LM route of every frame on both paths: the per-level evaluation counts (equal counts = the same accept / reject /
+            # break decisions all the way, TrackerAndScaler.cpp:559,588) and, with equal counts, the end points
+            ce, ge = np.array(cpu_evals, np.int64)[:, :nl], np.asarray(gpu_evals)[:n, :nl]
+            same = (ce == ge).all(1)
+            pd = np.abs(np.asarray(gpu_poses)[:n] - np.array(cpu_poses)).max(1)
+            out["lm_routes_vs_cpu_ref"] = {"frames": n, "same_evaluation_counts": int(same.sum()), "different_evaluation_counts": int((~same).sum()),
+                                           "same_counts_but_poses_apart_1e-4": int((same & (pd >= 1e-4)).sum()),
+                                           "different_counts_among_frames_the_cpu_path_tracks": int((~same & ok).sum()),
+                                           "max_pose_diff_same_route": float(pd[same & (pd < 1e-4)].max()) if (same & (pd < 1e-4)).any() else None}
     if not args.no_cpu_all_cores:
         try:
             out["all_cores"] = cpu_all_cores(args, wl)
@@ -956,6 +977,74 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
             "shards": world, "merge": "dsm_ringdb_merge_topk (C ABI, librccl)" if world > 1 else "one shard: no merge", **res}
 
 
+VALU_PEAK_TOPS = 78.6  # MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector counts an FMA as two; unfused add / mul / sub issue at half of that
+
+
+def ringkey_single_gpu_leg(args, ctx, seconds=0.25):
+    """config.ringkey of the N = 1 line: search_ringkey's k-NN (search_place.h:25-57) on ONE GPU at SURVEY.md
+    8(d)'s sizes, each with its own roofline -- HBM for the few-query scan (one sweep of the 80-byte keys), the vector pipes for
+    the many-query kernel (FLANN's L2 functor: 59 unfused operations per (query, key) pair) --, an in-run bit-exact check
+    against the oracle's brute force and a brute-force CPU baseline on the same keys (one core, bounded sample)."""
+    import torch
+
+    from direct_stereo_slam_amd.ringdb import RingKeyDB, unpack
+    from oracle import oracle as O
+
+    cases = []
+    for n, q in ((10_000, 1024), (1_000_000, 1024), (10_000_000, 1024), (10_000_000, 1)):
+        keys, qs = make_ringkey_data(n, q)
+        db = RingKeyDB(ctx, capacity=n + 16)
+        db.add_points(keys)
+        dq = torch.from_numpy(qs).cuda()
+        out = torch.empty((q, 3), dtype=torch.int64, device="cuda")
+
+        def call():
+            db.knn_packed_device(dq.data_ptr(), q, out.data_ptr())
+            ctx.sync()
+
+        for _ in range(3):
+            call()
+        t0 = time.perf_counter()
+        call()
+        one = time.perf_counter() - t0
+        reps = max(3, min(2000, int(seconds / max(one, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        dt = (time.perf_counter() - t0) / reps
+        got_d, got_i = unpack(out.cpu().numpy())
+        # oracle: brute force over the same keys (FLANN L2 accumulation order), a bounded number of the queries
+        orc = O.OracleRingDB(native=True)
+        orc.add_points(keys)
+        n_chk = max(1, min(q, int(2e8 // n)))
+        ok = True
+        t0 = time.perf_counter()
+        ref = [orc.knn(qs[i]) for i in range(n_chk)]
+        cpu_dt = time.perf_counter() - t0
+        for i, (io, do) in enumerate(ref):
+            exp = [(np.float32(d), j) for d, j in zip(do, io) if j >= 0 and d < 0.1]
+            got = [(np.float32(d), int(j)) for d, j in zip(got_d[i], got_i[i]) if j >= 0]
+            ok = ok and got == exp
+        pairs = float(n) * q
+        if q <= 32:
+            groups = (q + 7) // 8 if q > 8 else 1
+            by = 80.0 * n * groups + 104.0 * q
+            roof = {"bound": "hbm", "achieved": by / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / dt / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "ringkey_knn_fewq4_kernel" if q <= 2 else "ringkey_knn_fewq_kernel", "bytes_per_call": by}
+        else:
+            ops = 59.0 * pairs
+            roof = {"bound": "valu", "achieved": ops / dt / 1e12, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32 vector operations: 20 sub + 20 mul + 19 add per pair, FLANN's order)",
+                    "frac": ops / dt / 1e12 / VALU_PEAK_TOPS, "kernel": "ringkey_knn_kernel", "hbm_GBps": (80.0 * n + 104.0 * q) / dt / 1e9}
+        cases.append({"N": n, "Q": q, "us_per_call": 1e6 * dt, "queries_per_s": q / dt, "pairs_per_s": pairs / dt, "roofline": roof,
+                      "matches_oracle_bit_exact": bool(ok), "queries_checked": n_chk,
+                      "cpu_baseline": {"value": n_chk / cpu_dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                                       "sample": f"{n_chk} of the {q} queries, brute force over the same {n} keys (oracle/dsm_oracle.c orc_ringdb_knn, gcc -O3 -march=native), {cpu_dt:.2f} s"}})
+        db.close()
+        del orc, dq, out
+    return {"workload": "search_ringkey k-NN (k = 3, threshold 0.1) over N x 20 float keys, Q queries per call, one GPU, keys and queries resident",
+            "cases": cases}
+
+
 def line_guard(res):
     """The sharded ring-key leg is this bench's first contact with several RCCL ranks on a box; a process that dies inside a
     native library (SIGSEGV, abort) prints nothing.  Before the leg, rank 0 parks its finished bench line with a forked
@@ -966,6 +1055,8 @@ def line_guard(res):
     parked = copy.deepcopy(res)
     parked["config"]["ringkey_sharded"] = {"error": "rank 0 ended inside the sharded ring-key leg (the bench line is the one measured before it)"}
     text = (json.dumps(parked) + "\n").encode()
+    # (os.pipe() descriptors are non-inheritable across exec (PEP 446), and the guard is made after every other child of this
+    # process -- the CPU legs' forked workers -- has come and gone: nobody else holds the write end)
     r, w = os.pipe()
     sys.stdout.flush()
     pid = os.fork()
@@ -1044,7 +1135,7 @@ def bench_tracking(args):
         "roofline": m["roofline"],
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(args, wl, m["poses"], m["good"])
+        res["cpu_baseline"] = cpu_baseline(args, wl, m["poses"], m["good"], m.get("evals"))
     else:
         res["cpu_baseline"] = None
     del wl
@@ -1062,7 +1153,7 @@ def bench_tracking(args):
                    "evals_per_frame_by_level": m3["detail"]["evals_per_frame_by_level"], "launch_pairs_per_step": m3["detail"]["launch_pairs_per_step"],
                    "roofline": m3["roofline"]}
             if rank == 0 and world == 1 and not args.no_cpu:
-                leg["cpu_baseline"] = cpu_baseline(a3, wl3, m3["poses"], m3["good"])
+                leg["cpu_baseline"] = cpu_baseline(a3, wl3, m3["poses"], m3["good"], m3.get("evals"))
             res["config"]["fixed_schedule_leg"] = leg
             del wl3
         except Exception as e:  # a reported extra, never a reason to lose the bench line
@@ -1079,6 +1170,11 @@ def bench_tracking(args):
             del wl2
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["reference_five_level"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_ringkey_leg and not args.with_upload:
+        try:
+            res["config"]["ringkey"] = ringkey_single_gpu_leg(args, ctx)
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            res["config"]["ringkey"] = {"error": repr(e)}
     stuck = False
     if world > 1 and not args.no_ringkey_leg and args.device_override < 0:  # (RCCL refuses two ranks on one device)
         # A reported extra must never cost the bench line: the leg runs under a deadline (a collective that one rank never

@@ -256,7 +256,10 @@ int dsm_ringdb_attach_comm(dsm_ringdb *db, dsm_comm *comm) {
   if (comm && (comm->ctx != db->ctx || comm->nranks != db->shard_count || comm->rank != db->shard_rank))
     return invalid("dsm_ringdb_attach_comm: the communicator's context / rank / size must match the database's shard");
   if (db->comm && db->comm != comm) ringdb_forget_comm(db);
-  if (comm && !db->d_agree) DSM_HIP(hipMalloc(&db->d_agree, 4 * sizeof(unsigned long long)));
+  if (comm && !db->d_agree) {
+    DSM_HIP(hipSetDevice(db->ctx->device)); // (a process that drives several devices: the buffer belongs on the context's)
+    DSM_HIP(hipMalloc(&db->d_agree, 4 * sizeof(unsigned long long)));
+  }
   db->comm = comm;
   if (comm && std::find(comm->attached.begin(), comm->attached.end(), db) == comm->attached.end()) comm->attached.push_back(db);
   return DSM_OK;
@@ -298,17 +301,40 @@ void dsm::ringdb_forget_comm(dsm_ringdb *db) {
 }
 
 int dsm::ringdb_agree(dsm_ringdb *db, bool ready, const char *why_not) {
-  if (!db->d_agree || (!db->comm && !db->tr_allreduce)) {
+  if (!db->comm && !db->tr_allreduce) { // no transport at all: nobody is waiting for this rank in a collective
     set_error("sharded ring-key DB: attach a communicator first (dsm_ringdb_attach_comm)");
     return DSM_ERR_STATE;
   }
   hipStream_t st = db->ctx->stream;
+  // A failure on THIS rank before the collective must not make it leave alone -- the other ranks would wait in the
+  // all-reduce for ever, which is what this round exists to prevent: it becomes "not ready" and the rank still takes part.
+  std::string local_err;
+  if (!db->d_agree) { // (attached without the buffer: make it now)
+    hipError_t e = hipSetDevice(db->ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&db->d_agree, 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+      hip_fail(e, "ringdb_agree: allocating the agreement words", __FILE__, __LINE__);
+      return DSM_ERR_HIP; // without a device buffer this rank cannot enter the collective at all
+    }
+  }
   // (every word stays below 2^63: transports may order the words as signed integers, as the packed candidates allow)
   const unsigned long long kBig = 1ull << 62, sz = (unsigned long long)db->size_global;
   unsigned long long w[3] = {ready ? 1ull : 0ull, sz, kBig - sz};
-  DSM_HIP(hipMemcpyAsync(db->d_agree, w, sizeof w, hipMemcpyHostToDevice, st));
+  {
+    hipError_t e = hipMemcpyAsync(db->d_agree, w, sizeof w, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { // say "not ready" by other means and go on into the collective
+      local_err = std::string("staging the agreement words failed: ") + hipGetErrorString(e);
+      ready = false;
+      (void)hipMemsetAsync(db->d_agree, 0, sizeof w, st);
+    }
+  }
   int rc = db->comm ? rccl_allreduce_min(db->comm, db->d_agree, 3, (void *)st) : db->tr_allreduce(db->tr_user, db->d_agree, 3, (void *)st);
   if (rc) return rc;
+  if (!local_err.empty()) {
+    (void)hipStreamSynchronize(st);
+    set_error("collective ring-key query: this rank could not take part: " + local_err);
+    return DSM_ERR_STATE;
+  }
   DSM_HIP(hipMemcpyAsync(w, db->d_agree, sizeof w, hipMemcpyDeviceToHost, st));
   DSM_HIP(hipStreamSynchronize(st));
   if (w[0] != 1ull) {

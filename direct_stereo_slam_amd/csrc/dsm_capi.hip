@@ -1112,6 +1112,19 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
       spec[L] = P.fixed_schedule <= 0 && (P.speculate >= 2 || (P.speculate == 1 && max_n <= 8192 && launch_points <= 1000000ll));
     }
   }
+  // the learnt "rounds most problems need" belong to calls of this size and form: another batch-size bucket (powers of four)
+  // or form must not inherit them (a batch of hundreds following a single-frame call would switch to compact launches after
+  // one round, covering almost every problem)
+  {
+    int bucket = 0;
+    for (int v = N; v >= 4; v >>= 2) bucket++;
+    const int key = bucket * 4 + (use_queue ? 2 : 0) + (P.persistent_coarse > 0 ? 1 : 0);
+    if (key != ctx->sched_bulk_key) {
+      for (int m = 0; m < 3; m++)
+        for (int l = 0; l < DSM_MAX_LEVELS; l++) ctx->sched_bulk[m][l] = 1 << 30;
+      ctx->sched_bulk_key = key;
+    }
+  }
   int *sched = ctx->sched[mode], *sched2 = ctx->sched[mode2];
   const int *bulk = ctx->sched_bulk[mode], *bulk2 = ctx->sched_bulk[mode2];
   int ng = ctx->n_streams < 1 ? 1 : ctx->n_streams;

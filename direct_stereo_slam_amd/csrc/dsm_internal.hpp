@@ -76,6 +76,7 @@ struct dsm_context {
   // rounds the problems of recent calls needed): from there on a round is ONE fused evaluate + step launch (dsm_params.fuse_lm = 1)
   int sched_bulk[3][DSM_MAX_LEVELS] = {{1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30}, {1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30},
                                        {1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30, 1 << 30}};
+  int sched_bulk_key = -1; // batch-size bucket and launch form the sched_bulk figures were learnt on
   // stats / timing
   bool timing = false;
   dsm_stats stats{};

@@ -159,8 +159,13 @@ __device__ __forceinline__ void taps_gradients(const Taps &T, float w00, float w
   const float d01 = fix(T.r2[2] - T.r2[0]), d11 = fix(T.r2[3] - T.r2[1]);
   const float e00 = fix(T.r2[1] - T.r0[0]), e10 = fix(T.r2[2] - T.r0[1]);
   const float e01 = fix(T.r3[0] - T.r1[1]), e11 = fix(T.r3[1] - T.r1[2]);
+#ifdef DSM_REF_POINT_OPS // A/B build (tools/experiments/lm_flip_attribution.py): getInterpolatedElement33's own association, unfused
+  g1 = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
+  g2 = ((w11 * e11 + w01 * e01) + w10 * e10) + w00 * e00;
+#else
   g1 = __builtin_fmaf(w00, d00, __builtin_fmaf(w10, d10, __builtin_fmaf(w01, d01, w11 * d11)));
   g2 = __builtin_fmaf(w00, e00, __builtin_fmaf(w10, e10, __builtin_fmaf(w01, e01, w11 * e11)));
+#endif
 }
 template <bool EXACT, bool GRAD = true>
 __device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1, float &g2) {
@@ -295,7 +300,11 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
           };
           W.u = quot(pt0);
           W.v = quot(pt1);
+#ifdef DSM_REF_POINT_OPS
+          W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2;
+#else
           W.new_idepth = MODE == 2 ? r1 : id * r1;
+#endif
         }
       }
       const float Ku = fxl * W.u + cxl;
@@ -323,7 +332,11 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       // scales this point's terms of E and of the normal equations -- sums that are compared to tolerance, E then
       // entering the LM accept test like any other rounding of the sum -- so the hardware reciprocal (1 ulp)
       // replaces the IEEE division.
+#if defined(DSM_REF_POINT_OPS) || defined(DSM_IEEE_HUBER)
+      const float hw = ar < huber ? 1.0f : huber / ar; // the reference's IEEE division (:794-795)
+#else
       const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
+#endif
       const bool sat = ar > cutoff;                    // :797
       const bool use = fin && !sat;
       const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
@@ -345,10 +358,17 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         float J[9];
         J[0] = nid * dx;
         J[1] = nid * dy;
+#ifdef DSM_REF_POINT_OPS // calcGSSSEPose's unfused SSE sequence (:664-677)
+        J[2] = 0.0f - nid * (u * dx + v * dy);
+        J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+        J[4] = (u * v) * dy + dx * (1.0f + u * u);
+        J[5] = u * dy - v * dx;
+#else
         J[2] = -(nid * __builtin_fmaf(u, dx, v * dy));
         J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
         J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
         J[5] = __builtin_fmaf(u, dy, -(v * dx));
+#endif
         J[6] = keep(aff0 * (b0 - refColor));
         J[7] = -1.0f;
         J[8] = keep(residual);
@@ -358,7 +378,11 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
           const float Jw = J[r] * wgt;
   #pragma unroll
           for (int c = r; c < 9; c++) {
+#ifdef DSM_REF_POINT_OPS // Accumulator9::updateSSE_eighted: _mm_add_ps(acc, _mm_mul_ps(Jw, J)), unfused
+            acc[idx] = acc[idx] + Jw * J[c];
+#else
             acc[idx] = __builtin_fmaf(Jw, J[c], acc[idx]);
+#endif
             idx++;
           }
         }
@@ -760,8 +784,12 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
   return ((double)hf * (double)invn) * scale_of(p, r);
 }
 
-// Eigen LDLT<Lower> + solve (call sites :509,:513,:518,:529), restated operation for operation from Eigen's unblocked
-// in-place algorithm (the CPU checker restates the same sequence), executed by one wave on wave-uniform data.
+// Eigen LDLT<Lower> + solve (call sites :509,:513,:518,:529): the unblocked in-place algorithm restated from its published
+// form -- the same restatement the CPU checker (orc_ldlt_solve) carries, and it is THAT checker the
+// increments are bit-identical to.  Real Eigen is not in this image and was never run against either: its A21 update goes
+// through the gemv kernel (column blocks of four, alpha = -1 folded into the accumulation), so last-bit differences from the
+// reference's own solve are possible; the pivot-order argument below does not depend on that.  Executed by one wave on
+// wave-uniform data.
 //
 // Eigen's unblocked LDLT is LEFT-looking: at step k it looks for the first maximum of |diagonal| among the rows not yet
 // eliminated, swaps it into position k, and only then applies the pending updates to column k.  The diagonal entries it
@@ -777,8 +805,8 @@ __device__ __forceinline__ double build_b_elem(const ParamsDev &p, const double 
 //      with ONE division per step; no pivot search and no divergence inside the chain; L^-T gets its columns through a
 //      64-word LDS transpose;
 //   4. the solution is un-permuted through eight LDS words.
-// Every element sees Eigen's operations in Eigen's order (the CPU checker restates the same sequence): given bitwise equal H
-// and b the increments are bitwise equal.  (The fully wave-uniform form of the same arithmetic -- every lane all 36 entries --
+// Every element sees the checker's operations in the checker's order: given bitwise equal H and b the increments are bitwise
+// equal to the checker's (not: proven equal to Eigen's, see above).  (The fully wave-uniform form of the same arithmetic -- every lane all 36 entries --
 // took 6.8-7.7 k shader cycles, issue-bound by its 36 IEEE double divisions; the cross-lane right-looking form of rounds
 // 1-2, another pivot order, 7.7 k.)
 // Rows / columns whose bit is clear in `active` do not take part (the 6- and 7-dim sub-solves): they are ordered last and
@@ -1817,6 +1845,19 @@ __global__ __launch_bounds__(kCoarseThreads) __attribute__((amdgpu_waves_per_eu(
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_px, bool spec) {
   if (max_px > kCoarseArenaFloats) max_px = kCoarseArenaFloats;
+  {
+    // never ask for more LDS than the device gives a workgroup (gfx950: 160 KB; the kernel's static part is ~39 KB)
+    static int lds_limit = 0;
+    if (!lds_limit) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+        lds_limit = v;
+      else
+        lds_limit = 64 * 1024;
+    }
+    const int room = (lds_limit - 40 * 1024) / (int)sizeof(float);
+    if (max_px > room) max_px = room > 0 ? room : 0;
+  }
   const int arena_floats = (max_px + 3) & ~3;
   dim3 grid(nprob), block(kCoarseThreads);
   const size_t dyn = sizeof(float) * (size_t)arena_floats;
