@@ -66,6 +66,10 @@ def parse():
                          "motion's sigma).  Measured on the CPU path (DESIGN.md section 6): neither the evaluations per frame nor the share of "
                          "frames that end in a wrong minimum (6-11 %%) depend on it")
     ap.add_argument("--init-err", type=float, default=0.25, help="sigma of the constant-motion guess's error as a fraction of the motion's sigma")
+    ap.add_argument("--scene-family", default="relief", choices=["relief", "plane"],
+                    help="'relief' (default, round 4): synth.ReliefScene -- a smooth relief over the plane under a broadband texture (32 sinusoids, 6-480 px); the "
+                         "CPU oracle tracks every frame of this family from the identity guess (tools/scene_failure_rate.py).  'plane': rounds 1-3's single "
+                         "textured plane (eight sinusoids, 8-128 px), on which the reference algorithm itself ends in a wrong minimum on 6-11 %% of the frames")
     ap.add_argument("--textures", default="all", choices=["all", "converging"],
                     help="'all' (default): textures 0 .. 17, nothing left out; 'converging': round 2's hand-picked list (SCENE_SEEDS: the "
                          "textures on which the reference algorithm converges from the identity guess for THEIR first motion)")
@@ -248,14 +252,15 @@ def build_frames(args, w, h, K, T):
     seeds = frame_seeds(args)
     n_frames = args.scenes if args.scenes else args.batch
     n_tex = min(len(seeds), n_frames)
-    key = (w, h, tuple(K), n_frames, args.init, args.init_err, args.textures, bool(args.u8))
+    key = (w, h, tuple(K), n_frames, args.init, args.init_err, args.textures, bool(args.u8), args.scene_family)
+    Scene = S.ReliefScene if args.scene_family == "relief" else S.PlaneScene
     if key in _FRAMES:  # (the fixed-schedule leg runs on the frames of the headline leg)
         return _FRAMES[key]
     u8 = (lambda im: np.clip(np.rint(im), 0, 255).astype(np.float32)) if args.u8 else (lambda im: im)
     textures, first = [], []
     for k in range(n_tex):
         seed = 0x5EED0000 + seeds[k]
-        scene = S.PlaneScene(seed=seed)
+        scene = Scene(seed=seed)
         rng = np.random.default_rng(seed)
         ref = scene.render(K, w, h, noise=2.0, rng=rng)
         R, t = S.random_motion(rng)
@@ -584,6 +589,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
               "pose_eval_kernels_by_level": per_level, "max_abs_translation_error_m": float(terr_all.max()),
               "distinct_frames": int(wl["distinct_frames"]), "textures": int(wl["textures"]),
               "initial_guess": args.init if args.init == "identity" else f"constant-motion (error sigma {args.init_err} x motion sigma)", "texture_list": args.textures,
+              "scene_family": args.scene_family,
               "fixed_schedule": int(wl["params"].fixed_schedule), "work_queue": int(wl["params"].work_queue),
               "frames_with_translation_error_above_1cm": int((terr_all > 0.01).sum()), "all_tracked": bool(good.all())}
     return dict(dt=dt, value=world * frames / dt, ms_per_step=1e3 * dt / steps, good=good, poses=poses, roofline=roofline, detail=detail, n0=n0,
@@ -708,6 +714,7 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
               "whole_step_GBps": all_bytes / (1e-3 * (stt.total_ms + sts.total_ms)) / 1e9,
               "pose_eval_kernels_by_level": per_level, "max_abs_translation_error_m": float(terr_all.max()),
               "distinct_frames": int(wl["distinct_frames"]), "textures": int(wl["textures"]), "initial_guess": args.init if args.init == "identity" else f"constant-motion (error sigma {args.init_err} x motion sigma)", "texture_list": args.textures,
+              "scene_family": args.scene_family,
               "fixed_schedule": int(wl["params"].fixed_schedule), "work_queue": int(wl["params"].work_queue),
               "frames_with_translation_error_above_1cm": int((terr_all > 0.01).sum()), "all_tracked": bool(good.all())}
     return dict(dt=dt, value=world * B * steps / dt, ms_per_step=1e3 * dt / steps, good=good, poses=poses, roofline=roofline,
@@ -716,7 +723,8 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
 
 def workload_label(args, wl, n0):
     sched = f"fixed schedule 1+{wl['params'].fixed_schedule} evaluations per level" if wl["params"].fixed_schedule > 0 else "LM as executed"
-    return (f"{CONFIGS[wl['config']][3]}, {args.template} template n0={n0}, {sched}, {wl['distinct_frames']} distinct frames, "
+    scenes = "relief scenes (broadband texture)" if args.scene_family == "relief" else "single-plane scenes of rounds 1-3"
+    return (f"{CONFIGS[wl['config']][3]}, {args.template} template n0={n0}, {sched}, {wl['distinct_frames']} distinct frames, {scenes}, "
             f"track every frame + scale-opt every {args.kf_every}th")
 
 

@@ -146,6 +146,77 @@ class PlaneScene:
         return ((r @ (R @ self.n)) / (self.d + self.n @ (R.T @ t))).astype(np.float32)
 
 
+class ReliefScene(PlaneScene):
+    """A textured RELIEF over the plane n.X = d: the surface point above plane coordinates (p, q) is raised by hgt(p, q) along the
+    normal -- a few smooth bumps of 3 - 9 m wavelength, 0.15 m in all: depth structure and parallax instead of one homography, slopes
+    below the shallowest viewing angle so that no ray meets the surface twice -- and the
+    texture is broadband: 32 sinusoids of wavelengths 6 ... 480 px (amplitude ~ wavelength^spectrum; 0 = equal weights, 1 = a
+    natural-image-like 1/f spectrum) instead of eight between 8 and 128 px, so that every pyramid level sees unambiguous structure
+    and a frame's cost surface has one basin at the scale of the motion prior (the eight-wave single-plane scenes drive the
+    reference algorithm itself into a wrong minimum on 6-11 % of the frames from the identity guess; on this family
+    the CPU oracle tracks 96 of 96 frames: tools/scene_failure_rate.py).  Ray casting: Newton iterations from the plane's
+    intersection."""
+
+    def __init__(self, seed=0, normal=(-0.5, 0.6, 1.0), dist=6.0, n_waves=32, wavelength_px=(6.0, 480.0), fx_ref=718.856, relief_m=0.15,
+                 relief_wavelength_m=(3.0, 9.0), n_bumps=5, spectrum=0.0):
+        super().__init__(seed, normal, dist, n_waves, wavelength_px, fx_ref)
+        rng = np.random.default_rng(seed ^ 0x0BADC0DE)
+        z0 = self.d / self.n[2]
+        px = z0 / fx_ref
+        lam = np.exp(rng.uniform(math.log(wavelength_px[0]), math.log(wavelength_px[1]), n_waves)) * px
+        ang = rng.uniform(0, 2 * math.pi, n_waves)
+        self.freq = np.stack([np.cos(ang) / lam, np.sin(ang) / lam], 1)
+        self.phase = rng.uniform(0, 2 * math.pi, n_waves)
+        self.amp = rng.uniform(0.6, 1.0, n_waves) * (lam / lam.max()) ** spectrum
+        self.amp *= 100.0 / np.sqrt((self.amp ** 2).sum()) / 2.2  # rms ~ 32 grey levels; clipped to [0, 255] when rendered
+        bl = rng.uniform(relief_wavelength_m[0], relief_wavelength_m[1], n_bumps)
+        ba = rng.uniform(0, 2 * math.pi, n_bumps)
+        self.bfreq = np.stack([np.cos(ba) / bl, np.sin(ba) / bl], 1)
+        self.bphase = rng.uniform(0, 2 * math.pi, n_bumps)
+        self.bamp = rng.uniform(0.5, 1.0, n_bumps)
+        self.bamp *= relief_m / self.bamp.sum()
+
+    def height(self, p, q, grad=False):
+        hgt = np.zeros(np.shape(p))
+        gp, gq = np.zeros(np.shape(p)), np.zeros(np.shape(p))
+        for k in range(len(self.bamp)):
+            ph = 2 * math.pi * (self.bfreq[k, 0] * p + self.bfreq[k, 1] * q) + self.bphase[k]
+            hgt = hgt + self.bamp[k] * np.sin(ph)
+            if grad:
+                c = self.bamp[k] * 2 * math.pi * np.cos(ph)
+                gp, gq = gp + c * self.bfreq[k, 0], gq + c * self.bfreq[k, 1]
+        return (hgt, gp, gq) if grad else hgt
+
+    def texture(self, X):
+        return np.clip(super().texture(X), 0.0, 255.0)
+
+    def _cast(self, K, w, h, R, t):
+        """depth z along every pixel's ray (x, y, 1) of a camera x_cam = R x_ref + t, and the surface points in the reference frame"""
+        R = np.eye(3) if R is None else R
+        t = np.zeros(3) if t is None else np.asarray(t, np.float64)
+        r = self._rays(K, w, h)
+        dn, d1, d2 = r @ (R @ self.n), r @ (R @ self.e1), r @ (R @ self.e2)  # d(n.X, p, q) / dz along the ray
+        z = (self.d + self.n @ (R.T @ t)) / dn  # the plane's intersection
+        if self.bamp.sum() > 0:
+            for _ in range(5):  # Newton on f(z) = n.X(z) - d - hgt(p(z), q(z)); quadratic convergence (slopes << 1)
+                Xref = (r * z[..., None] - t) @ R
+                hgt, gp, gq = self.height(Xref @ self.e1, Xref @ self.e2, grad=True)
+                z = z - (Xref @ self.n - self.d - hgt) / (dn - gp * d1 - gq * d2)
+        return z, (r * z[..., None] - t) @ R
+
+    def render(self, K, w, h, R=None, t=None, a=0.0, b=0.0, noise=0.0, rng=None):
+        _, Xref = self._cast(K, w, h, R, t)
+        Xp = Xref - np.multiply.outer(self.height(Xref @ self.e1, Xref @ self.e2), self.n)  # the texture lives on the plane coordinates
+        img = math.exp(a) * self.texture(Xp) + b
+        if noise > 0:
+            img = img + (rng or np.random.default_rng(0)).normal(0, noise, img.shape)
+        return img.astype(np.float32)
+
+    def idepth(self, K, w, h, R=None, t=None):
+        z, _ = self._cast(K, w, h, R, t)
+        return (1.0 / z).astype(np.float32)
+
+
 def dense_template(scene, K, w, h, nlevels, ref_pyr, idepth_scale=1.0, R=None, t=None):
     """every interior pixel 2<=x<wl-2, 2<=y<hl-2 is a template point (the emit rule of
     makeCoarseDepthL0, TrackerAndScaler.cpp:291-314), row-major order as the reference emits.

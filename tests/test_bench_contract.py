@@ -118,7 +118,7 @@ def test_frames_are_distinct_and_round_2s_workload_is_reproducible(monkeypatch):
     assert not np.array_equal(frames[0][1], frames[18][1])  # same texture, another motion and noise: another image
     assert all(np.array_equal(f[3], S.IDENTITY_POSE) for f in frames)  # identity guess
     m._FRAMES.clear()
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "16", "--scenes", "8", "--textures", "converging"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--batch", "16", "--scenes", "8", "--textures", "converging", "--scene-family", "plane"])
     a = m.parse()
     tex8, frames8 = m.build_frames(a, w, h, K, S.KITTI_T_STEREO)
     assert len(frames8) == 8 and m.frame_seeds(a) == m.SCENE_SEEDS
