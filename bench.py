@@ -115,6 +115,11 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the bench plumbing (barrier, max over ranks); nccl = RCCL")
     ap.add_argument("--device-override", type=int, default=-1, help="testing: put every rank on this device")
     ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidths (two access patterns) and exit")
+    ap.add_argument("--replay", action="store_true", help="run the replay-mode leg alone (config.replay of the default line): one sequence, one frame in flight, C++ adaptors, per-stage ms for the GPU and the CPU path")
+    ap.add_argument("--no-replay-leg", action="store_true", help="skip config.replay in the default line")
+    ap.add_argument("--replay-frames", type=int, default=200)
+    ap.add_argument("--replay-kf-every", type=int, default=4)
+    ap.add_argument("--replay-active", type=int, default=2000, help="active points per keyframe (the semi-dense template grows to ~10^4 points by dilation)")
     ap.add_argument("--ringkey", action="store_true", help="benchmark the sharded ring-key search alone instead")
     ap.add_argument("--no-ringkey-leg", action="store_true", help="skip the ring-key leg of the default line (N = 1: config.ringkey; N > 1: config.ringkey_sharded)")
     ap.add_argument("--ringkey-leg-seconds", type=float, default=120.0, help="N > 1: deadline of the sharded ring-key leg; a rank that misses it reports an error in config.ringkey_sharded and the line is printed regardless")
@@ -985,6 +990,97 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
             "shards": world, "merge": "dsm_ringdb_merge_topk (C ABI, librccl)" if world > 1 else "one shard: no merge", **res}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# replay mode: ONE sequence, one frame in flight, driven from the C++ adaptors (tools/replay/replay_bench.cpp)
+# ------------------------------------------------------------------------------------------------------------------
+REPLAY_CONFIGS = {
+    # name: (w, h, levels, K, T_stereo, label)  -- BASELINE configs[1] and [2]
+    "kitti00": (1232, 368, 5, None, None, "KITTI-00 shape 1232x368 (cams/kitti/0_2), 5 levels"),
+    "malaga06": (1024, 768, 5, (795.11588, 795.11588, 517.12973, 395.59665),
+                 np.array([[1, 0, 0, -0.119471], [0, 1, 0, 0], [0, 0, 1, 0.000000001], [0, 0, 0, 1]], np.float64),
+                 "Malaga urban extract 06 shape 1024x768 (cams/malaga), 5 levels"),
+}
+
+
+def write_replay_pack(path, name, n_frames, kf_every, n_active, seed=0x5EED0404):
+    """A synthetic stereo sequence for tools/replay/replay_bench.cpp: the camera travels ALONG the relief scene (constant distance,
+    gentle yaw), mono8 images, per keyframe the right image and `n_active` active points (random interior pixels with the scene's
+    inverse depth there and HdiF-style weights: what the window's PointHessians hold, TrackerAndScaler.cpp:149-164)."""
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+
+    from direct_stereo_slam_amd import synth as S
+
+    w, h, nl, K, T, _ = REPLAY_CONFIGS[name]
+    K = S.kitti_K_work() if K is None else K
+    T = S.KITTI_T_STEREO if T is None else T
+    scene = S.ReliefScene(seed=seed, fx_ref=K[0])
+    rng = np.random.default_rng(seed)
+    poses, c, R = [], np.zeros(3), np.eye(3)
+    for i in range(n_frames):  # x_cam = R (x_w - c)
+        poses.append((R.copy(), -R @ c))
+        step = scene.e1 * 0.10 + scene.e2 * 0.02 * np.sin(i / 9.0) + scene.n * 0.01 * np.cos(i / 7.0) + rng.normal(0, 0.003, 3)
+        c = c + step
+        R = S.so3_exp(np.array([0.0005 * np.sin(i / 11.0), 0.003 * np.sin(i / 13.0), 0.0004]) + rng.normal(0, 0.0003, 3)) @ R
+    u8 = lambda im: np.clip(np.rint(im), 0, 255).astype(np.uint8)
+
+    def frame(i):
+        R, t = poses[i]
+        r = np.random.default_rng(seed + 7919 * i)
+        out = [S.pose_from_Rt(R, t), u8(scene.render(K, w, h, R, t, noise=1.0, rng=r))]
+        if i % kf_every == 0:
+            Rr, tr = T[:3, :3] @ R, T[:3, :3] @ t + T[:3, 3]
+            out.append(u8(scene.render(K, w, h, Rr, tr, noise=1.0, rng=r)))
+            pu = r.integers(3, w - 3, n_active).astype(np.float32)
+            pv = r.integers(3, h - 3, n_active).astype(np.float32)
+            idl = scene.idepth(K, w, h, R, t)
+            out += [pu, pv, idl[pv.astype(int), pu.astype(int)].astype(np.float32), np.sqrt(1e-3 / (r.uniform(1e-3, 10, n_active) + 1e-12)).astype(np.float32)]
+        return out
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as ex:
+        frames = list(ex.map(frame, range(n_frames)))
+    with open(path, "wb") as f:
+        f.write(b"DSMRPLY1")
+        f.write(struct.pack("<6i", w, h, nl, n_frames, kf_every, n_active))
+        f.write(np.asarray(K, np.float32).tobytes())
+        f.write(np.asarray(T, np.float64).tobytes())
+        f.write(struct.pack("<d", 40.0))  # lidar_range (main.cpp:307)
+        for fr in frames:
+            for a in fr:
+                f.write(np.ascontiguousarray(a).tobytes())
+
+
+def replay_leg(args, names=("kitti00", "malaga06")):
+    """config.replay of the default line: the sequence a drop-in user runs -- per-stage mean ms under the
+    reference's own names (main.cpp:181-201) for the GPU path through the C++ adaptors and for the CPU path, side by side."""
+    import tempfile
+
+    exe = os.path.join(ROOT, "tools", "replay", "_build", "replay_bench")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
+    src = os.path.join(ROOT, "tools", "replay", "replay_bench.cpp")
+    lib, orc = os.path.join(ROOT, "direct_stereo_slam_amd", "lib"), os.path.join(ROOT, "oracle", "_build")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, src, "-L" + lib, "-ldsm_hotpath", "-L" + orc, "-l:libdsm_oracle_native.so",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath," + orc])
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name in names:
+            pack = os.path.join(td, name + ".bin")
+            t0 = time.perf_counter()
+            write_replay_pack(pack, name, args.replay_frames, args.replay_kf_every, args.replay_active)
+            t_pack = time.perf_counter() - t0
+            prefix = os.path.join(ROOT, "gpurun_out", "replay_" + name) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.path.join(td, name)
+            p = subprocess.run([exe, pack, prefix, "both"], capture_output=True, text=True, timeout=1200)
+            if p.returncode != 0:
+                out[name] = {"error": (p.stderr or p.stdout)[-600:]}
+                continue
+            d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            d["label"] = REPLAY_CONFIGS[name][5]
+            d["sequence_rendering_s"] = round(t_pack, 1)
+            out[name] = d
+    return out
+
+
 VALU_PEAK_TOPS = 78.6  # MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector counts an FMA as two; unfused add / mul / sub issue at half of that
 
 
@@ -1178,6 +1274,11 @@ def bench_tracking(args):
             del wl2
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["reference_five_level"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_replay_leg and not args.with_upload and not args.no_cpu:
+        try:
+            res["config"]["replay"] = replay_leg(args)
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            res["config"]["replay"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_ringkey_leg and not args.with_upload:
         try:
             res["config"]["ringkey"] = ringkey_single_gpu_leg(args, ctx)
@@ -1244,7 +1345,9 @@ if __name__ == "__main__":
             # 4096 template points + the image rows they land on)
             "read_bandwidth_GBps_chunk_per_workgroup": {f"{kb}KiB": round(c.read_bandwidth_chunked(3 << 30, kb << 10, 5), 1) for kb in (16, 112, 1024)}}))
         sys.exit(0)
-    if a.ringkey:
+    if a.replay:
+        print(json.dumps({"replay": replay_leg(a)}))
+    elif a.ringkey:
         bench_ringkey(a)
     else:
         bench_tracking(a)

@@ -58,7 +58,7 @@ public:
   // reference: TrackerAndScaler(int w, int h, const std::vector<double>& tfm_vec, const Mat33f& K1)
   TrackerAndScaler(dsm_context *ctx, int w, int h, int pyrLevelsUsed, const std::vector<double> &tfm_vec,
                    const float K1_fx_fy_cx_cy[4], const dsm_params *params = nullptr)
-      : refFrameID(-1), lastRef(nullptr), lastRef_aff_g2l(0, 0), firstCoarseRMSE(-1), levels_(pyrLevelsUsed) {
+      : refFrameID(-1), lastRef(nullptr), lastRef_aff_g2l(0, 0), firstCoarseRMSE(-1), ctx_(ctx), levels_(pyrLevelsUsed) {
     if (tfm_vec.size() != 16) throw std::invalid_argument("tfm_vec must hold 16 doubles");
     check_abi();
     check(dsm_tracker_create(ctx, w, h, pyrLevelsUsed, tfm_vec.data(), K1_fx_fy_cx_cy, params, &t_), "dsm_tracker_create");
@@ -140,6 +140,19 @@ public:
 
   dsm_tracker *handle() { return t_; }
 
+  // "next" row N1: hand over the camera image itself (DSM_PIXEL_F32: the undistorted float image FrontEnd.cpp:605,680 feed to
+  // makeImages; DSM_PIXEL_U8: the "mono8" camera bytes, main.cpp:216-217) instead of a host-built (I,dx,dy) pyramid: the pyramid
+  // is built on the device.  A FrameView carrying the same unique_id afterwards counts as resident in that slot (its dIp may be
+  // null), so trackNewestCoarse / optimizeScale skip their upload.  row_pitch_bytes: 0 = tight rows.
+  void uploadImage(int slot, const void *pixels, int pixel_type, float ab_exposure, long long unique_id, size_t row_pitch_bytes = 0) {
+    dsm_tracker *ts[1] = {t_};
+    const int slots[1] = {slot};
+    const void *imgs[1] = {pixels};
+    const float ex[1] = {ab_exposure};
+    check(dsm_upload_images(ctx_, 1, ts, slots, imgs, ex, pixel_type, row_pitch_bytes), "uploadImage");
+    uploaded_[slot] = unique_id;
+  }
+
   // act as pure output (TrackerAndScaler.h:59-64)
   int refFrameID;
   const FrameView *lastRef;
@@ -154,6 +167,7 @@ private:
     uploaded_[slot] = f.unique_id;
   }
   dsm_tracker *t_ = nullptr;
+  dsm_context *ctx_ = nullptr;
   int levels_;
   long long uploaded_[2] = {-1, -1};
 };
