@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--compact", type=int, default=None, help="dsm_params.compact_tail (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
+    ap.add_argument("--tile", type=int, default=None, help="dsm_params.tile_l0 (default: library default): 1 = tile-ordered level-0 template, warped window staged in LDS")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="upper bound of the frames timed on the CPU baseline (rank 0, N=1); the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the single-core CPU baseline leg once --cpu-min-frames are done")
@@ -322,6 +323,8 @@ def build_workload(args, ctx, config):
         params.speculate = args.speculate
     if args.compact is not None:
         params.compact_tail = args.compact
+    if args.tile is not None:
+        params.tile_l0 = args.tile
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0
@@ -996,6 +999,7 @@ def ringkey_sharded_leg(args, ctx, rank, world, steps=20, check=True):
 REPLAY_CONFIGS = {
     # name: (w, h, levels, K, T_stereo, label)  -- BASELINE configs[1] and [2]
     "kitti00": (1232, 368, 5, None, None, "KITTI-00 shape 1232x368 (cams/kitti/0_2), 5 levels"),
+    "tiny": (308, 92, 3, (179.714, 179.714, 151.67, 45.18), None, "quarter-size test geometry 308x92, 3 levels (tests/test_replay_bench.py)"),
     "malaga06": (1024, 768, 5, (795.11588, 795.11588, 517.12973, 395.59665),
                  np.array([[1, 0, 0, -0.119471], [0, 1, 0, 0], [0, 0, 1, 0.000000001], [0, 0, 0, 1]], np.float64),
                  "Malaga urban extract 06 shape 1024x768 (cams/malaga), 5 levels"),
@@ -1050,11 +1054,8 @@ def write_replay_pack(path, name, n_frames, kf_every, n_active, seed=0x5EED0404)
                 f.write(np.ascontiguousarray(a).tobytes())
 
 
-def replay_leg(args, names=("kitti00", "malaga06")):
-    """config.replay of the default line (VERDICT r03 item 4): the sequence a drop-in user runs -- per-stage mean ms under the
-    reference's own names (main.cpp:181-201) for the GPU path through the C++ adaptors and for the CPU path, side by side."""
-    import tempfile
-
+def build_replay_bench():
+    """tools/replay/replay_bench.cpp -> tools/replay/_build/replay_bench (g++; links the product library and the oracle's timing build)"""
     exe = os.path.join(ROOT, "tools", "replay", "_build", "replay_bench")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
@@ -1062,6 +1063,15 @@ def replay_leg(args, names=("kitti00", "malaga06")):
     lib, orc = os.path.join(ROOT, "direct_stereo_slam_amd", "lib"), os.path.join(ROOT, "oracle", "_build")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, src, "-L" + lib, "-ldsm_hotpath", "-L" + orc, "-l:libdsm_oracle_native.so",
                            "-Wl,-rpath," + lib, "-Wl,-rpath," + orc])
+    return exe
+
+
+def replay_leg(args, names=("kitti00", "malaga06")):
+    """config.replay of the default line (VERDICT r03 item 4): the sequence a drop-in user runs -- per-stage mean ms under the
+    reference's own names (main.cpp:181-201) for the GPU path through the C++ adaptors and for the CPU path, side by side."""
+    import tempfile
+
+    exe = build_replay_bench()
     out = {}
     with tempfile.TemporaryDirectory() as td:
         for name in names:

@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("speculate", C.c_int),
         ("compact_tail", C.c_int),
         ("fixed_schedule", C.c_int),
+        ("tile_l0", C.c_int),
         ("frame_check", C.c_int),
         ("frame_grad_tol", C.c_float),
     ]

@@ -240,6 +240,7 @@ void dsm_params_default(dsm_params *p) {
   p->speculate = 1;
   p->compact_tail = 1;
   p->fixed_schedule = 0;
+  p->tile_l0 = 0;
   p->frame_check = 1;
   p->frame_grad_tol = 0.0f;
 }
@@ -432,6 +433,11 @@ int dsm_tracker_destroy(dsm_tracker *t) {
   if (t->ctx->copy_stream) hipStreamSynchronize(t->ctx->copy_stream);
   for (int l = 0; l < t->nlevels; l++) {
     hipFree(t->d_pts[l]);
+    if (l == 0) {
+      hipFree(t->d_pts_tile);
+      hipFree(t->d_tile_range);
+      t->d_pts_tile = nullptr, t->d_tile_range = nullptr;
+    }
     hipFree(t->d_img[0][l]);
     hipFree(t->d_img[1][l]);
   }
@@ -468,6 +474,29 @@ int dsm_tracker_make_k(dsm_tracker *t, float fx, float fy, float cx, float cy) {
   return DSM_OK;
 }
 
+// tile-ordered copy of the (dense, row-major) level-0 template resident in t->d_pts[0], and its per-tile inverse-depth ranges
+static int build_tile_copy(dsm_tracker *t) {
+  dsm_context *ctx = t->ctx;
+  const int tiles_x = (t->w - 4 + kTileEdge - 1) / kTileEdge, tiles_y = (t->h - 4 + kTileEdge - 1) / kTileEdge, tiles = tiles_x * tiles_y;
+  if (!t->d_pts_tile || t->tiles != tiles) {
+    if (t->d_pts_tile) DSM_HIP(hipFree(t->d_pts_tile));
+    if (t->d_tile_range) DSM_HIP(hipFree(t->d_tile_range));
+    t->d_pts_tile = nullptr, t->d_tile_range = nullptr;
+    DSM_HIP(hipMalloc(&t->d_pts_tile, sizeof(float4) * (size_t)tiles * kTileEdge * kTileEdge));
+    DSM_HIP(hipMalloc(&t->d_tile_range, sizeof(float2) * (size_t)tiles));
+    t->tiles = tiles, t->tiles_x = tiles_x;
+  }
+  launch_tile_order(ctx->stream, t->w, t->h, tiles_x, tiles, t->d_pts[0], t->d_pts_tile, t->d_tile_range);
+  DSM_HIP(hipGetLastError());
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  t->desc.lv[0].pts_tile = t->d_pts_tile;
+  t->desc.lv[0].tile_range = t->d_tile_range;
+  t->desc.lv[0].n_tile = tiles * kTileEdge * kTileEdge;
+  t->desc.lv[0].tiles_x = tiles_x;
+  t->desc_dirty = true;
+  return DSM_OK;
+}
+
 int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, double ref_aff_b,
                         float ref_exposure, const int *n, const float *const *pc_u,
                         const float *const *pc_v, const float *const *pc_idepth,
@@ -498,6 +527,17 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
   t->ref_frame_id = ref_frame_id;
   t->have_ref = true;
   t->desc_dirty = true;
+  // dsm_params.tile_l0: a dense level-0 template (every interior pixel, row-major -- checked, not assumed) gets its tile-ordered copy
+  t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr;
+  if (t->params.tile_l0 && n[0] == (t->w - 4) * (t->h - 4) && n[0] > 0) {
+    bool dense = true;
+    const int wi = t->w - 4;
+    for (int i = 0; i < n[0] && dense; i++) dense = pc_u[0][i] == (float)(2 + i % wi) && pc_v[0][i] == (float)(2 + i / wi);
+    if (dense) {
+      rc = build_tile_copy(t);
+      if (rc) return rc;
+    }
+  }
   return DSM_OK;
 }
 
@@ -540,6 +580,7 @@ int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, in
   }
   for (int l = 0; l < t->nlevels; l++) {
     t->desc.lv[l].n = h_n[l];
+    if (l == 0) t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr; // a semi-dense template has no tile form
     if (n_out) n_out[l] = h_n[l];
   }
   t->desc.ref_a = ref_aff_a; // :323-324
@@ -560,6 +601,7 @@ int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {
   DSM_HIP(hipSetDevice(t->ctx->device));
   for (int l = 0; l < t->nlevels; l++) launch_scale_depth(t->ctx->stream, t->desc.lv[l].n, t->d_pts[l], scale);
   DSM_HIP(hipStreamSynchronize(t->ctx->stream));
+  if (t->desc.lv[0].tiles_x > 0) return build_tile_copy(t); // the copy and its depth ranges follow the scaled template
   return DSM_OK;
 }
 
@@ -932,7 +974,8 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
       return invalid("batch: all trackers must share image size and levels");
     int rc = check_ready(t, i < n ? mode : mode2);
     if (rc) return rc;
-    const int need = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
+    const int tile_chunks = ((t->w - 4 + kTileEdge - 1) / kTileEdge) * ((t->h - 4 + kTileEdge - 1) / kTileEdge) * kTileEdge * kTileEdge / (kThreads * 16);
+    const int need = 2 * std::max(max_chunks_upto(t->w * t->h), tile_chunks) * kPartialStride; // second half: the speculative candidate's partials
     if (need > ps) ps = need;
   }
   int rc = ensure_batch_capacity(ctx, n + n2, ps);
@@ -1033,14 +1076,14 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   bool use_queue = P.work_queue >= 2 && n2 == 0;
   if (P.work_queue == 1 && n >= 32 && n2 == 0) {
     long long chunks0 = 0;
-    for (int i = 0; i < n; i++) chunks0 += num_chunks(ts[i]->desc.lv[0].n);
+    for (int i = 0; i < n; i++) chunks0 += level_chunks(ts[i]->desc, 0);
     use_queue = chunks0 <= 24576; // (256 dense S2 frames = 29.7 k chunks: 4 % slower than the launch form; 192: faster)
   }
   if (use_queue) {
     int max_items = 1;
     for (int L = 0; L <= coarsest; L++)
       for (int i = 0; i < n; i++) {
-        const int c = num_chunks(ts[i]->desc.lv[L].n);
+        const int c = level_chunks(ts[i]->desc, L);
         if (c > max_items) max_items = c;
       }
     if (max_items >= (1 << kQueueChunkBits) || n >= (1 << (32 - kQueueChunkBits))) return invalid("work queue: batch or level too large");
@@ -1088,7 +1131,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   for (int L = 0; L < nlevels; L++) {
     int max_chunks = 1, max_it = 0, max_n = 0;
     for (int i = 0; i < N; i++) {
-      const int c = num_chunks(ts[i]->desc.lv[L].n);
+      const int c = level_chunks(ts[i]->desc, L);
       if (c > max_chunks) max_chunks = c;
       if (ts[i]->desc.lv[L].n > max_n) max_n = ts[i]->desc.lv[L].n;
       const int it_i = ts[i]->params.fixed_schedule > 0 ? ts[i]->params.fixed_schedule : ts[i]->params.max_iterations[L];
@@ -1668,7 +1711,7 @@ static int single_eval(dsm_tracker *t, int mode, int lvl, const double *pose, co
   DSM_HIP(hipMemcpyAsync(ctx->d_start, ctx->h_start, sizeof(StartInfo), hipMemcpyHostToDevice, ctx->stream));
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_PREP, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, ctx->d_start, nullptr, nullptr);
-  launch_eval(ctx->stream, mode, lvl, round8(num_chunks(t->desc.lv[lvl].n) > 0 ? num_chunks(t->desc.lv[lvl].n) : 1), 1, ctx->d_tracker_ptrs,
+  launch_eval(ctx->stream, mode, lvl, round8(level_chunks(t->desc, lvl) > 0 ? level_chunks(t->desc, lvl) : 1), 1, ctx->d_tracker_ptrs,
               ctx->d_states, ctx->d_partials, ctx->partial_stride, nullptr, nullptr);
   launch_lm(ctx->stream, mode, LM_OP_SINGLE_FINISH, lvl, 1, ctx->d_tracker_ptrs, ctx->d_states, ctx->d_partials,
             ctx->partial_stride, nullptr, ctx->d_single, nullptr);

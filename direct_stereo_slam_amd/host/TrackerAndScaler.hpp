@@ -172,6 +172,62 @@ private:
   long long uploaded_[2] = {-1, -1};
 };
 
+// ---- streaming form of many sequences (dsm_stream_*): continuous admission ------------------------------
+// Many TrackerAndScaler instances (one per sequence / hypothesis) share the GPU: each submits its trackNewestCoarse /
+// optimizeScale problem and polls for the result; the stream keeps `track_slots` + `scale_slots` problems resident, advances
+// them one LM round per tick whatever level each stands on, and refills a slot the moment its problem retires.  Results are
+// bit-identical to the trackers' own calls.  The tracker's template and frames must stay untouched until its result is back.
+class Stream {
+public:
+  Stream(dsm_context *ctx, int track_slots, int scale_slots) {
+    check_abi();
+    check(dsm_stream_create(ctx, track_slots, scale_slots, &s_), "dsm_stream_create");
+  }
+  ~Stream() { dsm_stream_destroy(s_); }
+  Stream(const Stream &) = delete;
+  Stream &operator=(const Stream &) = delete;
+
+  // trackNewestCoarse of `tracker` on the frame resident in its NEW_LEFT slot (upload it first: uploadImage, or a FrameView
+  // through trackNewestCoarse's own path); returns the ticket the result carries
+  uint64_t submitTrack(TrackerAndScaler &tracker, const SE3 &lastToNew_guess, const AffLight &aff_g2l, int coarsestLvl,
+                       const double minResForAbort[5] = nullptr) {
+    dsm_tracker *t = tracker.handle();
+    const double pose[7] = {lastToNew_guess.q[0], lastToNew_guess.q[1], lastToNew_guess.q[2], lastToNew_guess.q[3],
+                            lastToNew_guess.t[0], lastToNew_guess.t[1], lastToNew_guess.t[2]};
+    const double aff[2] = {aff_g2l.a, aff_g2l.b};
+    double mr[DSM_MAX_LEVELS];
+    for (int i = 0; i < DSM_MAX_LEVELS; i++) mr[i] = (i < 5 && minResForAbort) ? minResForAbort[i] : NAN;
+    uint64_t ticket = 0;
+    check(dsm_stream_submit_track(s_, 1, &t, pose, aff, coarsestLvl, mr, &ticket), "dsm_stream_submit_track");
+    return ticket;
+  }
+  // optimizeScale of `tracker` on the frame resident in its NEW_RIGHT slot
+  uint64_t submitScale(TrackerAndScaler &tracker, float scale, int coarsestLvl) {
+    dsm_tracker *t = tracker.handle();
+    uint64_t ticket = 0;
+    check(dsm_stream_submit_scale(s_, 1, &t, &scale, coarsestLvl, &ticket), "dsm_stream_submit_scale");
+    return ticket;
+  }
+  void advance() { check(dsm_stream_advance(s_), "dsm_stream_advance"); }
+  void drain() { check(dsm_stream_drain(s_), "dsm_stream_drain"); }
+  // appends the problems retired so far; dsm_stream_result::pose / aff / good / last_residuals / flow are trackNewestCoarse's
+  // outputs, scale / err optimizeScale's
+  void results(std::vector<dsm_stream_result> &out) {
+    int ready = 0;
+    check(dsm_stream_counts(s_, nullptr, nullptr, &ready), "dsm_stream_counts");
+    if (ready <= 0) return;
+    const size_t at = out.size();
+    out.resize(at + (size_t)ready);
+    int n = 0;
+    check(dsm_stream_results(s_, ready, out.data() + at, &n), "dsm_stream_results");
+    out.resize(at + (size_t)n);
+  }
+  dsm_stream *handle() { return s_; }
+
+private:
+  dsm_stream *s_ = nullptr;
+};
+
 // ---- "next" row N4: the hypothesis loop of FrontEnd::trackNewCoarse (FrontEnd.cpp:194-256) -----------
 // Same results as the reference's sequential loop; try 0 runs alone, the remaining tries as ONE batched
 // launch sequence without abort, and the abort / take-over logic (TrackerAndScaler.cpp:598,

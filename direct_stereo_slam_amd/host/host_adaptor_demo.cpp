@@ -74,11 +74,31 @@ int main(int argc, char **argv) {
     const bool good = tracker.trackNewestCoarse(nf, pose, aff, nl - 1, minres, last);
     float scale = 1.0f;
     const float err = tracker.optimizeScale(rf, scale, nl - 1);
+    // the same two problems through the streaming form (dsm_host::Stream): frames are resident from the calls above
+    int stream_equal = 0;
+    {
+      dsm_host::Stream stream(ctx, 2, 2);
+      const uint64_t tk = stream.submitTrack(tracker, dsm_host::SE3(), dsm_host::AffLight(), nl - 1, minres);
+      const uint64_t ts = stream.submitScale(tracker, 1.0f, nl - 1);
+      stream.drain();
+      std::vector<dsm_stream_result> res;
+      stream.results(res);
+      for (const dsm_stream_result &r : res) {
+        if (r.ticket == tk) {
+          bool same = (r.good != 0) == good && r.aff[0] == aff.a && r.aff[1] == aff.b;
+          for (int i = 0; i < 4; i++) same = same && r.pose[i] == pose.q[i];
+          for (int i = 0; i < 3; i++) same = same && r.pose[4 + i] == pose.t[i];
+          stream_equal += same;
+        } else if (r.ticket == ts) {
+          stream_equal += r.scale == scale && r.err == err;
+        }
+      }
+    }
     printf("{\"good\": %d, \"pose\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"aff\": [%.17g, %.17g], "
-           "\"last0\": %.9g, \"flow\": [%.9g, %.9g, %.9g], \"scale\": %.9g, \"scale_err\": %.9g, \"ref_id\": %d}\n",
+           "\"last0\": %.9g, \"flow\": [%.9g, %.9g, %.9g], \"scale\": %.9g, \"scale_err\": %.9g, \"ref_id\": %d, \"stream_results_equal\": %d}\n",
            good ? 1 : 0, pose.q[0], pose.q[1], pose.q[2], pose.q[3], pose.t[0], pose.t[1], pose.t[2], aff.a, aff.b, last[0],
            tracker.lastFlowIndicators[0], tracker.lastFlowIndicators[1], tracker.lastFlowIndicators[2], scale, err,
-           tracker.refFrameID);
+           tracker.refFrameID, stream_equal);
   }
   dsm_context_destroy(ctx);
   return 0;

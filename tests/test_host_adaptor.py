@@ -47,8 +47,10 @@ def test_reference_binding_through_standin_types_equals_the_plain_adaptor(ctx, t
     path = tmp_path / "fixture.bin"
     write_fixture(sc, path)
     plain, bound = run_host("host_adaptor_demo", path), run_host("reference_binding_check", path)
-    assert json.loads(plain)["good"] == 1
-    assert plain == bound
+    a, b = json.loads(plain), json.loads(bound)
+    assert a["good"] == 1
+    a.pop("stream_results_equal")  # (the plain demo also exercises dsm_host::Stream)
+    assert a == b and plain.split(', "stream_results_equal"')[0] == bound.rstrip("}")
 
 
 def test_cpp_adaptor_matches_python_mirror(ctx, tmp_path):
@@ -60,6 +62,7 @@ def test_cpp_adaptor_matches_python_mirror(ctx, tmp_path):
     good, pose, aff, last = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     err, s = trk.optimizeScale(1.0, sc.nl - 1)
     assert bool(res["good"]) == good and res["ref_id"] == 7
+    assert res["stream_results_equal"] == 2  # dsm_host::Stream returned the track AND the scale result bit for bit
     np.testing.assert_array_equal(res["pose"], pose)  # same library, same launches: bit identical
     np.testing.assert_array_equal(res["aff"], aff)
     assert np.float32(res["scale"]) == np.float32(s) and np.float32(res["scale_err"]) == np.float32(err)
