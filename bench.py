@@ -499,6 +499,10 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     barrier_sync(world)
     run.reset_stats()
     p0 = run.passes
+    import gc
+
+    gc.collect()
+    gc.disable()  # (see measure(): Python's collector is host noise, not the path)
     t0 = time.perf_counter()
     for i in range(steps):
         run.step(("t", i))
@@ -506,6 +510,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     ctx.sync()
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
+    gc.enable()
     timed = run.acc
     run.acc = None
     timed_passes = run.passes - p0
@@ -649,12 +654,23 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
         one_step(ctx, wl, kf_idx, with_upload)
     ctx.sync()
     barrier_sync(world)
+    import gc
+
+    gc.collect()
+    gc.disable()  # (a generation-2 collection of this process's many small objects is a 40 ms host pause: measured inside a 33 ms timed region, round 4)
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("DSM_BENCH_TRACE_STEPS") else None
     for _ in range(steps):
+        ts = time.perf_counter()
         out = one_step(ctx, wl, kf_idx, with_upload)
+        if trace is not None:
+            trace.append(round(1e3 * (time.perf_counter() - ts), 3))
     ctx.sync()
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
+    gc.enable()
+    if trace is not None:
+        sys.stderr.write(f"per-step ms: {trace}\n")
     good, poses = out[0], out[1]
 
     # roofline of the dominant kernel (level-0 pose eval): one extra step, same stream configuration, with one pair
