@@ -8,17 +8,26 @@ it spawns the N ranks itself and fails loudly when fewer devices exist.
 Headline workload (config.workload) = the configuration BASELINE.json's metric is quoted on: KITTI-00 input 1241x376,
 SIX pyramid levels.  DSO's level rule stops at five levels for the reference's 1232x368 crop, so the six-level form pads
 the input to 1248x384 (divisible by 32; SURVEY.md section 8d "S2") and runs the reference's LM rules with a six-entry
-iteration table.  Dense template (every interior pixel is a point), seeded synthetic scenes with ground-truth motion,
-LM iterations AS EXECUTED (TrackerAndScaler.cpp:451-638, :854-964).  A "step" = B independent stereo frames per GPU, ALL
-DISTINCT (own ground-truth motion and image noise; 18 textures repeat, none left out): every frame is tracked against its
-keyframe template (trackNewestCoarse from the identity pose) and every 5th
-frame additionally runs the stereo scale optimiser from s = 1 (keyframe cadence, FrontEnd.cpp:806-811).  The library
-runs with dsm_params_default().  Inputs (pyramids, templates) are resident in HBM when the timed region starts.  Second
-objects of the line: the same frames on SURVEY.md 8d's fixed schedule (config.fixed_schedule_leg: 1 + 3 evaluations per
-level, CPU leg on the same schedule) and the reference-faithful five-level workload (S1, 1232x368,
-config.reference_five_level).
+iteration table.  Dense template (every interior pixel is a point), seeded synthetic RELIEF scenes (round 4: broadband
+texture over a smooth relief; the CPU oracle tracks every frame of the family; `--scene-family plane` = rounds 1-3's scenes)
+with ground-truth motion, LM iterations AS EXECUTED (TrackerAndScaler.cpp:451-638, :854-964).
 
-Tracking does not shard inside a frame: N GPUs = N independent replicas of the same batch, no
+A "step" = B independent stereo frames per GPU, ALL DISTINCT (own ground-truth motion and image noise; 18 textures repeat,
+none left out), SUBMITTED to the streaming form of the batched calls (dsm_stream_*, tick engine): every frame's
+trackNewestCoarse from the identity pose and, for every 5th frame (keyframe cadence,
+FrontEnd.cpp:806-811), the stereo scale optimiser from s = 1, followed by one advance of the stream; at most B track problems
+are resident at any time, problems are admitted as slots free up and retire individually, and after the K-th step the pool
+is drained INSIDE the timed region (everything submitted inside it is completed inside it).  `--stream 0` = round 3's step:
+one synchronous dsm_track_and_scale_batch call.  The library runs with its default parameters.  Inputs (pyramids,
+templates) are resident in HBM when the timed region starts.
+
+Further objects of the line: the same frames on SURVEY.md 8d's fixed schedule (config.fixed_schedule_leg: 1 + 3
+evaluations per level, CPU leg on the same schedule), the reference-faithful five-level workload (S1, 1232x368,
+config.reference_five_level), the replay-mode per-stage figures of ONE sequence driven from the C++ adaptors, GPU and CPU
+path side by side (config.replay, tools/replay/replay_bench.cpp), and the ring-key search on one GPU at SURVEY.md 8d's
+sizes with its own rooflines, oracle check and CPU brute force (config.ringkey).
+
+Tracking does not shard inside a frame: N GPUs = N independent replicas of the same work, no
 data-path collective ("scaling": "weak").  What does shard is the ring-key database: with N > 1 the line also carries
 config.ringkey_sharded -- the DB split `ordinal mod N`, local scans, cross-shard merge by RCCL all-reduce(min) through the
 C ABI (dsm_ringdb_merge_topk), checked against the unsharded answer.
@@ -428,32 +437,33 @@ class StreamRunner:
         self.owner = {}
         self.out = {}
         self.passes = 0
-        self.acc = None  # accumulated statistics of the passes since reset_stats()
+        self.trace = [] if os.environ.get("DSM_BENCH_TRACE_STEPS") else None
+        self.t_last = time.perf_counter()
+        self.acc = None  # statistics of the advances since reset_stats() (the stream's own are cumulative: differenced here)
+        self.prev = None
 
     def reset_stats(self):
+        self.st.sync()  # nothing of an earlier advance may leak into the new count
+        self._collect(count_pass=False)
         self.acc = dict(evals=np.zeros(6, np.int64), ro=np.zeros(6, np.int64), bytes=0, bytes_scale=0, ms=0.0, l_ms=np.zeros(6), l_sum_ms=np.zeros(6),
                         dispatches=np.zeros(6, np.int64), launches=np.zeros(6, np.int64), passes=0, retired=0, wall=0.0)
 
-    def _collect(self):
+    def _collect(self, count_pass=True):
         n_track = 0
         for r in self.st.results():
             self.out[r.ticket] = r
             n_track += r.kind == 0
-        self.passes += 1
-        if self.acc is not None:
+        self.passes += 1 if count_pass else 0
+        a, b = self.st.stats()
+        cur = dict(evals=np.array(a.evals, np.int64), ro=np.array(a.evals_residual_only, np.int64), bytes=int(a.algorithmic_bytes), bytes_scale=int(b.algorithmic_bytes),
+                   ms=float(a.total_ms), l_ms=np.array(a.eval_kernel_union_ms), l_sum_ms=np.array(a.eval_kernel_ms), dispatches=np.array(a.eval_dispatches, np.int64),
+                   launches=np.array(a.launches, np.int64) + np.array(b.launches, np.int64))
+        if self.acc is not None and self.prev is not None:
             self.acc["retired"] += n_track
-            a, b = self.st.stats()
-            acc = self.acc
-            acc["evals"] += np.array(a.evals, np.int64)
-            acc["ro"] += np.array(a.evals_residual_only, np.int64)
-            acc["bytes"] += a.algorithmic_bytes
-            acc["bytes_scale"] += b.algorithmic_bytes
-            acc["ms"] += a.total_ms
-            acc["l_ms"] += np.array(a.eval_kernel_union_ms)
-            acc["l_sum_ms"] += np.array(a.eval_kernel_ms)
-            acc["dispatches"] += np.array(a.eval_dispatches, np.int64)
-            acc["launches"] += np.array(a.launches, np.int64) + np.array(b.launches, np.int64)
-            acc["passes"] += 1
+            for k, v in cur.items():
+                self.acc[k] = self.acc[k] + (v - self.prev[k])
+            self.acc["passes"] += 1 if count_pass else 0
+        self.prev = cur
 
     def step(self, tag):
         wl, B = self.wl, self.B
@@ -462,9 +472,14 @@ class StreamRunner:
         self.owner[tag] = (tk, ts)
         self.st.advance()
         self._collect()
+        if self.trace is not None:
+            self.trace.append(round(1e3 * (time.perf_counter() - self.t_last), 2))
+            self.t_last = time.perf_counter()
 
     def drain(self):
         while True:
+            self.st.sync()  # (the tail is short chains: nothing to overlap)
+            self._collect(count_pass=False)  # the statistics of what the sync read back, before the next advance starts a new count
             resident, waiting, _ = self.st.counts()
             if resident == 0 and waiting == 0:
                 return
@@ -513,6 +528,8 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     gc.enable()
     timed = run.acc
     run.acc = None
+    if run.trace is not None:
+        sys.stderr.write(f"per-step host ms (warm-up, then the timed steps): {run.trace}\n")
     timed_passes = run.passes - p0
     good, poses, err, sc = run.results_of(("t", steps - 1))
     last_evals = run.last_evals
@@ -526,6 +543,8 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     for i in range(8):  # steady state without instrumentation: frames retired per second while the pool is kept full
         run.step(("s", i))
     ctx.sync()
+    run.st.sync()
+    run._collect(count_pass=False)
     steady = dict(run.acc, wall=time.perf_counter() - ts0)
     ctx.set_timing(True)
     run.reset_stats()

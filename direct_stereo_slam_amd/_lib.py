@@ -112,6 +112,8 @@ SYMBOLS = {
     "dsm_stream_submit_scale": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_float_p, C.c_int, C.POINTER(C.c_uint64)]),
     "dsm_stream_advance": (C.c_int, [_vp]),
     "dsm_stream_drain": (C.c_int, [_vp]),
+    "dsm_stream_sync": (C.c_int, [_vp]),
+    "dsm_stream_set_pipelined": (C.c_int, [_vp, C.c_int]),
     "dsm_stream_results": (C.c_int, [_vp, C.c_int, C.POINTER(StreamResult), c_int_p]),
     "dsm_stream_counts": (C.c_int, [_vp, c_int_p, c_int_p, c_int_p]),
     "dsm_stream_set_quantile": (C.c_int, [_vp, C.c_int, C.c_double]),

@@ -1043,7 +1043,7 @@ void collect_eval_timing(dsm_context *ctx, const std::vector<int> &ev_lvl, int n
         ce = p.second;
     }
     if (ce >= 0) busy += ce - cs;
-    st.eval_kernel_union_ms[l] = busy;
+    st.eval_kernel_union_ms[l] += busy; // (+=: a stream's statistics are cumulative; the batch calls clear theirs per call)
   }
 }
 } // namespace dsm

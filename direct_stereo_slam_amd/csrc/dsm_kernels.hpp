@@ -78,9 +78,9 @@ struct TickSegCtl { // one per segment (stream group / companion): item counts o
   int overflow; // an item list ran over (cannot happen by construction: checked by the host)
   int pad[29];
 };
-struct TickModeCtl { // one per problem kind, shared by the kind's segments
-  int pending_head, pending_count; // waiting problems: next to admit / uploaded by the host
-  int retired, results_cap;        // results written / capacity of the result array
+struct TickModeCtl { // one per problem kind, shared by the kind's segments; every counter is monotonic over the stream's life
+  int pending_head, pending_count; // waiting problems: admitted so far (device) / handed over so far (host: the only word it writes)
+  int retired, ring;               // results written so far / entries of the waiting and result rings (a power of two)
   long long sched_evals[DSM_MAX_LEVELS], sched_ro[DSM_MAX_LEVELS]; // evaluations staged (they run in the next tick)
   long long sched_items[DSM_MAX_LEVELS];
 };

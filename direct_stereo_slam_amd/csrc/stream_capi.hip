@@ -115,10 +115,22 @@ struct dsm_stream {
   TickModeCtl *d_modectl = nullptr, *h_modectl = nullptr;
   std::vector<unsigned *> d_items; // [segment][2]
   std::vector<int> items_cap, last_count;
-  TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr};
-  int pending_cap[2] = {0, 0};
-  TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};
-  int results_cap[2] = {0, 0};
+  TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr}; // waiting rings (device / pinned staging)
+  TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};   // result rings (device / two pinned copies)
+  int ring[2] = {0, 0};
+  int *h_count_word = nullptr; // pinned: the pending_count words of the two advances in flight
+  hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
+  bool pipelined = true;       // advance returns once its work is enqueued; results surface one advance late
+  long long collected = 0;     // advances whose read-back has been processed
+  long long handed[2] = {0, 0}; // problems appended to the device's waiting ring so far
+  struct Seen {
+    long long admitted, retired;
+    long long evals[DSM_MAX_LEVELS], ro[DSM_MAX_LEVELS];
+  } seen[2];
+  int inflight_parity[2] = {0, 0};
+  bool inflight_timed[2] = {false, false}; // the advance was enqueued with per-dispatch events (dsm_context_set_timing)
+  std::vector<int> ev_lvl;
+  const dsm_params *sched_params = nullptr;
   unsigned long long *d_slot_ticket = nullptr;
   int parity = 0;
   int resident[2] = {0, 0};
@@ -155,6 +167,11 @@ static void stream_free(dsm_stream *s) {
     if (s->h_results[m]) hipHostFree(s->h_results[m]);
   }
   hipFree(s->d_slot_ticket);
+  if (s->h_count_word) hipHostFree(s->h_count_word);
+  for (int k = 0; k < 2; k++) {
+    if (s->ev_begin[k]) hipEventDestroy(s->ev_begin[k]);
+    if (s->ev_end[k]) hipEventDestroy(s->ev_end[k]);
+  }
   delete s;
 }
 
@@ -218,6 +235,8 @@ int dsm_stream_destroy(dsm_stream *s) {
   if (!s) return DSM_OK;
   hipSetDevice(s->ctx->device);
   hipStreamSynchronize(s->ctx->stream);
+  for (hipStream_t st : s->ctx->extra_streams) hipStreamSynchronize(st);
+  if (s->ctx->companion_stream) hipStreamSynchronize(s->ctx->companion_stream);
   stream_free(s);
   return DSM_OK;
 }
@@ -317,9 +336,13 @@ int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *r
   if (!s) return invalid("null stream");
   int r = 0;
   for (const Slot &sl : s->slots) r += sl.state != SLOT_FREE;
-  if (s->engine == 1) r = s->resident[0] + s->resident[1];
+  long long on_the_way = 0;
+  if (s->engine == 1) { // as of the last read-back: in a slot / in the device's waiting ring
+    r = (int)((s->seen[0].admitted - s->seen[0].retired) + (s->seen[1].admitted - s->seen[1].retired));
+    on_the_way = (s->handed[0] - s->seen[0].admitted) + (s->handed[1] - s->seen[1].admitted);
+  }
   if (resident_out) *resident_out = r;
-  if (waiting_out) *waiting_out = (int)(s->waiting[0].size() + s->waiting[1].size());
+  if (waiting_out) *waiting_out = (int)(s->waiting[0].size() + s->waiting[1].size() + on_the_way);
   if (results_out) *results_out = (int)s->done.size();
   return DSM_OK;
 }
@@ -421,8 +444,6 @@ int dsm_stream_advance(dsm_stream *s) {
     else
       top2 = sl.lvl > top2 ? sl.lvl : top2;
   }
-  memset(&s->stats[0], 0, sizeof(dsm_stats));
-  memset(&s->stats[1], 0, sizeof(dsm_stats));
   if (n_live == 0) return DSM_OK;
   // Nothing is waiting and the pool is at most a quarter full: what is resident is the END of the job -- nothing rides with
   // the stragglers any more, so a pass gives every level the rounds the slowest retired problem needed (they finish in one or
@@ -521,7 +542,7 @@ int dsm_stream_advance(dsm_stream *s) {
         }
       }
     for (const Seg &sg : segs)
-      if (sg.rows[L] > 0) s->stats[sg.mode].launches[L] = seg_rounds(sg);
+      if (sg.rows[L] > 0) s->stats[sg.mode].launches[L] += seg_rounds(sg);
   }
   DSM_HIP(hipGetLastError());
   for (size_t si = 1; si < segs.size(); si++) { // join
@@ -536,8 +557,8 @@ int dsm_stream_advance(dsm_stream *s) {
   s->passes++;
   float ms = 0;
   DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
-  s->stats[0].total_ms = s->stats[1].total_ms = ms;
-  s->stats[0].polls = 1;
+  s->stats[0].total_ms += ms, s->stats[1].total_ms += ms;
+  s->stats[0].polls += 1;
   if (ctx->timing) collect_eval_timing(ctx, ev_lvl, nlevels, s->stats[0]);
   for (int i = 0; i < N; i++) {
     Slot &sl = s->slots[i];
@@ -645,9 +666,10 @@ static int tick_setup(dsm_stream *s) {
   if (s->cap[1] > 0) s->tsegs.push_back(Seg{nullptr, cap0, N, 1, true, {}});
   const int nseg = (int)s->tsegs.size();
   int rc = alloc_dev(&s->d_segctl, nseg);
-  if (!rc) rc = alloc_pinned(&s->h_segctl, nseg);
+  if (!rc) rc = alloc_pinned(&s->h_segctl, 2 * (size_t)nseg);
   if (!rc) rc = alloc_dev(&s->d_modectl, 2);
-  if (!rc) rc = alloc_pinned(&s->h_modectl, 2);
+  if (!rc) rc = alloc_pinned(&s->h_modectl, 2 * 2);
+  if (!rc) rc = alloc_pinned(&s->h_count_word, 4);
   if (!rc) rc = alloc_dev(&s->d_slot_ticket, N);
   if (rc) return rc;
   // an item list holds at most one evaluation (+ its speculative twin) per slot of the segment
@@ -665,172 +687,69 @@ static int tick_setup(dsm_stream *s) {
       if ((rc = alloc_dev(&s->d_items[2 * si + b], cap))) return rc;
   }
   DSM_HIP(hipMemsetAsync(s->d_segctl, 0, sizeof(TickSegCtl) * nseg, ctx->stream));
-  DSM_HIP(hipMemsetAsync(s->d_modectl, 0, sizeof(TickModeCtl) * 2, ctx->stream));
   DSM_HIP(hipMemsetAsync(s->d_slot_ticket, 0, sizeof(unsigned long long) * N, ctx->stream));
+  // the waiting ring and the result ring of each kind: the host appends waiting problems and never lets more in than the result
+  // ring has room for; the device consumes / produces by monotonic counters
+  for (int mode = 0; mode < 2; mode++) {
+    int ring = 1024;
+    while (ring < 4 * s->cap[mode]) ring <<= 1;
+    s->ring[mode] = ring;
+    if ((rc = alloc_dev(&s->d_pending[mode], ring)) || (rc = alloc_pinned(&s->h_pending[mode], ring)) || (rc = alloc_dev(&s->d_results[mode], ring)) ||
+        (rc = alloc_pinned(&s->h_results[mode], 2 * (size_t)ring)))
+      return rc;
+    TickModeCtl mc;
+    memset(&mc, 0, sizeof mc);
+    mc.ring = ring;
+    s->h_modectl[mode] = mc;
+  }
+  DSM_HIP(hipMemcpyAsync(s->d_modectl, s->h_modectl, sizeof(TickModeCtl) * 2, hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < 2; k++) {
+    DSM_HIP(hipEventCreate(&s->ev_begin[k]));
+    DSM_HIP(hipEventCreate(&s->ev_end[k]));
+  }
   DSM_HIP(hipStreamSynchronize(ctx->stream));
+  memset(s->seen, 0, sizeof s->seen);
   s->tick_ready = true;
   return DSM_OK;
 }
 
-// One advance of the tick engine: the waiting problems go to the device (at most one per slot), free slots take them, then
-// `ticks` ticks -- evaluate every staged item, step every resident problem; finished problems retire into the result array
-// and their slots take the next waiting problem on the spot -- and ONE read-back: control blocks, then the results.
-static int tick_advance(dsm_stream *s) {
+// the read-back of advance `k` (parity k & 1): control blocks and result rings are in the pinned copies once ev_end[k & 1] is reached
+static int tick_collect(dsm_stream *s, long long k) {
   dsm_context *ctx = s->ctx;
-  DSM_HIP(hipSetDevice(ctx->device));
-  memset(&s->stats[0], 0, sizeof(dsm_stats));
-  memset(&s->stats[1], 0, sizeof(dsm_stats));
-  if (s->resident[0] + s->resident[1] == 0 && s->waiting[0].empty() && s->waiting[1].empty()) return DSM_OK;
-  if (!s->partial_stride) return invalid("dsm_stream: nothing was ever submitted");
-  int rc;
-  if (!s->tick_ready && (rc = tick_setup(s))) return rc;
-  const int nseg = (int)s->tsegs.size();
-  const int n_track_segs = s->cap[1] > 0 ? nseg - 1 : nseg;
-  rc = ensure_streams(ctx, n_track_segs < 1 ? 1 : n_track_segs, s->cap[1] > 0 && n_track_segs > 0);
-  if (rc) return rc;
-  for (int si = 0; si < nseg; si++)
-    s->tsegs[si].st = si == 0 ? ctx->stream : s->tsegs[si].companion ? ctx->companion_stream : ctx->extra_streams[si - 1];
-  // ---- the waiting problems of each kind, at most one per slot and advance ----
-  int n_pend[2] = {0, 0};
-  std::vector<dsm_tracker *> fresh;
-  const dsm_params *P = nullptr;
-  for (int mode = 0; mode < 2; mode++) {
-    const int n = (int)std::min<size_t>(s->waiting[mode].size(), (size_t)s->cap[mode]);
-    n_pend[mode] = n;
-    if (n > s->pending_cap[mode]) {
-      const int want = n > 2 * s->pending_cap[mode] ? n : 2 * s->pending_cap[mode];
-      if ((rc = regrow_dev(&s->d_pending[mode], want)) || (rc = regrow_pinned(&s->h_pending[mode], want))) return rc;
-      s->pending_cap[mode] = want;
-    }
-    for (int i = 0; i < n; i++) {
-      const Waiting &wt = s->waiting[mode][i];
-      TickPending &pd = s->h_pending[mode][i];
-      pd.start = wt.start;
-      pd.trk = wt.trk->d_desc;
-      pd.ticket = wt.ticket;
-      fresh.push_back(wt.trk);
-      if (!P) P = &wt.trk->params;
-    }
-    const int rcap = s->resident[mode] + n + 1;
-    if (rcap > s->results_cap[mode]) {
-      const int want = rcap > 2 * s->results_cap[mode] ? rcap : 2 * s->results_cap[mode];
-      if ((rc = regrow_dev(&s->d_results[mode], want)) || (rc = regrow_pinned(&s->h_results[mode], want))) return rc;
-      s->results_cap[mode] = want;
-    }
-    TickModeCtl &mc = s->h_modectl[mode];
-    memset(&mc, 0, sizeof mc);
-    mc.pending_count = n;
-    mc.results_cap = s->results_cap[mode];
-  }
-  if (!P)
-    for (auto &kv : s->origin)
-      if (kv.second.admitted_at >= 0) {
-        P = &kv.second.trk->params;
-        break;
-      }
-  if (!P) return invalid("dsm_stream: internal: no resident or waiting problem");
-  if (!fresh.empty() && (rc = sync_descs(ctx, fresh.data(), (int)fresh.size()))) return rc;
-  DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream));
-  for (int mode = 0; mode < 2; mode++)
-    if (n_pend[mode]) DSM_HIP(hipMemcpyAsync(s->d_pending[mode], s->h_pending[mode], sizeof(TickPending) * n_pend[mode], hipMemcpyHostToDevice, ctx->stream));
-  DSM_HIP(hipMemcpyAsync(s->d_modectl, s->h_modectl, sizeof(TickModeCtl) * 2, hipMemcpyHostToDevice, ctx->stream));
-  if (nseg > 1) {
-    DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
-    for (int si = 1; si < nseg; si++) DSM_HIP(hipStreamWaitEvent(s->tsegs[si].st, ctx->fork_event, 0));
-  }
-  const int T = s->ticks;
-  size_t ev_used = 0;
-  std::vector<int> ev_lvl;
-  const int speculate = P->fixed_schedule > 0 ? 0 : P->speculate;
-  auto seg_args = [&](int si, int &i0, int &ns, int &mode) {
-    const Seg &sg = s->tsegs[si];
-    i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
-  };
-  for (int si = nseg - 1; si >= 0; si--) {
-    int i0, ns, mode;
-    seg_args(si, i0, ns, mode);
-    if (n_pend[mode])
-      launch_tick_admit(s->tsegs[si].st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, s->d_items[2 * si + s->parity],
-                        s->d_segctl + si, s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0);
-  }
-  for (int t = 0; t < T; t++) {
-    const int buf = (s->parity + t) & 1;
-    for (int si = nseg - 1; si >= 0; si--) {
-      int i0, ns, mode;
-      seg_args(si, i0, ns, mode);
-      const Seg &sg = s->tsegs[si];
-      // grid: what the segment's list held at the end of the last advance plus slack (the kernel strides over a longer list)
-      long long grid = (long long)s->last_count[si] * 5 / 4 + 256;
-      if (s->last_count[si] == 0) grid = (long long)ns * 16;
-      if (grid > s->items_cap[si]) grid = s->items_cap[si];
-      float *part = s->d_partials + (size_t)i0 * s->partial_stride;
-      hipEvent_t ea = nullptr, eb = nullptr;
-      if (ctx->timing && !sg.companion) {
-        ea = get_event(ctx, ev_used++);
-        eb = get_event(ctx, ev_used++);
-        ev_lvl.push_back(0); // (all levels in one launch: booked under index 0)
-        if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
-      }
-      launch_tick_eval(sg.st, mode, (int)grid, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + buf], s->d_segctl + si, buf);
-      if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
-      launch_tick_lm(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, part, s->partial_stride,
-                     s->d_items[2 * si + (buf ^ 1)], s->d_segctl + si, buf ^ 1, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode],
-                     s->d_results[mode], s->d_slot_ticket + i0, speculate);
-    }
-  }
-  s->parity = (s->parity + T) & 1;
-  DSM_HIP(hipGetLastError());
-  for (int si = 1; si < nseg; si++) {
-    hipEvent_t ev = s->tsegs[si].companion ? ctx->companion_event : ctx->join_events[si - 1];
-    DSM_HIP(hipEventRecord(ev, s->tsegs[si].st));
-    DSM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
-  }
-  // ---- one read-back: the control blocks, then as many results as were written ----
-  DSM_HIP(hipMemcpyAsync(s->h_modectl, s->d_modectl, sizeof(TickModeCtl) * 2, hipMemcpyDeviceToHost, ctx->stream));
-  DSM_HIP(hipMemcpyAsync(s->h_segctl, s->d_segctl, sizeof(TickSegCtl) * nseg, hipMemcpyDeviceToHost, ctx->stream));
-  DSM_HIP(hipEventRecord(ctx->ev_total[1], ctx->stream));
-  DSM_HIP(hipStreamSynchronize(ctx->stream));
-  for (int mode = 0; mode < 2; mode++) {
-    const int nr = s->h_modectl[mode].retired;
-    if (nr > s->results_cap[mode]) {
-      set_error("internal: the tick engine retired more problems than its result array holds");
-      return DSM_ERR_STATE;
-    }
-    if (nr) DSM_HIP(hipMemcpyAsync(s->h_results[mode], s->d_results[mode], sizeof(TickResult) * nr, hipMemcpyDeviceToHost, ctx->stream));
-  }
-  DSM_HIP(hipStreamSynchronize(ctx->stream));
-  s->advances++;
-  s->total_ticks += T;
-  s->passes++;
+  const int par = (int)(k & 1), nseg = (int)s->tsegs.size();
+  DSM_HIP(hipEventSynchronize(s->ev_end[par]));
   float ms = 0;
-  DSM_HIP(hipEventElapsedTime(&ms, ctx->ev_total[0], ctx->ev_total[1]));
-  s->stats[0].total_ms = s->stats[1].total_ms = ms;
-  s->stats[0].polls = 1;
-  if (ctx->timing) collect_eval_timing(ctx, ev_lvl, 1, s->stats[0]);
+  DSM_HIP(hipEventElapsedTime(&ms, s->ev_begin[par], s->ev_end[par]));
+  s->stats[0].total_ms += ms, s->stats[1].total_ms += ms; // (the stream's statistics are cumulative)
+  s->stats[0].polls += 1;
+  if (s->inflight_timed[par]) collect_eval_timing(ctx, s->ev_lvl, 1, s->stats[0]);
   for (int si = 0; si < nseg; si++) {
-    if (s->h_segctl[si].overflow) {
+    const TickSegCtl &sc = s->h_segctl[par * nseg + si];
+    if (sc.overflow) {
       set_error("internal: an item list of the tick engine ran over");
       return DSM_ERR_STATE;
     }
-    s->last_count[si] = s->h_segctl[si].count[s->parity];
+    s->last_count[si] = sc.count[s->inflight_parity[par]];
   }
   for (int mode = 0; mode < 2; mode++) {
-    const TickModeCtl &mc = s->h_modectl[mode];
-    const int admitted = mc.pending_head < n_pend[mode] ? mc.pending_head : n_pend[mode];
-    for (int i = 0; i < admitted; i++) {
-      auto it = s->origin.find(s->waiting[mode].front().ticket);
-      if (it != s->origin.end()) it->second.admitted_at = s->advances;
-      s->waiting[mode].pop_front();
+    const TickModeCtl &mc = s->h_modectl[par * 2 + mode];
+    dsm_stream::Seen &sn = s->seen[mode];
+    const int ring = s->ring[mode];
+    const long long new_ret = (long long)mc.retired - sn.retired;
+    if (new_ret < 0 || new_ret > ring) {
+      set_error("internal: the tick engine's result ring ran over");
+      return DSM_ERR_STATE;
     }
-    s->resident[mode] += admitted - mc.retired;
     dsm_stats &st = s->stats[mode];
     for (int l = 0; l < s->nlevels; l++) {
-      st.evals[l] = mc.sched_evals[l];
-      st.evals_residual_only[l] = mc.sched_ro[l];
-      st.launches[l] = T;
+      st.evals[l] += mc.sched_evals[l] - sn.evals[l];
+      st.evals_residual_only[l] += mc.sched_ro[l] - sn.ro[l];
+      sn.evals[l] = mc.sched_evals[l], sn.ro[l] = mc.sched_ro[l];
+      st.launches[l] += s->ticks;
     }
-    for (int i = 0; i < mc.retired; i++) {
-      const TickResult &R = s->h_results[mode][i];
+    const TickResult *res = s->h_results[mode] + (size_t)par * ring;
+    for (long long i = 0; i < new_ret; i++) {
+      const TickResult &R = res[(sn.retired + i) & (ring - 1)];
       auto it = s->origin.find(R.ticket);
       if (it == s->origin.end()) {
         set_error("internal: the tick engine returned an unknown ticket");
@@ -842,7 +761,7 @@ static int tick_advance(dsm_stream *s) {
       r.ticket = R.ticket;
       r.kind = mode;
       r.status = R.status;
-      r.passes = (int)(s->advances - og.admitted_at + 1);
+      r.passes = (int)(k - og.admitted_at + 1);
       if (mode == 0) {
         const bool wrote = R.status == ST_GOOD || R.status == ST_BAD_AFFINE; // as dsm_track_batch (:612-613 / :598)
         memcpy(r.pose, wrote ? R.cur : og.pose0, sizeof r.pose);
@@ -867,19 +786,179 @@ static int tick_advance(dsm_stream *s) {
       s->retired[mode]++;
       s->origin.erase(it);
     }
+    sn.retired = mc.retired;
+    sn.admitted = mc.pending_head;
+    s->resident[mode] = (int)(sn.admitted - sn.retired);
+  }
+  return DSM_OK;
+}
+
+// everything in flight is read back
+static int tick_sync(dsm_stream *s) {
+  while (s->collected < s->advances) {
+    const int rc = tick_collect(s, s->collected);
+    if (rc) return rc;
+    s->collected++;
+  }
+  return DSM_OK;
+}
+
+// One advance of the tick engine, PIPELINED: waiting problems are appended to the device's waiting ring, free slots take them,
+// then `ticks` ticks -- evaluate every staged item, step every resident problem; finished problems retire into the result ring and
+// their slots take the next waiting problem on the spot -- and the control blocks and result rings are copied back behind them.
+// The call returns as soon as that is ENQUEUED; what it reads back is the PREVIOUS advance's (its kernels ran while the host
+// prepared this one), so results surface one advance late and the device never waits for the host (dsm_stream_sync / drain wait
+// for everything).  With dsm_context_set_timing the advance is synchronous (its events are read right away).
+static int tick_advance(dsm_stream *s) {
+  dsm_context *ctx = s->ctx;
+  DSM_HIP(hipSetDevice(ctx->device));
+  if (!s->partial_stride) return DSM_OK; // nothing was ever submitted
+  int rc;
+  if (!s->tick_ready && (rc = tick_setup(s))) return rc;
+  if (s->collected == s->advances && s->resident[0] + s->resident[1] == 0 && s->waiting[0].empty() && s->waiting[1].empty() &&
+      s->handed[0] == s->seen[0].admitted && s->handed[1] == s->seen[1].admitted)
+    return DSM_OK; // idle
+  const int nseg = (int)s->tsegs.size();
+  const int n_track_segs = s->cap[1] > 0 ? nseg - 1 : nseg;
+  rc = ensure_streams(ctx, n_track_segs < 1 ? 1 : n_track_segs, s->cap[1] > 0 && n_track_segs > 0);
+  if (rc) return rc;
+  for (int si = 0; si < nseg; si++)
+    s->tsegs[si].st = si == 0 ? ctx->stream : s->tsegs[si].companion ? ctx->companion_stream : ctx->extra_streams[si - 1];
+  if ((s->advances - s->collected >= 2 || ctx->timing) && (rc = tick_sync(s))) return rc; // (at most one advance behind: the pinned copies are two deep;
+                                                                                          // a timed advance reads its own events alone)
+  const long long k = s->advances;
+  const int par = (int)(k & 1);
+  // ---- waiting problems -> the device's ring: as many as the waiting ring and the result ring have room for ----
+  std::vector<dsm_tracker *> fresh;
+  int n_new[2] = {0, 0};
+  for (int mode = 0; mode < 2; mode++) {
+    const int ring = s->ring[mode];
+    const long long room = std::min<long long>(ring - (s->handed[mode] - s->seen[mode].admitted), ring - (s->handed[mode] - s->seen[mode].retired));
+    const int n = (int)std::min<long long>((long long)s->waiting[mode].size(), room > 0 ? room : 0);
+    n_new[mode] = n;
+    for (int i = 0; i < n; i++) {
+      const Waiting &wt = s->waiting[mode].front();
+      TickPending &pd = s->h_pending[mode][(s->handed[mode] + i) & (ring - 1)];
+      pd.start = wt.start;
+      pd.trk = wt.trk->d_desc;
+      pd.ticket = wt.ticket;
+      fresh.push_back(wt.trk);
+      if (!s->sched_params) s->sched_params = &wt.trk->params;
+      auto it = s->origin.find(wt.ticket);
+      if (it != s->origin.end()) it->second.admitted_at = k;
+      s->waiting[mode].pop_front();
+    }
+  }
+  if (!s->sched_params) return invalid("dsm_stream: internal: no problem was ever handed over");
+  if (!fresh.empty() && (rc = sync_descs(ctx, fresh.data(), (int)fresh.size()))) return rc;
+  DSM_HIP(hipEventRecord(s->ev_begin[par], ctx->stream));
+  if (ctx->timing) DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream)); // (collect_eval_timing places the dispatches relative to it)
+  for (int mode = 0; mode < 2; mode++) {
+    if (!n_new[mode]) continue;
+    const int ring = s->ring[mode];
+    const int first = (int)(s->handed[mode] & (ring - 1)), n1 = std::min(n_new[mode], ring - first);
+    DSM_HIP(hipMemcpyAsync(s->d_pending[mode] + first, s->h_pending[mode] + first, sizeof(TickPending) * n1, hipMemcpyHostToDevice, ctx->stream));
+    if (n_new[mode] > n1)
+      DSM_HIP(hipMemcpyAsync(s->d_pending[mode], s->h_pending[mode], sizeof(TickPending) * (n_new[mode] - n1), hipMemcpyHostToDevice, ctx->stream));
+    s->handed[mode] += n_new[mode];
+    s->h_count_word[par * 2 + mode] = (int)s->handed[mode];
+    DSM_HIP(hipMemcpyAsync(&s->d_modectl[mode].pending_count, &s->h_count_word[par * 2 + mode], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (nseg > 1) {
+    DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+    for (int si = 1; si < nseg; si++) DSM_HIP(hipStreamWaitEvent(s->tsegs[si].st, ctx->fork_event, 0));
+  }
+  const int T = s->ticks;
+  size_t ev_used = 0;
+  s->ev_lvl.clear();
+  const int speculate = s->sched_params->fixed_schedule > 0 ? 0 : s->sched_params->speculate;
+  for (int si = nseg - 1; si >= 0; si--) {
+    const Seg &sg = s->tsegs[si];
+    const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
+    if (s->handed[mode] > s->seen[mode].admitted) // (something may be waiting on the device: free slots take it)
+      launch_tick_admit(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, s->d_items[2 * si + s->parity], s->d_segctl + si,
+                        s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0);
+  }
+  for (int t = 0; t < T; t++) {
+    const int buf = (s->parity + t) & 1;
+    for (int si = nseg - 1; si >= 0; si--) {
+      const Seg &sg = s->tsegs[si];
+      const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
+      // grid: what the segment's list held at the end of the last advance read back, plus slack (the kernel strides over a longer list)
+      long long grid = (long long)s->last_count[si] * 5 / 4 + 256;
+      if (s->last_count[si] == 0) grid = (long long)ns * 16;
+      if (grid > s->items_cap[si]) grid = s->items_cap[si];
+      float *part = s->d_partials + (size_t)i0 * s->partial_stride;
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (ctx->timing && !sg.companion) {
+        ea = get_event(ctx, ev_used++);
+        eb = get_event(ctx, ev_used++);
+        s->ev_lvl.push_back(0); // (all levels in one launch: booked under index 0)
+        if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
+      }
+      launch_tick_eval(sg.st, mode, (int)grid, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + buf], s->d_segctl + si, buf);
+      if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
+      launch_tick_lm(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + (buf ^ 1)],
+                     s->d_segctl + si, buf ^ 1, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_results[mode], s->d_slot_ticket + i0,
+                     speculate);
+    }
+  }
+  s->parity = (s->parity + T) & 1;
+  s->inflight_parity[par] = s->parity;
+  s->inflight_timed[par] = ctx->timing;
+  DSM_HIP(hipGetLastError());
+  for (int si = 1; si < nseg; si++) {
+    hipEvent_t ev = s->tsegs[si].companion ? ctx->companion_event : ctx->join_events[si - 1];
+    DSM_HIP(hipEventRecord(ev, s->tsegs[si].st));
+    DSM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+  }
+  // ---- read-back behind the ticks: control blocks and the result rings, into this advance's pinned copies ----
+  DSM_HIP(hipMemcpyAsync(s->h_modectl + par * 2, s->d_modectl, sizeof(TickModeCtl) * 2, hipMemcpyDeviceToHost, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(s->h_segctl + par * nseg, s->d_segctl, sizeof(TickSegCtl) * nseg, hipMemcpyDeviceToHost, ctx->stream));
+  for (int mode = 0; mode < 2; mode++)
+    if (s->handed[mode] > s->seen[mode].retired) // (results may appear)
+      DSM_HIP(hipMemcpyAsync(s->h_results[mode] + (size_t)par * s->ring[mode], s->d_results[mode], sizeof(TickResult) * s->ring[mode], hipMemcpyDeviceToHost,
+                             ctx->stream));
+  DSM_HIP(hipEventRecord(s->ev_end[par], ctx->stream));
+  s->advances++;
+  s->total_ticks += T;
+  s->passes++;
+  // what was in flight before this advance has finished on the device by now, or finishes while the host is busy here
+  if (ctx->timing || !s->pipelined) return tick_sync(s);
+  while (s->collected < s->advances - 1) {
+    rc = tick_collect(s, s->collected);
+    if (rc) return rc;
+    s->collected++;
   }
   return DSM_OK;
 }
 
 extern "C" {
 
+int dsm_stream_sync(dsm_stream *s) {
+  if (!s) return invalid("null stream");
+  if (s->engine != 1 || !s->tick_ready) return DSM_OK;
+  DSM_HIP(hipSetDevice(s->ctx->device));
+  return tick_sync(s);
+}
+
+int dsm_stream_set_pipelined(dsm_stream *s, int on) {
+  if (!s) return invalid("null stream");
+  const int rc = dsm_stream_sync(s);
+  if (rc) return rc;
+  s->pipelined = on != 0;
+  return DSM_OK;
+}
+
 int dsm_stream_drain(dsm_stream *s) {
   if (!s) return invalid("null stream");
   for (;;) {
+    int rc = dsm_stream_sync(s); // (the tail is short chains: nothing to overlap)
+    if (rc) return rc;
     int resident = 0, waiting = 0;
     dsm_stream_counts(s, &resident, &waiting, nullptr);
     if (resident == 0 && waiting == 0) return DSM_OK;
-    const int rc = dsm_stream_advance(s);
+    rc = dsm_stream_advance(s);
     if (rc) return rc;
   }
 }

@@ -2268,11 +2268,25 @@ __device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned 
 __device__ __forceinline__ void tick_try_admit(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
                                                unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc,
                                                const TickPending *pending, unsigned long long *slot_ticket, int lane) {
-  int h = 0;
-  if (lane == 0) h = mc->pending_head < mc->pending_count ? atomicAdd(&mc->pending_head, 1) : 0x7FFFFFFF;
+  // pending_head / pending_count are monotonic over the life of the stream (the waiting list is a ring the host appends to while the
+  // device consumes): an index is taken by compare-and-swap so that the head never runs past the count -- an overshoot would skip
+  // entries the host appends later
+  int h = -1;
+  if (lane == 0) {
+    const int cnt = __hip_atomic_load(&mc->pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur = __hip_atomic_load(&mc->pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (cur < cnt) {
+      const int seen = atomicCAS(&mc->pending_head, cur, cur + 1);
+      if (seen == cur) {
+        h = cur;
+        break;
+      }
+      cur = seen;
+    }
+  }
   h = __builtin_amdgcn_readfirstlane(h);
-  if (h >= mc->pending_count) return;
-  const TickPending &Pn = pending[h];
+  if (h < 0) return;
+  const TickPending &Pn = pending[h & (mc->ring - 1)];
   const TrackerDev *tp = Pn.trk;
   stage_in(trk, tp, lane, 64);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2371,9 +2385,9 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   }
   // the problem terminated: its result, then the slot takes the next waiting problem
   if (lane == 0) {
-    const int r = atomicAdd(&mc->retired, 1);
-    if (r < mc->results_cap) {
-      TickResult &R = results[r];
+    const int r = atomicAdd(&mc->retired, 1); // monotonic; the host never lets more problems in than the result ring has room for
+    {
+      TickResult &R = results[r & (mc->ring - 1)];
       const LMState &F = sh.st;
       R.ticket = slot_ticket[prob];
       R.status = F.status;

@@ -256,6 +256,13 @@ class Stream:
     def drain(self):
         check(self.L.dsm_stream_drain(self.h))
 
+    def sync(self):
+        """wait for everything in flight and read it back (the tick engine's advances are pipelined)"""
+        check(self.L.dsm_stream_sync(self.h))
+
+    def set_pipelined(self, on):
+        check(self.L.dsm_stream_set_pipelined(self.h, int(bool(on))))
+
     def counts(self):
         """(resident, waiting, results ready)"""
         a, b, c = C.c_int(), C.c_int(), C.c_int()

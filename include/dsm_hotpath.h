@@ -338,9 +338,16 @@ int dsm_stream_submit_track(dsm_stream *s, int n, dsm_tracker *const *trackers, 
                             int coarsest_lvl, const double *min_res_for_abort, uint64_t *tickets_out);
 int dsm_stream_submit_scale(dsm_stream *s, int n, dsm_tracker *const *trackers, const float *scale0, int coarsest_lvl,
                             uint64_t *tickets_out);
+/* One advance.  Tick engine: PIPELINED by default -- the call returns once the advance is enqueued and reads back the PREVIOUS one
+ * (whose kernels ran while the host prepared this one), so results surface one advance late and the device never waits for the
+ * host; dsm_stream_sync waits for everything in flight and reads it back (dsm_stream_drain does so itself);
+ * dsm_stream_set_pipelined(s, 0) makes every advance synchronous.  Pass engine: synchronous. */
 int dsm_stream_advance(dsm_stream *s);
+int dsm_stream_sync(dsm_stream *s);
+int dsm_stream_set_pipelined(dsm_stream *s, int on);
 int dsm_stream_drain(dsm_stream *s);
 int dsm_stream_results(dsm_stream *s, int max_results, dsm_stream_result *out, int *n_out);
+/* as of the last read-back: problems in a slot / waiting (on the host or in the device's waiting ring) / results ready */
 int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *results_out);
 /* The engine behind advance (set before the first advance / while nothing is resident):
  *   0  PASSES: one sweep down the pyramid per advance with a bounded number of lock-step rounds per level (below); problems
@@ -356,7 +363,8 @@ int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance);
 int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q);
 /* ... or fixed: rounds_per_level[DSM_MAX_LEVELS] for problems of `mode` (0 track, 1 scale); entries <= 0 / NULL = learnt */
 int dsm_stream_set_rounds(dsm_stream *s, int mode, const int *rounds_per_level);
-/* statistics of the LAST pass (evaluations, algorithmic bytes, launches = rounds per level, timing as dsm_context_set_timing) */
+/* CUMULATIVE statistics of the stream as of the last read-back (evaluations staged, algorithmic bytes of the problems retired,
+ * launches = rounds / ticks per level, device time of the advances, per-dispatch timing as dsm_context_set_timing): callers difference them */
 int dsm_stream_get_stats(dsm_stream *s, dsm_stats *track_out, dsm_stats *scale_out);
 /* the schedule in force and the stream's counters: passes run, problems retired (of `mode`), slot-passes spent carrying */
 int dsm_stream_get_schedule(dsm_stream *s, int mode, int *rounds_out, long long *passes_out, long long *retired_out, long long *carried_out);

@@ -19,11 +19,13 @@ def _batch_reference(ctx, trks, nl, scales):
     return good, poses, affs, last, flow, err, sc, ev_t, ev_s
 
 
-def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1, engine=0, ticks=0):  # noqa: PLR0913
+def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1, engine=0, ticks=0, pipelined=True):  # noqa: PLR0913
     from direct_stereo_slam_amd.tracker import Stream
 
     n = len(trks)
     st = Stream(ctx, track_slots, scale_slots, engine, ticks)
+    if not pipelined:
+        st.set_pipelined(False)
     if rounds is not None:
         st.set_rounds(0, rounds)
         st.set_rounds(1, rounds)
@@ -102,8 +104,10 @@ def test_stream_results_equal_the_batch_calls_bit_for_bit(ctx, streams):
         # (a) a pool as large as the job; (b) a small pool, few ticks per advance: slots are refilled inside an advance and
         # across advances; (c) one tick per advance, submissions in waves; (d) many ticks: problems admitted AND retired
         # inside one advance
-        for slots, sslots, ticks, waves in ((20, 20, 16, 1), (7, 5, 5, 1), (6, 4, 1, 3), (3, 2, 200, 2)):
-            res, passes, sched = _stream_run(ctx, trks, nl, scales.copy(), slots, sslots, None, None, waves, engine=1, ticks=ticks)
+        # (advances are pipelined -- results surface one advance late -- except in the last case, where every advance is read
+        # back before the call returns)
+        for slots, sslots, ticks, waves, pipelined in ((20, 20, 16, 1, True), (7, 5, 5, 1, True), (6, 4, 1, 3, True), (3, 2, 200, 2, True), (7, 5, 5, 2, False)):
+            res, passes, sched = _stream_run(ctx, trks, nl, scales.copy(), slots, sslots, None, None, waves, engine=1, ticks=ticks, pipelined=pipelined)
             _check(res, ref, len(trks), nl)
     finally:
         ctx.set_streams(1)

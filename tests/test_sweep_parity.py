@@ -5,7 +5,10 @@ depend on the summation order; the device reduces in a fixed tree, the reference
 the two paths may legitimately part ways where a test is decided by those bits.  What must hold:
   * the tracked / aborted FLAG is the same in every case;
   * the two paths take the same route -- same per-level evaluation counts AND poses within 1e-4 -- in at least 96 % of the
-    cases (round 2 measured 475 of 480 on the counts); with equal counts the scales agree to 1e-4 relative;
+    cases (round 2 measured 475 of 480 on the counts; round 4: 8 of these 256 part ways, and a build whose per-point values
+    follow the reference's operation sequence to the letter -- IEEE divisions, no FMA: only the ORDER of the sums left --
+    parts ways in 7: the summation order owns the flips, tools/experiments/lm_flip_attribution_r04.log); with equal counts
+    the scales agree to 1e-4 relative;
   * where they part ways (a test decided by the last bits of a float sum; on the 154x46 scenes with three times the motion
     the valley is flat enough for that to move the end point) both still end within 2 cm of each other."""
 import numpy as np
