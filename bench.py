@@ -62,6 +62,13 @@ CONFIGS = {
 
 
 def parse():
+    a = _parse()
+    if a.streams is None:
+        a.streams = 3 if (a.stream and not a.with_upload) else 2
+    return a
+
+
+def _parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -88,7 +95,8 @@ def parse():
     ap.add_argument("--config", default="S2", choices=list(CONFIGS), help="S2 = 1248x384x6 (the metric's own configuration, default), S1 = 1232x368x5 (reference-faithful), S3 = 1920x1080x6 (BASELINE configs[3] shape)")
     ap.add_argument("--template", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--kf-every", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch is split over (overlaps the small kernels)")
+    ap.add_argument("--streams", type=int, default=None, help="stream groups the resident problems are split over (one group's LM launches run under another's evaluations); "
+                                                             "default: 3 for the streaming form, 2 for the batch form (each measured best, DESIGN.md section 4.3)")
     ap.add_argument("--no-adaptive", action="store_true", help="worst-case launch schedule, never poll")
     ap.add_argument("--with-upload", action="store_true", help="secondary figure: every step also hands the B new left images (and the right images of the keyframes) over as HOST buffers (PCIe + device pyramid build inside the timed region); never the headline value")
     ap.add_argument("--u8", action="store_true", help="with --with-upload: camera bytes (mono8) are handed over instead of float images; the synthetic images are rounded to 0..255 for the whole run")
@@ -118,7 +126,7 @@ def parse():
     ap.add_argument("--cpu-min-frames", type=int, default=448, help="distinct frames the single-core CPU leg covers at least (the ATE half of the metric is taken over them)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the short reference-faithful five-level (S1) leg reported in config.reference_five_level")
-    ap.add_argument("--second-leg-steps", type=int, default=5)
+    ap.add_argument("--second-leg-steps", type=int, default=10, help="timed steps of the fixed-schedule and five-level legs (streamed: ramp-up and drain are inside, so a handful of steps understates the rate)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-core leg of the CPU baseline (one share of frames per physical core, forked workers)")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
@@ -606,7 +614,8 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
                        "a step submits its frames and runs one advance, the pool is drained after the last step)") if ticks else
                       "stream, pass engine (dsm_stream_*: one sweep of the pyramid per step with carried stragglers + drain)",
               "stream": {"engine": "ticks" if ticks else "passes", "track_slots": B, "scale_slots": max(1, len(kf_idx)), "advances_in_timed_region": int(timed_passes),
-                         "ticks_per_advance": (args.stream_ticks or 32) if ticks else None,
+                         "ticks_per_advance": (args.stream_ticks or "auto (library default: what retires about what an advance hands over; mean of the timed region %.1f)"
+                                               % (float(timed["launches"][0]) / max(1, 2 * timed_passes))) if ticks else None,
                          "rounds_per_level_of_a_pass": None if ticks else sched["rounds"][:wl["nl"]], "quantile": args.stream_quantile if args.stream_quantile is not None else "library default",
                          "frames_submitted": frames, "ms_per_pass": 1e3 * dt / max(1, timed_passes),
                          "device_ms_per_advance": float(timed["ms"]) / max(1, timed_passes),

@@ -103,8 +103,18 @@ __host__ __device__ inline int tick_positions(int n) {
   const int nch = num_chunks(n);
   return nch < 8 ? nch : 8 * ((nch + 7) >> 3);
 }
+// start of an advance, before the stream groups fork: which free slot takes which entry of the waiting ring (tick_reserve_kernel)
+constexpr int kTickMaxSegs = 20;
+struct TickSegDesc {
+  int mode, i0, ns;
+};
+struct TickReserveArgs {
+  int nseg;
+  TickSegDesc seg[kTickMaxSegs];
+};
+void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, int *admit_idx);
 void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket);
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const int *admit_idx);
 void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
                       TickSegCtl *seg, int buf);
 void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,

@@ -22,6 +22,7 @@
 // launch form (profiles/r04_queue_form_b2048.json, r04_launch_form_b2048.json): its per-item cost is there in steady
 // state too, so the streaming form is built on the launches.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -121,6 +122,11 @@ struct dsm_stream {
   int *h_count_word = nullptr; // pinned: the pending_count words of the two advances in flight
   hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
   bool pipelined = true;       // advance returns once its work is enqueued; results surface one advance late
+  // ticks per advance.  auto_ticks (the default until dsm_stream_set_engine names a number): as many as retire 7/8 of what the
+  // advance hands over -- handed x (mean life of a problem in ticks, learnt from the retired ones) / slots x 7/8 (tick_advance)
+  bool auto_ticks = true;
+  double life_ticks = 0.0;
+  int inflight_ticks[2] = {0, 0};
   long long collected = 0;     // advances whose read-back has been processed
   long long handed[2] = {0, 0}; // problems appended to the device's waiting ring so far
   struct Seen {
@@ -132,6 +138,7 @@ struct dsm_stream {
   std::vector<int> ev_lvl;
   const dsm_params *sched_params = nullptr;
   unsigned long long *d_slot_ticket = nullptr;
+  int *d_admit_idx = nullptr; // per slot: the waiting-ring entry it takes at the start of this advance, or -1 (tick_reserve_kernel)
   int parity = 0;
   int resident[2] = {0, 0};
   struct Origin {
@@ -167,6 +174,7 @@ static void stream_free(dsm_stream *s) {
     if (s->h_results[m]) hipHostFree(s->h_results[m]);
   }
   hipFree(s->d_slot_ticket);
+  hipFree(s->d_admit_idx);
   if (s->h_count_word) hipHostFree(s->h_count_word);
   for (int k = 0; k < 2; k++) {
     if (s->ev_begin[k]) hipEventDestroy(s->ev_begin[k]);
@@ -254,7 +262,7 @@ int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance) {
   dsm_stream_counts(s, &resident, nullptr, nullptr);
   if (resident && engine != s->engine) return invalid("dsm_stream_set_engine: problems are resident");
   s->engine = engine;
-  if (ticks_per_advance > 0) s->ticks = ticks_per_advance;
+  if (ticks_per_advance > 0) s->ticks = ticks_per_advance, s->auto_ticks = false;
   return DSM_OK;
 }
 
@@ -671,6 +679,7 @@ static int tick_setup(dsm_stream *s) {
   if (!rc) rc = alloc_pinned(&s->h_modectl, 2 * 2);
   if (!rc) rc = alloc_pinned(&s->h_count_word, 4);
   if (!rc) rc = alloc_dev(&s->d_slot_ticket, N);
+  if (!rc) rc = alloc_dev(&s->d_admit_idx, N);
   if (rc) return rc;
   // an item list holds at most one evaluation (+ its speculative twin) per slot of the segment
   const int tile_chunks = ((s->w - 4 + kTileEdge - 1) / kTileEdge) * ((s->h - 4 + kTileEdge - 1) / kTileEdge) * kTileEdge * kTileEdge / (kThreads * 16);
@@ -745,11 +754,13 @@ static int tick_collect(dsm_stream *s, long long k) {
       st.evals[l] += mc.sched_evals[l] - sn.evals[l];
       st.evals_residual_only[l] += mc.sched_ro[l] - sn.ro[l];
       sn.evals[l] = mc.sched_evals[l], sn.ro[l] = mc.sched_ro[l];
-      st.launches[l] += s->ticks;
+      st.launches[l] += s->inflight_ticks[par];
     }
     const TickResult *res = s->h_results[mode] + (size_t)par * ring;
+    long long life_sum = 0;
     for (long long i = 0; i < new_ret; i++) {
       const TickResult &R = res[(sn.retired + i) & (ring - 1)];
+      for (int l = 0; l < DSM_MAX_LEVELS; l++) life_sum += R.rounds[l];
       auto it = s->origin.find(R.ticket);
       if (it == s->origin.end()) {
         set_error("internal: the tick engine returned an unknown ticket");
@@ -785,6 +796,10 @@ static int tick_collect(dsm_stream *s, long long k) {
       s->done.push_back(r);
       s->retired[mode]++;
       s->origin.erase(it);
+    }
+    if (new_ret > 0 && mode == (s->cap[0] > 0 ? 0 : 1)) { // (a tick = one LM round of every resident problem)
+      const double mean = (double)life_sum / (double)new_ret;
+      s->life_ticks = s->life_ticks > 0.0 ? 0.75 * s->life_ticks + 0.25 * mean : mean;
     }
     sn.retired = mc.retired;
     sn.admitted = mc.pending_head;
@@ -864,20 +879,41 @@ static int tick_advance(dsm_stream *s) {
     s->h_count_word[par * 2 + mode] = (int)s->handed[mode];
     DSM_HIP(hipMemcpyAsync(&s->d_modectl[mode].pending_count, &s->h_count_word[par * 2 + mode], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   }
+  const bool may_admit[2] = {s->handed[0] > s->seen[0].admitted, s->handed[1] > s->seen[1].admitted}; // (something may be waiting on the device)
+  if (may_admit[0] || may_admit[1]) {
+    TickReserveArgs ra;
+    if (nseg > kTickMaxSegs) return invalid("dsm_stream: too many stream groups");
+    ra.nseg = nseg;
+    for (int si = 0; si < nseg; si++) ra.seg[si] = TickSegDesc{s->tsegs[si].mode, s->tsegs[si].i0, s->tsegs[si].i1 - s->tsegs[si].i0};
+    launch_tick_reserve(ctx->stream, ra, s->d_states, s->d_modectl, s->d_admit_idx);
+  }
   if (nseg > 1) {
     DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
     for (int si = 1; si < nseg; si++) DSM_HIP(hipStreamWaitEvent(s->tsegs[si].st, ctx->fork_event, 0));
   }
-  const int T = s->ticks;
+  int T = s->ticks;
+  if (s->auto_ticks && s->life_ticks > 0.0) {
+    const int m = s->cap[0] > 0 ? 0 : 1;
+    // sized to retire 7/8 of what the advance hands over: the rest stays in the device's waiting ring as the buffer from which a slot
+    // freed by a retirement is refilled on the spot (a caller that hands over a full pool every advance builds a backlog of an eighth of
+    // a pool per advance; it is worked off at full occupancy when the caller stops).  Nothing handed over: the residents' own life.
+    // (With dsm_params.fixed_schedule every problem lives the same number of ticks and a cohort admitted together stays on one level,
+    // which evaluates in larger single-level launches: there an advance is one cohort's whole life.)
+    const double share = s->sched_params->fixed_schedule > 0 ? 1.0 : 0.875;
+    const double t = n_new[m] > 0 ? share * (double)n_new[m] * s->life_ticks / (double)s->cap[m] : s->life_ticks;
+    T = (int)std::ceil(t);
+    T = T < 8 ? 8 : T > 256 ? 256 : T;
+  }
+  s->inflight_ticks[par] = T;
   size_t ev_used = 0;
   s->ev_lvl.clear();
   const int speculate = s->sched_params->fixed_schedule > 0 ? 0 : s->sched_params->speculate;
   for (int si = nseg - 1; si >= 0; si--) {
     const Seg &sg = s->tsegs[si];
     const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
-    if (s->handed[mode] > s->seen[mode].admitted) // (something may be waiting on the device: free slots take it)
+    if (may_admit[mode]) // (free slots take what tick_reserve_kernel gave them)
       launch_tick_admit(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, s->d_items[2 * si + s->parity], s->d_segctl + si,
-                        s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0);
+                        s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0, s->d_admit_idx + i0);
   }
   for (int t = 0; t < T; t++) {
     const int buf = (s->parity + t) & 1;

@@ -2263,29 +2263,11 @@ __device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned 
   }
 }
 
-// wave 0: take the next waiting problem (if any) into slot `prob`: tracker pointer, ticket, state machine started, first items staged.
+// wave 0: entry h of the waiting ring goes into slot `prob`: tracker pointer, ticket, state machine started, first items staged.
 // st / trk: LDS scratch of the caller.
-__device__ __forceinline__ void tick_try_admit(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
-                                               unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc,
-                                               const TickPending *pending, unsigned long long *slot_ticket, int lane) {
-  // pending_head / pending_count are monotonic over the life of the stream (the waiting list is a ring the host appends to while the
-  // device consumes): an index is taken by compare-and-swap so that the head never runs past the count -- an overshoot would skip
-  // entries the host appends later
-  int h = -1;
-  if (lane == 0) {
-    const int cnt = __hip_atomic_load(&mc->pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int cur = __hip_atomic_load(&mc->pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (cur < cnt) {
-      const int seen = atomicCAS(&mc->pending_head, cur, cur + 1);
-      if (seen == cur) {
-        h = cur;
-        break;
-      }
-      cur = seen;
-    }
-  }
-  h = __builtin_amdgcn_readfirstlane(h);
-  if (h < 0) return;
+__device__ __forceinline__ void tick_admit_entry(int mode, int h, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
+                                                 unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, const TickPending *pending,
+                                                 unsigned long long *slot_ticket, int lane) {
   const TickPending &Pn = pending[h & (mc->ring - 1)];
   const TrackerDev *tp = Pn.trk;
   stage_in(trk, tp, lane, 64);
@@ -2304,16 +2286,102 @@ __device__ __forceinline__ void tick_try_admit(int mode, int prob, const Tracker
   tick_push(st, prob, items, seg, buf, cap, mc, lane);
 }
 
-// start of an advance: every free slot takes a waiting problem
+// wave 0, inside a tick: the slot whose problem just retired takes the next waiting problem (if any) on the spot.
+__device__ __forceinline__ void tick_try_admit(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
+                                               unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc,
+                                               const TickPending *pending, unsigned long long *slot_ticket, int lane) {
+  // pending_head / pending_count are monotonic over the life of the stream (the waiting list is a ring the host appends to while the
+  // device consumes): an index is taken by compare-and-swap so that the head never runs past the count -- an overshoot would skip
+  // entries the host appends later.  (Few problems retire in one tick, so the swap is rarely contended; the start of an advance,
+  // where every free slot wants an entry at once, goes through tick_reserve_kernel instead.)
+  int h = -1;
+  if (lane == 0) {
+    const int cnt = __hip_atomic_load(&mc->pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int cur = __hip_atomic_load(&mc->pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (cur < cnt) {
+      const int seen = atomicCAS(&mc->pending_head, cur, cur + 1);
+      if (seen == cur) {
+        h = cur;
+        break;
+      }
+      cur = seen;
+    }
+  }
+  h = __builtin_amdgcn_readfirstlane(h);
+  if (h < 0) return;
+  tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, lane);
+}
+
+// Start of an advance, on the context's stream before the stream groups fork (nothing else touches the stream's state then): one
+// workgroup hands the entries of the waiting rings to the free slots -- admit_idx[slot] = ring index or -1.  Where fewer problems
+// wait than slots are free, the segments (stream groups) of a kind share them in proportion to their free slots.  (Every free
+// slot taking its entry by compare-and-swap on the one head word cost 250-350 us per advance: a retry per winner.)
+__global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, const LMState *__restrict__ states, TickModeCtl *__restrict__ mcs,
+                                                           int *__restrict__ admit_idx) {
+  __shared__ int nfree[kTickMaxSegs], take[kTickMaxSegs], base[kTickMaxSegs], wave_tot[4], running;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < kTickMaxSegs) nfree[tid] = 0;
+  __syncthreads();
+  for (int si = 0; si < a.nseg; si++) {
+    int c = 0;
+    for (int j = tid; j < a.seg[si].ns; j += 256) c += states[a.seg[si].i0 + j].status != ST_RUNNING;
+    if (c) atomicAdd(&nfree[si], c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int mode = 0; mode < 2; mode++) {
+      long long F = 0;
+      for (int si = 0; si < a.nseg; si++)
+        if (a.seg[si].mode == mode) F += nfree[si];
+      const int head = __hip_atomic_load(&mcs[mode].pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int cnt = __hip_atomic_load(&mcs[mode].pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long A = (long long)cnt - head;
+      if (A < 0) A = 0;
+      long long given = 0;
+      for (int si = 0; si < a.nseg; si++)
+        if (a.seg[si].mode == mode) {
+          take[si] = F <= A ? nfree[si] : (int)(A * nfree[si] / (F > 0 ? F : 1));
+          given += take[si];
+        }
+      for (int si = 0; si < a.nseg && F > A && given < A; si++) // (the rounding's remainder: one more each, from the first segment on)
+        if (a.seg[si].mode == mode && take[si] < nfree[si]) take[si]++, given++;
+      int b = head;
+      for (int si = 0; si < a.nseg; si++)
+        if (a.seg[si].mode == mode) base[si] = b, b += take[si];
+      __hip_atomic_store(&mcs[mode].pending_head, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  for (int si = 0; si < a.nseg; si++) {
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < a.seg[si].ns; j0 += 256) {
+      const int j = j0 + tid;
+      const bool fr = j < a.seg[si].ns && states[a.seg[si].i0 + j].status != ST_RUNNING;
+      const unsigned long long m = __ballot(fr);
+      if (lane == 0) wave_tot[wv] = __popcll(m);
+      __syncthreads();
+      int r = running + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wv; w++) r += wave_tot[w];
+      if (j < a.seg[si].ns) admit_idx[a.seg[si].i0 + j] = fr && r < take[si] ? base[si] + r : -1;
+      __syncthreads();
+      if (tid == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+      __syncthreads();
+    }
+  }
+}
+
+// start of an advance: the free slots take the entries tick_reserve_kernel gave them
 __global__ __launch_bounds__(64) void tick_admit_kernel(int mode, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
                                                         int buf, int cap, TickModeCtl *mc, const TickPending *pending,
-                                                        unsigned long long *slot_ticket) {
+                                                        unsigned long long *slot_ticket, const int *__restrict__ admit_idx) {
   const int prob = blockIdx.x;
   __shared__ __attribute__((aligned(16))) LMState st;
   __shared__ __attribute__((aligned(16))) TrackerDev trk;
-  if (states[prob].status == ST_RUNNING) return;
+  const int h = admit_idx[prob];
+  if (h < 0) return;
   stage_in(st, &states[prob], threadIdx.x, 64); // (fields the start does not write keep their old bits: none is read)
-  tick_try_admit(mode, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, threadIdx.x);
+  tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, threadIdx.x);
 }
 
 template <int MODE>
@@ -2404,9 +2472,13 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   tick_try_admit(MODE, prob, trackers, states, sh.st, sh.trk, items_next, seg, buf_next, cap, mc, pending, slot_ticket, lane);
 }
 
+void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, int *admit_idx) {
+  hipLaunchKernelGGL(tick_reserve_kernel, dim3(1), dim3(256), 0, s, a, states, mcs, admit_idx);
+}
 void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket) {
-  hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, items, seg, buf, items_cap, mc, pending, slot_ticket);
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const int *admit_idx) {
+  hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, items, seg, buf, items_cap, mc, pending, slot_ticket,
+                     admit_idx);
 }
 void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
                       TickSegCtl *seg, int buf) {

@@ -14,7 +14,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py $Q --steps 2 --warmup 1 > $OUT/pmc_write.log 2>&1
 # 2. per-kernel statistics of the default command (without the CPU / second legs: they only add host time and other kernels)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py $Q > $OUT/trace.log 2>&1
-python $R/tools/tick_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 3 > $OUT/tick_timeline.txt 2>&1
+python $R/tools/tick_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) 2 1200 > $OUT/tick_timeline.txt 2>&1
 python $R/tools/summarize_profiles_r04.py $OUT $TAG $R/gpurun_out/${TAG}_profiles pmc > $OUT/summary_pmc.log 2>&1
 mkdir -p $R/profiles && cp $R/gpurun_out/${TAG}_profiles/${TAG}_pmc_traffic.json $R/profiles/ 2>/dev/null
 # 3. the default bench line (CPU legs, five-level and fixed-schedule legs, replay and ring-key legs)
@@ -22,7 +22,7 @@ timeout 1500 python $R/bench.py > $OUT/bench_default.log 2>&1
 # 4. the other forms and workloads
 for spec in "batch_form:--stream 0" "pass_engine:--stream-engine 0" "plane_scenes:--scene-family plane" "plane_scenes_batch_form:--scene-family plane --stream 0" \
             "b256:--batch 256" "b1024:--batch 1024" "cfg_S3:--config S3 --batch 256" "cfg_sparse:--template sparse" "fixed3:--fixed-schedule 3" \
-            "b1:--batch 1 --scenes 1 --steps 50 --stream 0" "b1_S1:--batch 1 --scenes 1 --steps 50 --stream 0 --config S1" "ticks16:--stream-ticks 16" "ticks64:--stream-ticks 64" \
+            "b1:--batch 1 --scenes 1 --steps 50 --stream 0" "b1_S1:--batch 1 --scenes 1 --steps 50 --stream 0 --config S1" "ticks16:--stream-ticks 16" "ticks32:--stream-ticks 32" "ticks64:--stream-ticks 64" "streams2:--streams 2" \
             "evals_only_batch_form:--evals-only --kf-every 100000 --streams 1 --stream 0"; do
   name=${spec%%:*}; args=${spec#*:}
   timeout 500 python $R/bench.py $Q $args > $OUT/bench_$name.log 2>&1
