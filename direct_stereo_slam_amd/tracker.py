@@ -221,7 +221,8 @@ class Stream:
             self.set_engine(engine, ticks)
 
     def set_engine(self, engine, ticks=0):
-        """0: passes with carried stragglers; 1 (the library's default): ticks (one LM round per resident problem and tick, device-side admission)"""
+        """0: passes with carried stragglers; 1 (the library's default): ticks (one LM round per resident problem and tick, device-side admission).
+        ticks = 0 keeps what is in force (initially: every advance sized by the stream from the retired problems' mean life)"""
         check(self.L.dsm_stream_set_engine(self.h, int(engine), int(ticks)))
 
     def close(self):
