@@ -1330,7 +1330,23 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         for (const Seg &sg : segs)
           if (seg_bulk(sg) < seg_steps(sg))
             DSM_HIP(hipMemcpyAsync(ctx->h_status + 2 * sg.i0, ctx->d_status + 2 * sg.i0, sizeof(int) * 2 * (sg.i1 - sg.i0), hipMemcpyDeviceToHost, sg.st));
-        for (Seg &sg : segs) {
+        // the segments in the order their read-backs complete (the others keep their queues busy meanwhile): whichever stream is
+        // idle already, else the first one still pending
+        std::vector<char> tail_done(segs.size(), 0);
+        DSM_HIP(hipGetLastError()); // (launch errors so far; a "not ready" answer below is consumed where it is returned)
+        auto idle = [](hipStream_t st) {
+          const hipError_t q = hipStreamQuery(st);
+          if (q == hipErrorNotReady) (void)hipGetLastError();
+          return q == hipSuccess;
+        };
+        for (size_t done = 0; done < segs.size(); done++) {
+          int pick = -1;
+          for (size_t si = 0; si < segs.size() && pick < 0; si++)
+            if (!tail_done[si] && (seg_bulk(segs[si]) >= seg_steps(segs[si]) || idle(segs[si].st))) pick = (int)si;
+          for (size_t si = 0; si < segs.size() && pick < 0; si++)
+            if (!tail_done[si]) pick = (int)si;
+          tail_done[pick] = 1;
+          Seg &sg = segs[pick];
           const int kb = seg_bulk(sg), ks = seg_steps(sg);
           if (kb >= ks) continue;
           DSM_HIP(hipStreamSynchronize(sg.st));

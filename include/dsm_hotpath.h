@@ -73,7 +73,8 @@ typedef struct dsm_params {
   float lambda_extrapolation_limit;   /* literal                    (TrackerAndScaler.cpp:464,863)   0.001*/
   int max_iterations[DSM_MAX_LEVELS]; /* literal {10,20,50,50,50}   (TrackerAndScaler.cpp:463,862); [5]=50 is an extension */
   int adaptive_schedule;              /* 1 (default): speculative per-level launch counts learnt from previous calls, one
-                                         host read-back per pass; 0: enqueue the worst case (2*(7+max_iterations) launch
+                                         host read-back per pass (plus, with compact_tail, one per level and stream group in the
+                                         first pass); 0: enqueue the worst case (2*(7+max_iterations) launch
                                          pairs per level) and never poll.  Scheduling only -- results are identical. */
   int persistent_coarse;              /* N > 0: pyramid levels whose target plane has at most min(N, 9216) pixels (156x48,
                                          120x67, ...; and at most 20 chunks of template points) run their whole LM loop inside
