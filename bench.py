@@ -133,8 +133,10 @@ def _parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the bench plumbing (barrier, max over ranks); nccl = RCCL")
     ap.add_argument("--device-override", type=int, default=-1, help="testing: put every rank on this device")
     ap.add_argument("--membw", action="store_true", help="print the measured read-only streaming bandwidths (two access patterns) and exit")
-    ap.add_argument("--replay", action="store_true", help="run the replay-mode leg alone (config.replay of the default line): one sequence, one frame in flight, C++ adaptors, per-stage ms for the GPU and the CPU path")
+    ap.add_argument("--replay", action="store_true", help="run the replay-mode leg alone (config.replay of the default line): one sequence, one frame in flight, C++ adaptors, per-stage ms for the GPU and the CPU path; "
+                                                             "then --replay-concurrent sequences through one dsm_host::Stream")
     ap.add_argument("--no-replay-leg", action="store_true", help="skip config.replay in the default line")
+    ap.add_argument("--replay-concurrent", type=int, default=64, help="config.replay.<first shape>.concurrent: this many sequences through ONE dsm_host::Stream from C++ (0: skip)")
     ap.add_argument("--replay-frames", type=int, default=200)
     ap.add_argument("--replay-kf-every", type=int, default=4)
     ap.add_argument("--replay-active", type=int, default=2000, help="active points per keyframe (the semi-dense template grows to ~10^4 points by dilation)")
@@ -1124,7 +1126,8 @@ def replay_leg(args, names=("kitti00", "malaga06")):
             write_replay_pack(pack, name, args.replay_frames, args.replay_kf_every, args.replay_active)
             t_pack = time.perf_counter() - t0
             prefix = os.path.join(ROOT, "gpurun_out", "replay_" + name) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.path.join(td, name)
-            p = subprocess.run([exe, pack, prefix, "both"], capture_output=True, text=True, timeout=1200)
+            conc = args.replay_concurrent if name == names[0] else 0  # (the concurrent-sequences leg on the first shape only)
+            p = subprocess.run([exe, pack, prefix, "both", str(conc), "1"], capture_output=True, text=True, timeout=1200)
             if p.returncode != 0:
                 out[name] = {"error": (p.stderr or p.stdout)[-600:]}
                 continue

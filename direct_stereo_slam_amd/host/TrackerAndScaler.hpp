@@ -153,6 +153,9 @@ public:
     uploaded_[slot] = unique_id;
   }
 
+  // (uploadImages below: the pixels with this identity were handed over to `slot` by a batched call)
+  void noteResident(int slot, long long unique_id) { uploaded_[slot] = unique_id; }
+
   // act as pure output (TrackerAndScaler.h:59-64)
   int refFrameID;
   const FrameView *lastRef;
@@ -171,6 +174,20 @@ private:
   int levels_;
   long long uploaded_[2] = {-1, -1};
 };
+
+// uploadImage for many trackers in ONE hand-over (dsm_upload_images: one staging copy, one pyramid launch sequence, one host
+// synchronisation for all of them) -- what a node serving several sequences does with the frames that arrived together
+inline void uploadImages(dsm_context *ctx, const std::vector<TrackerAndScaler *> &trackers, const std::vector<int> &slots,
+                         const std::vector<const void *> &pixels, int pixel_type, const std::vector<float> &ab_exposures,
+                         const std::vector<long long> &unique_ids, size_t row_pitch_bytes = 0) {
+  const size_t n = trackers.size();
+  if (!n) return;
+  if (slots.size() != n || pixels.size() != n || ab_exposures.size() != n || unique_ids.size() != n) throw std::runtime_error("uploadImages: sizes differ");
+  std::vector<dsm_tracker *> ts(n);
+  for (size_t i = 0; i < n; i++) ts[i] = trackers[i]->handle();
+  check(dsm_upload_images(ctx, (int)n, ts.data(), slots.data(), pixels.data(), ab_exposures.data(), pixel_type, row_pitch_bytes), "uploadImages");
+  for (size_t i = 0; i < n; i++) trackers[i]->noteResident(slots[i], unique_ids[i]);
+}
 
 // ---- streaming form of many sequences (dsm_stream_*): continuous admission ------------------------------
 // Many TrackerAndScaler instances (one per sequence / hypothesis) share the GPU: each submits its trackNewestCoarse /

@@ -24,12 +24,12 @@ def _bench():
     return m
 
 
-def _run(tmp_path, which, n_frames=44):
+def _run(tmp_path, which, n_frames=44, extra=()):
     m = _bench()
     exe = m.build_replay_bench()
     pack = tmp_path / "tiny.bin"
     m.write_replay_pack(str(pack), "tiny", n_frames, 4, 600)
-    out = subprocess.run([exe, str(pack), str(tmp_path / "run"), which], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, str(pack), str(tmp_path / "run"), which, *extra], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]), tmp_path
 
@@ -54,3 +54,15 @@ def test_gpu_leg_matches_the_cpu_leg(ctx, tmp_path):
     assert g["frames_lost"] == 0 and g["hypothesis_tries"] == c["hypothesis_tries"]
     assert x["max_abs_trajectory_diff_m"] < 2e-4 and abs(x["ate_ratio_gpu_over_cpu"] - 1) < 0.01
     assert x["queries_with_identical_candidates"] >= x["loop_queries"] - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined", ["1", "0"])
+def test_concurrent_sequences_through_one_stream_equal_the_one_sequence_run(ctx, tmp_path, pipelined):
+    """S sequences submit into ONE dsm_host::Stream from C++ (frames' first hypotheses, keyframes' scale guesses): scheduling only --
+    every sequence's trajectory and scales equal the one-sequence run's bit for bit"""
+    d, _ = _run(tmp_path, "gpu", extra=("6", pipelined))
+    c = d["concurrent"]
+    assert c["sequences"] == 6 and c["frames"] == 6 * 44 and c["frames_lost"] == 0
+    assert c["max_abs_trajectory_diff_vs_the_one_sequence_run_m"] == 0.0 and c["scales_equal_the_one_sequence_run"] is True
+    assert c["frames_per_s"] > 0 and c["advances"] > 0

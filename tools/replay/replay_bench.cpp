@@ -660,6 +660,228 @@ static RunResult run(B &be, const Pack &P) {
   return R;
 }
 
+// ---- concurrent mode: S sequences share the GPU through ONE dsm_host::Stream ("one (or many batched) independent
+// sequence(s) per GPU"; BASELINE configs[3], [4]) ----
+// Every sequence is the driver above reduced to the tracker's calls -- hand-over, trackNewCoarse, makeKeyFrame, optimizeScale, tracker
+// swap (the loop descriptors stay with the one-sequence run) -- and has ONE problem in flight: its frame's first hypothesis (the
+// constant-motion guess; a frame it does not settle goes through the whole list synchronously, as trackHypotheses does) or its
+// keyframe's scale guesses.  All sequences submit into one stream; an advance moves every resident problem.  Results equal the
+// one-sequence run's bit for bit (the stream is scheduling only), which main() checks.
+struct ConcurrentResult {
+  int sequences = 0, advances = 0, fallbacks = 0, lost = 0;
+  long long frames = 0;
+  double wall_ms = 0, latency_ms_sum = 0, latency_ms_max = 0;
+  std::vector<std::vector<SE3>> est;
+  std::vector<std::vector<float>> scales;
+};
+
+static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
+  struct Seq {
+    std::unique_ptr<dsm_host::TrackerAndScaler> a, b;
+    dsm_host::TrackerAndScaler *cur = nullptr, *nxt = nullptr;
+    std::deque<dsm_host::FrameView> views;
+    std::vector<SE3> est;
+    std::vector<float> scales;
+    SE3 T_kf, est_now;
+    AffLight aff_last, aff_now;
+    double last_rmse0 = 100;
+    bool trapped = false;
+    int scale_fails = 0, n_kf = 0, frame = 0, lag = 0, scale_pending = 0;
+    enum { IDLE, TRACKING, SCALING, DONE } state = IDLE;
+    std::vector<SE3> tries;
+    std::vector<uint64_t> scale_tickets;
+    std::vector<float> scale_val, scale_err;
+    Clock::time_point t_start;
+  };
+  ConcurrentResult R;
+  R.sequences = S;
+  dsm_context *ctx = nullptr;
+  dsm_host::check(dsm_context_create(0, &ctx), "dsm_context_create");
+  {
+    dsm_params prm;
+    dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
+    std::vector<double> tv(P.T, P.T + 16);
+    std::vector<Seq> seqs((size_t)S);
+    for (int s = 0; s < S; s++) {
+      Seq &q = seqs[s];
+      q.a.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
+      q.b.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
+      q.a->makeK(P.K[0], P.K[1], P.K[2], P.K[3]);
+      q.b->makeK(P.K[0], P.K[1], P.K[2], P.K[3]);
+      q.cur = q.a.get(), q.nxt = q.b.get();
+      q.lag = s % (2 * P.kf_every); // the sequences' keyframes do not fall on the same iteration
+    }
+    dsm_host::Stream stream(ctx, S, std::min(8 * S, 256));
+    if (!pipelined) dsm_host::check(dsm_stream_set_pipelined(stream.handle(), 0), "dsm_stream_set_pipelined");
+    std::map<uint64_t, std::pair<int, int>> owner; // ticket -> (sequence, index of the scale guess or -1 for the frame's tracking)
+    int n_done = 0;
+    auto left_id = [&](int s, int i) { return (long long)s * 100000000LL + i; };
+    auto frame_done = [&](Seq &q) {
+      const double ms = ms_since(q.t_start);
+      R.latency_ms_sum += ms, R.latency_ms_max = std::max(R.latency_ms_max, ms);
+      R.frames++;
+      q.frame++;
+      q.state = q.frame < P.n_frames ? Seq::IDLE : Seq::DONE;
+      n_done += q.state == Seq::DONE;
+    };
+    auto finish_kf = [&](Seq &q) {
+      std::swap(q.cur, q.nxt); // FrontEnd.cpp:627-632
+      q.T_kf = q.est_now;
+      q.last_rmse0 = 100;
+      frame_done(q);
+    };
+    // keyframes whose right image is still to be handed over (batched: submit_scales below)
+    std::vector<int> want_scale;
+    auto finish_track = [&](int s, Seq &q) {
+      const int i = q.frame;
+      q.est.push_back(q.est_now);
+      q.aff_last = q.aff_now;
+      if (i % P.kf_every != 0) return frame_done(q);
+      const KeyframeData &k = P.kf.at(i); // makeKeyFrame (FrontEnd.cpp:789-811)
+      q.views.emplace_back();
+      dsm_host::FrameView &ref = q.views.back();
+      ref.shell_id = i, ref.unique_id = left_id(s, i), ref.aff_g2l = q.aff_now;
+      q.nxt->setCoarseTrackingRef(ref, *q.cur, (int)k.pu.size(), k.pu.data(), k.pv.data(), k.pid.data(), k.pw.data());
+      q.n_kf++;
+      if (q.n_kf <= 4) return finish_kf(q); // :806
+      q.state = Seq::SCALING;
+      want_scale.push_back(s);
+    };
+    auto submit_scales = [&]() { // the right images of this iteration's new keyframes in ONE hand-over, then their scale guesses
+      if (want_scale.empty()) return;
+      std::vector<dsm_host::TrackerAndScaler *> ts;
+      std::vector<int> slots;
+      std::vector<const void *> px;
+      std::vector<float> ex;
+      std::vector<long long> ids;
+      for (int s : want_scale) {
+        Seq &q = seqs[s];
+        ts.push_back(q.nxt), slots.push_back(DSM_SLOT_NEW_RIGHT), px.push_back(P.kf.at(q.frame).right.data()), ex.push_back(1.0f);
+        ids.push_back(left_id(s, q.frame) + 50000000LL);
+      }
+      dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
+      for (int s : want_scale) {
+        Seq &q = seqs[s];
+        if (q.trapped)
+          q.scale_val = {1.0f}; // FrontEnd.cpp:991-993
+        else
+          q.scale_val = {0.1f, 1, 5, 10, 15, 25, 30, 50}; // :995-1003
+        q.scale_err.assign(q.scale_val.size(), -1.0f);
+        q.scale_pending = (int)q.scale_val.size();
+        for (size_t g = 0; g < q.scale_val.size(); g++) owner[stream.submitScale(*q.nxt, q.scale_val[g], P.nl - 1)] = {s, (int)g};
+      }
+      want_scale.clear();
+    };
+    auto start_frames = [&](int iter) { // every idle sequence's next frame: ONE hand-over for all of them, then their first hypotheses
+      for (int guard = 0; guard < 3; guard++) { // (a sequence's frame 0 completes on the spot: its frame 1 follows in the next round)
+        std::vector<int> who;
+        for (int s = 0; s < S; s++)
+          if (seqs[s].state == Seq::IDLE && iter >= seqs[s].lag) who.push_back(s);
+        if (who.empty()) return;
+        std::vector<dsm_host::TrackerAndScaler *> ts;
+        std::vector<int> slots;
+        std::vector<const void *> px;
+        std::vector<float> ex;
+        std::vector<long long> ids;
+        const auto t0 = Clock::now();
+        for (int s : who) {
+          Seq &q = seqs[s];
+          q.t_start = t0;
+          ts.push_back(q.cur), slots.push_back(DSM_SLOT_NEW_LEFT), px.push_back(P.left[q.frame].data()), ex.push_back(1.0f), ids.push_back(left_id(s, q.frame));
+        }
+        dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
+        bool again = false;
+        for (int s : who) {
+          Seq &q = seqs[s];
+          q.aff_now = q.aff_last;
+          if (q.frame == 0) {
+            q.est_now = P.gt[0]; // the initializer is out of scope: the first frame is at its true pose
+            finish_track(s, q);
+            again = true;
+            continue;
+          }
+          q.tries = hypothesis_list(q.est, q.T_kf);
+          owner[stream.submitTrack(*q.cur, q.tries[0], q.aff_last, P.nl - 1, nullptr)] = {s, -1};
+          q.state = Seq::TRACKING;
+        }
+        if (!again) return;
+      }
+    };
+    auto on_track = [&](int s, Seq &q, const dsm_stream_result &r) {
+      // the first try of trackHypotheses (FrontEnd.cpp:204-247): nothing achieved yet, so no abort threshold
+      const bool good = r.good != 0 && std::isfinite((float)r.last_residuals[0]);
+      SE3 pose;
+      AffLight aff = q.aff_last;
+      double res0 = NAN;
+      bool have = false;
+      if (good && r.last_residuals[0] < q.last_rmse0 * 1.5) { // settled by the first try (:245-247)
+        for (int k = 0; k < 4; k++) pose.q[k] = r.pose[k];
+        for (int k = 0; k < 3; k++) pose.t[k] = r.pose[4 + k];
+        aff = AffLight(r.aff[0], r.aff[1]);
+        res0 = r.last_residuals[0];
+        have = true;
+      } else { // the rest of the list, as the one-sequence driver runs it
+        dsm_host::FrameView fv;
+        fv.shell_id = q.frame, fv.unique_id = left_id(s, q.frame);
+        const dsm_host::HypothesesResult H = dsm_host::trackHypotheses(ctx, *q.cur, fv, q.tries, q.aff_last, P.nl - 1, q.last_rmse0);
+        pose = H.lastF_2_fh, aff = H.aff_g2l, res0 = H.achievedRes[0], have = H.haveOneGood;
+        R.fallbacks++;
+      }
+      R.lost += !have;
+      q.last_rmse0 = res0;
+      q.est_now = se3_mul(pose, q.T_kf);
+      q.aff_now = aff;
+      finish_track(s, q);
+    };
+    auto on_scale = [&](Seq &q, int g, const dsm_stream_result &r) {
+      q.scale_val[g] = r.scale, q.scale_err[g] = r.err;
+      if (--q.scale_pending > 0) return;
+      float new_scale = 1.0f, err = -1.0f;
+      if (q.trapped)
+        new_scale = q.scale_val[0], err = q.scale_err[0];
+      else
+        for (size_t j = 0; j < q.scale_val.size(); j++) // the smallest positive error wins, the first on ties (:998-1001)
+          if (q.scale_err[j] > 0 && (err < 0 || err > q.scale_err[j])) err = q.scale_err[j], new_scale = q.scale_val[j];
+      q.scales.push_back(new_scale);
+      bool ok = err < 15.0f; // scale_opt_thres (main.cpp:302)
+      if (q.trapped && std::fabs(new_scale - 1.0f) > 0.5f) ok = false;
+      q.scale_fails = ok ? 0 : q.scale_fails + 1;
+      if (q.scale_fails > 5) q.trapped = false;
+      if (ok) {
+        q.nxt->scaleCoarseDepthL0(new_scale);
+        q.trapped = true;
+      }
+      finish_kf(q);
+    };
+    std::vector<dsm_stream_result> res;
+    const auto t_all = Clock::now();
+    for (int iter = 0; n_done < S; iter++) {
+      if (iter > 100 * P.n_frames * 8) throw std::runtime_error("concurrent replay: no progress");
+      start_frames(iter);
+      submit_scales();
+      stream.advance();
+      R.advances++;
+      res.clear();
+      stream.results(res);
+      for (const dsm_stream_result &r : res) {
+        const auto it = owner.find(r.ticket);
+        if (it == owner.end()) throw std::runtime_error("concurrent replay: unknown ticket");
+        const int s = it->second.first, g = it->second.second;
+        owner.erase(it);
+        if (g < 0)
+          on_track(s, seqs[s], r);
+        else
+          on_scale(seqs[s], g, r);
+      }
+      submit_scales(); // (keyframes made from this advance's results)
+    }
+    R.wall_ms = ms_since(t_all);
+    for (Seq &q : seqs) R.est.push_back(q.est), R.scales.push_back(q.scales);
+  }
+  dsm_context_destroy(ctx);
+  return R;
+}
+
 static double ate(const std::vector<SE3> &a, const std::vector<SE3> &b) {
   double s = 0;
   for (size_t i = 0; i < a.size(); i++) {
@@ -689,13 +911,16 @@ static void print_result(const char *name, const RunResult &R, const Pack &P, co
 
 int main(int argc, char **argv) {
   if (argc < 3) {
-    fprintf(stderr, "usage: %s pack.bin out_prefix [gpu|cpu|both]\n", argv[0]);
+    fprintf(stderr, "usage: %s pack.bin out_prefix [gpu|cpu|both [concurrent_sequences [pipelined 0|1]]]\n", argv[0]);
     return 2;
   }
   const std::string which = argc > 3 ? argv[3] : "both";
   const Pack P = load_pack(argv[1]);
   const std::string prefix = argv[2];
+  const int n_concurrent = argc > 4 ? atoi(argv[4]) : 0;
+  const bool conc_pipelined = argc > 5 ? atoi(argv[5]) != 0 : true;
   RunResult rg, rc;
+  ConcurrentResult cc;
   bool have_g = false, have_c = false;
   std::vector<int> ids(P.n_frames);
   for (int i = 0; i < P.n_frames; i++) ids[i] = i;
@@ -720,6 +945,10 @@ int main(int argc, char **argv) {
       rg = run(be, P);
       have_g = true;
       dsm_host::save_trajectory((prefix + "_dslam_gpu.txt").c_str(), ids, centres(rg.est)); // LoopHandler.cpp:59-80
+    }
+    if (which != "cpu" && n_concurrent > 0) {
+      (void)run_concurrent(P, n_concurrent, conc_pipelined); // untimed: schedules, allocators, the stream's learnt life of a problem
+      cc = run_concurrent(P, n_concurrent, conc_pipelined);
     }
     if (which != "gpu") {
       CpuBackend be(P);
@@ -753,6 +982,26 @@ int main(int argc, char **argv) {
     printf(", \"gpu_vs_cpu\": {\"max_abs_trajectory_diff_m\": %.6g, \"ate_ratio_gpu_over_cpu\": %.6f, \"loop_queries\": %d, \"queries_with_identical_candidates\": %d, "
            "\"queries_with_identical_search_sc_match\": %d}",
            dmax, ate(rg.est, P.gt) / std::fmax(ate(rc.est, P.gt), 1e-30), (int)rg.candidates.size(), same_cand, same_match);
+  }
+  if (have_g && cc.sequences > 0) {
+    double dmax = 0, ate_max = 0;
+    bool scales_equal = true;
+    for (const std::vector<SE3> &e : cc.est) {
+      ate_max = std::fmax(ate_max, ate(e, P.gt));
+      for (size_t i = 0; i < e.size() && i < rg.est.size(); i++) {
+        const SE3 a = se3_inv(e[i]), b = se3_inv(rg.est[i]);
+        for (int c = 0; c < 3; c++) dmax = std::fmax(dmax, std::fabs(a.t[c] - b.t[c]));
+      }
+    }
+    for (const std::vector<float> &sc : cc.scales) scales_equal = scales_equal && sc == rg.scales;
+    printf(", \"concurrent\": {\"what\": \"%d sequences (the same frames, keyframes out of phase) through ONE dsm_host::Stream from C++: per sequence one problem in flight "
+           "(a frame's first hypothesis, or its keyframe's scale guesses), hand-over, setCoarseTrackingRef and tracker swap as in the one-sequence run; no loop descriptors\", "
+           "\"sequences\": %d, \"pipelined_advances\": %s, \"frames\": %lld, \"wall_ms\": %.3f, \"frames_per_s\": %.1f, \"ms_per_frame_of_one_sequence\": %.4f, "
+           "\"mean_frame_latency_ms\": %.4f, \"max_frame_latency_ms\": %.4f, \"advances\": %d, \"frames_through_the_whole_hypothesis_list\": %d, \"frames_lost\": %d, "
+           "\"max_ate_vs_ground_truth_m\": %.6g, \"max_abs_trajectory_diff_vs_the_one_sequence_run_m\": %.6g, \"scales_equal_the_one_sequence_run\": %s}",
+           cc.sequences, cc.sequences, conc_pipelined ? "true" : "false", cc.frames, cc.wall_ms, 1e3 * (double)cc.frames / cc.wall_ms,
+           cc.wall_ms * cc.sequences / (double)cc.frames, cc.latency_ms_sum / (double)cc.frames, cc.latency_ms_max, cc.advances, cc.fallbacks, cc.lost, ate_max, dmax,
+           scales_equal ? "true" : "false");
   }
   printf("}\n");
   return 0;
