@@ -82,6 +82,14 @@ class StreamResult(C.Structure):
     ]
 
 
+class RefJob(C.Structure):
+    _fields_ = [
+        ("t", C.c_void_p), ("frame_owner", C.c_void_p), ("slot", C.c_int), ("ref_frame_id", C.c_int),
+        ("ref_aff_a", C.c_double), ("ref_aff_b", C.c_double), ("ref_exposure", C.c_float), ("npts", C.c_int),
+        ("pu", c_float_p), ("pv", c_float_p), ("pidepth", c_float_p), ("pweight", c_float_p), ("n_out", c_int_p),
+    ]
+
+
 class LoopJob(C.Structure):
     _fields_ = [
         ("n_kf", C.c_int), ("kf_ids", c_int_p), ("kf_pose_wc", c_double_p), ("cur_cw", c_double_p),
@@ -135,6 +143,7 @@ SYMBOLS = {
     "dsm_tracker_destroy": (C.c_int, [_vp]),
     "dsm_tracker_make_k": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "dsm_tracker_set_ref": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_float, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
+    "dsm_set_refs_from_points": (C.c_int, [_vp, C.c_int, C.POINTER(RefJob)]),
     "dsm_tracker_set_ref_from_points": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_float, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_int_p]),
     "dsm_tracker_scale_depth": (C.c_int, [_vp, C.c_float]),
     "dsm_tracker_get_template": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]),

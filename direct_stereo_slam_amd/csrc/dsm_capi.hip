@@ -541,55 +541,82 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
   return DSM_OK;
 }
 
+int dsm_set_refs_from_points(dsm_context *ctx, int n_jobs, const dsm_ref_job *jobs) {
+  if (!ctx || n_jobs < 0 || (n_jobs && !jobs)) return invalid("dsm_set_refs_from_points: bad argument");
+  if (!n_jobs) return DSM_OK;
+  DSM_HIP(hipSetDevice(ctx->device));
+  std::vector<size_t> off((size_t)n_jobs + 1, 0);
+  for (int j = 0; j < n_jobs; j++) {
+    const dsm_ref_job &J = jobs[j];
+    dsm_tracker *t = J.t, *fo = J.frame_owner;
+    if (!t || !fo || J.slot < 0 || J.slot > 1 || J.npts < 0 || (J.npts > 0 && (!J.pu || !J.pv || !J.pidepth || !J.pweight)))
+      return invalid("dsm_tracker_set_ref_from_points: bad argument");
+    if (t->ctx != ctx || fo->ctx != ctx || fo->w != t->w || fo->h != t->h || fo->nlevels != t->nlevels)
+      return invalid("dsm_tracker_set_ref_from_points: the frame owner must share context, size and levels");
+    if (!fo->have_frame[J.slot]) {
+      set_error("dsm_tracker_set_ref_from_points: the keyframe's pyramid has not been uploaded to that slot");
+      return DSM_ERR_STATE;
+    }
+    for (int l = 0; l < t->nlevels; l++)
+      if ((long long)((t->w >> l) - 4) * ((t->h >> l) - 4) > t->pts_cap[l]) return invalid("template capacity too small");
+    for (int k = 0; k < j; k++)
+      if (jobs[k].t == t) return invalid("dsm_set_refs_from_points: a tracker takes one reference per call");
+    const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, J.npts);
+    off[j + 1] = off[j] + ((floats + 63) & ~(size_t)63);
+  }
+  int rc = ensure_stage(ctx, off[n_jobs]);
+  if (rc) return rc;
+  std::vector<int> h_n((size_t)n_jobs * (DSM_MAX_LEVELS + 1), 0);
+  for (int j = 0; j < n_jobs; j++) {
+    const dsm_ref_job &J = jobs[j];
+    dsm_tracker *t = J.t;
+    t->have_ref = false; // (until its counts are back)
+    float *ws = ctx->d_stage + off[j];
+    const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, J.npts), np_ = (size_t)J.npts;
+    if (J.npts > 0) {
+      DSM_HIP(hipMemcpyAsync(ws, J.pu, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(ws + np_, J.pv, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(ws + 2 * np_, J.pidepth, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
+      DSM_HIP(hipMemcpyAsync(ws + 3 * np_, J.pweight, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int *d_n = (int *)(ws + floats - 64);
+    const float *ref[DSM_MAX_LEVELS];
+    for (int l = 0; l < t->nlevels; l++) ref[l] = J.frame_owner->d_img[J.slot][l];
+    launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, J.npts, ws, ref, kTexel, t->d_pts, d_n);
+    DSM_HIP(hipMemcpyAsync(h_n.data() + (size_t)j * (DSM_MAX_LEVELS + 1), d_n, sizeof(int) * (t->nlevels + 1), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  DSM_HIP(hipGetLastError());
+  DSM_HIP(hipStreamSynchronize(ctx->stream));
+  for (int j = 0; j < n_jobs; j++)
+    if (h_n[(size_t)j * (DSM_MAX_LEVELS + 1) + jobs[j].t->nlevels]) // a point projected outside the image: the reference would corrupt memory (:160)
+      return invalid("dsm_tracker_set_ref_from_points: point outside the level-0 image");
+  for (int j = 0; j < n_jobs; j++) {
+    const dsm_ref_job &J = jobs[j];
+    dsm_tracker *t = J.t;
+    const int *hn = h_n.data() + (size_t)j * (DSM_MAX_LEVELS + 1);
+    for (int l = 0; l < t->nlevels; l++) {
+      t->desc.lv[l].n = hn[l];
+      if (l == 0) t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr; // a semi-dense template has no tile form
+      if (J.n_out) J.n_out[l] = hn[l];
+    }
+    t->desc.ref_a = J.ref_aff_a; // :323-324
+    t->desc.ref_b = J.ref_aff_b;
+    t->desc.ref_exposure = J.ref_exposure;
+    t->ref_frame_id = J.ref_frame_id;
+    t->have_ref = true;
+    t->desc_dirty = true;
+  }
+  return DSM_OK;
+}
+
 int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, int slot, int ref_frame_id, double ref_aff_a,
                                     double ref_aff_b, float ref_exposure, int npts, const float *pu, const float *pv,
                                     const float *pidepth, const float *pweight, int *n_out) {
-  if (!t || !frame_owner || slot < 0 || slot > 1 || npts < 0 || (npts > 0 && (!pu || !pv || !pidepth || !pweight)))
-    return invalid("dsm_tracker_set_ref_from_points: bad argument");
-  dsm_context *ctx = t->ctx;
-  if (frame_owner->ctx != ctx || frame_owner->w != t->w || frame_owner->h != t->h || frame_owner->nlevels != t->nlevels)
-    return invalid("dsm_tracker_set_ref_from_points: the frame owner must share context, size and levels");
-  if (!frame_owner->have_frame[slot]) {
-    set_error("dsm_tracker_set_ref_from_points: the keyframe's pyramid has not been uploaded to that slot");
-    return DSM_ERR_STATE;
-  }
-  DSM_HIP(hipSetDevice(ctx->device));
-  for (int l = 0; l < t->nlevels; l++)
-    if ((long long)((t->w >> l) - 4) * ((t->h >> l) - 4) > t->pts_cap[l]) return invalid("template capacity too small");
-  const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, npts);
-  int rc = ensure_stage(ctx, floats);
-  if (rc) return rc;
-  float *ws = ctx->d_stage;
-  if (npts > 0) {
-    DSM_HIP(hipMemcpyAsync(ws, pu, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
-    DSM_HIP(hipMemcpyAsync(ws + npts, pv, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
-    DSM_HIP(hipMemcpyAsync(ws + 2 * (size_t)npts, pidepth, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
-    DSM_HIP(hipMemcpyAsync(ws + 3 * (size_t)npts, pweight, sizeof(float) * npts, hipMemcpyHostToDevice, ctx->stream));
-  }
-  int *d_n = (int *)(ws + floats - 64);
-  const float *ref[DSM_MAX_LEVELS];
-  for (int l = 0; l < t->nlevels; l++) ref[l] = frame_owner->d_img[slot][l];
-  launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, npts, ws, ref, kTexel, t->d_pts, d_n);
-  DSM_HIP(hipGetLastError());
-  int h_n[DSM_MAX_LEVELS + 1];
-  DSM_HIP(hipMemcpyAsync(h_n, d_n, sizeof(int) * (t->nlevels + 1), hipMemcpyDeviceToHost, ctx->stream));
-  DSM_HIP(hipStreamSynchronize(ctx->stream));
-  if (h_n[t->nlevels]) { // a point projected outside the image: the reference would corrupt memory (:160)
-    t->have_ref = false;
-    return invalid("dsm_tracker_set_ref_from_points: point outside the level-0 image");
-  }
-  for (int l = 0; l < t->nlevels; l++) {
-    t->desc.lv[l].n = h_n[l];
-    if (l == 0) t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr; // a semi-dense template has no tile form
-    if (n_out) n_out[l] = h_n[l];
-  }
-  t->desc.ref_a = ref_aff_a; // :323-324
-  t->desc.ref_b = ref_aff_b;
-  t->desc.ref_exposure = ref_exposure;
-  t->ref_frame_id = ref_frame_id;
-  t->have_ref = true;
-  t->desc_dirty = true;
-  return DSM_OK;
+  if (!t) return invalid("dsm_tracker_set_ref_from_points: bad argument");
+  dsm_ref_job J;
+  J.t = t, J.frame_owner = frame_owner, J.slot = slot, J.ref_frame_id = ref_frame_id, J.ref_aff_a = ref_aff_a, J.ref_aff_b = ref_aff_b;
+  J.ref_exposure = ref_exposure, J.npts = npts, J.pu = pu, J.pv = pv, J.pidepth = pidepth, J.pweight = pweight, J.n_out = n_out;
+  return dsm_set_refs_from_points(t->ctx, 1, &J);
 }
 
 int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {

@@ -175,6 +175,34 @@ private:
   long long uploaded_[2] = {-1, -1};
 };
 
+// setCoarseTrackingRef (device template) for the new keyframes of several sequences in ONE call (dsm_set_refs_from_points: the
+// jobs' launches back to back, one host synchronisation)
+struct RefRequest {
+  TrackerAndScaler *tracker;
+  const FrameView *ref;         // must outlive the tracker's use of lastRef, as in the single call
+  TrackerAndScaler *frameOwner; // whose NEW_LEFT slot holds the keyframe's pyramid
+  int npts;
+  const float *pu, *pv, *pidepth, *pweight;
+};
+inline void setCoarseTrackingRefs(dsm_context *ctx, const std::vector<RefRequest> &reqs) {
+  if (reqs.empty()) return;
+  std::vector<dsm_ref_job> jobs(reqs.size());
+  for (size_t i = 0; i < reqs.size(); i++) {
+    const RefRequest &q = reqs[i];
+    dsm_ref_job &J = jobs[i];
+    J.t = q.tracker->handle(), J.frame_owner = q.frameOwner->handle(), J.slot = DSM_SLOT_NEW_LEFT, J.ref_frame_id = q.ref->shell_id;
+    J.ref_aff_a = q.ref->aff_g2l.a, J.ref_aff_b = q.ref->aff_g2l.b, J.ref_exposure = q.ref->ab_exposure, J.npts = q.npts;
+    J.pu = q.pu, J.pv = q.pv, J.pidepth = q.pidepth, J.pweight = q.pweight, J.n_out = nullptr;
+  }
+  check(dsm_set_refs_from_points(ctx, (int)jobs.size(), jobs.data()), "setCoarseTrackingRefs (device templates)");
+  for (const RefRequest &q : reqs) {
+    q.tracker->lastRef = q.ref;
+    q.tracker->refFrameID = q.ref->shell_id;     // :323
+    q.tracker->lastRef_aff_g2l = q.ref->aff_g2l; // :324
+    q.tracker->firstCoarseRMSE = -1;             // :326
+  }
+}
+
 // uploadImage for many trackers in ONE hand-over (dsm_upload_images: one staging copy, one pyramid launch sequence, one host
 // synchronisation for all of them) -- what a node serving several sequences does with the frames that arrived together
 inline void uploadImages(dsm_context *ctx, const std::vector<TrackerAndScaler *> &trackers, const std::vector<int> &slots,

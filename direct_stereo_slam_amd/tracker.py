@@ -358,6 +358,31 @@ class TrackerAndScaler:
         self.firstCoarseRMSE = -1.0
         return list(n)
 
+    @staticmethod
+    def setCoarseTrackingRefsFromPoints(ctx, jobs):
+        """dsm_set_refs_from_points: the device templates of several trackers' new keyframes in ONE call (one host synchronisation).
+        jobs: dicts with tracker, ref_frame_id, ref_aff, ref_exposure, pu, pv, pidepth, pweight and optionally frame_owner, slot.
+        Returns pc_n per level for every job."""
+        from ._lib import RefJob
+
+        arr = (RefJob * len(jobs))()
+        keep, outs = [], []
+        for J, j in zip(arr, jobs):
+            t = j["tracker"]
+            a = [np.ascontiguousarray(j[k], np.float32) for k in ("pu", "pv", "pidepth", "pweight")]
+            n = (C.c_int * t.nlevels)()
+            keep.append(a)
+            outs.append(n)
+            J.t, J.frame_owner = t.h, j.get("frame_owner", t).h
+            J.slot, J.ref_frame_id = j.get("slot", 0), j["ref_frame_id"]
+            J.ref_aff_a, J.ref_aff_b, J.ref_exposure, J.npts = float(j["ref_aff"][0]), float(j["ref_aff"][1]), j["ref_exposure"], len(a[0])
+            J.pu, J.pv, J.pidepth, J.pweight = [_fp(x) for x in a]
+            J.n_out = C.cast(n, C.POINTER(C.c_int))
+        check(ctx.L.dsm_set_refs_from_points(ctx.h, len(jobs), arr))
+        for j in jobs:
+            j["tracker"].firstCoarseRMSE = -1.0
+        return [list(n) for n in outs]
+
     def scaleCoarseDepthL0(self, scale):
         check(self.L.dsm_tracker_scale_depth(self.h, scale))
 

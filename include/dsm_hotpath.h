@@ -216,6 +216,20 @@ int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, in
                                     double ref_aff_a, double ref_aff_b, float ref_exposure, int npts,
                                     const float *pu, const float *pv, const float *pidepth, const float *pweight,
                                     int *n_out);
+/* The same for the new keyframes of several sequences in ONE call (a node serving many sequences, dsm_stream_*): every job's
+ * splat / pyramid / dilate / emit launches are enqueued back to back and the host waits ONCE for all the per-level counts.
+ * A tracker may appear as `t` in one job only; results per job as dsm_tracker_set_ref_from_points.  On an error no tracker of
+ * the batch has a valid reference any more. */
+typedef struct dsm_ref_job {
+  dsm_tracker *t, *frame_owner;
+  int slot, ref_frame_id;
+  double ref_aff_a, ref_aff_b;
+  float ref_exposure;
+  int npts;
+  const float *pu, *pv, *pidepth, *pweight;
+  int *n_out; /* may be NULL */
+} dsm_ref_job;
+int dsm_set_refs_from_points(dsm_context *ctx, int n_jobs, const dsm_ref_job *jobs);
 /* replaces TrackerAndScaler::scaleCoarseDepthL0(scale) (TrackerAndScaler.cpp:329-336) */
 int dsm_tracker_scale_depth(dsm_tracker *t, float scale);
 /* read back the device template of one level (tests; debugPlotIDepthMap replacement) */

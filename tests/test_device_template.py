@@ -89,3 +89,29 @@ def test_set_ref_from_points_errors(ctx):
     # empty window: every level empty, still a valid (if useless) reference
     n = trk.setCoarseTrackingRefFromPoints(1, (0, 0), 1.0, pu[:0], pv[:0], pid[:0], pw[:0])
     assert n == [0] * sc.nl
+
+
+def test_batched_set_refs_equal_the_single_calls(ctx):
+    """dsm_set_refs_from_points: the new keyframes of several trackers in one call (one host synchronisation) -- every template
+    equal to the one the single call builds, bit for bit; different point counts per job; a tracker twice in one call is refused"""
+    from direct_stereo_slam_amd._lib import DsmError
+
+    sc = make_scene("small", seed=84)
+    jobs, single = [], []
+    for j, npts in enumerate((1500, 40, 2600, 0)):
+        pu, pv, pid, pw = _points(sc, 840 + j, max(npts, 1), collisions=npts > 600)
+        pu, pv, pid, pw = pu[:npts], pv[:npts], pid[:npts], pw[:npts]
+        a, b = hip_tracker(ctx, sc), hip_tracker(ctx, sc)
+        for t in (a, b):
+            t.upload_frame(0, sc.ref_p, 1.0)
+        single.append((a, a.setCoarseTrackingRefFromPoints(10 + j, (0.01 * j, 1.0), 1.0 + j, pu, pv, pid, pw)))
+        jobs.append({"tracker": b, "ref_frame_id": 10 + j, "ref_aff": (0.01 * j, 1.0), "ref_exposure": 1.0 + j, "pu": pu, "pv": pv, "pidepth": pid, "pweight": pw})
+    ns = type(jobs[0]["tracker"]).setCoarseTrackingRefsFromPoints(ctx, jobs)
+    for (a, n_a), job, n_b in zip(single, jobs, ns):
+        b = job["tracker"]
+        assert n_a == n_b and b.refFrameID == a.refFrameID
+        for l in range(sc.nl):
+            for x, y in zip(a.get_template(l), b.get_template(l)):
+                np.testing.assert_array_equal(x, y)
+    with pytest.raises(DsmError):
+        type(jobs[0]["tracker"]).setCoarseTrackingRefsFromPoints(ctx, [jobs[0], jobs[0]])

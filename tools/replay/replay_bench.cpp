@@ -697,6 +697,18 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
   R.sequences = S;
   dsm_context *ctx = nullptr;
   dsm_host::check(dsm_context_create(0, &ctx), "dsm_context_create");
+  // the camera frames in page-locked memory (dsm_host_alloc), as a node's capture buffers would be: the hand-over of the frames that
+  // arrived together is one DMA, not a staged copy of pageable memory (which alone was 2 ms per advance at 128 sequences)
+  const size_t px = (size_t)P.w * P.h;
+  unsigned char *pinned = nullptr;
+  dsm_host::check(dsm_host_alloc(px * ((size_t)P.n_frames + P.kf.size()), (void **)&pinned), "dsm_host_alloc");
+  std::vector<const unsigned char *> left_px((size_t)P.n_frames);
+  std::map<int, const unsigned char *> right_px;
+  {
+    unsigned char *w = pinned;
+    for (int i = 0; i < P.n_frames; i++, w += px) memcpy(w, P.left[i].data(), px), left_px[i] = w;
+    for (const auto &kv : P.kf) memcpy(w, kv.second.right.data(), px), right_px[kv.first] = w, w += px;
+  }
   {
     dsm_params prm;
     dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
@@ -730,22 +742,38 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
       q.last_rmse0 = 100;
       frame_done(q);
     };
-    // keyframes whose right image is still to be handed over (batched: submit_scales below)
-    std::vector<int> want_scale;
+    // frames that became keyframes (their templates are built in ONE call: make_keyframes) and keyframes whose right image is
+    // still to be handed over (batched as well: submit_scales)
+    std::vector<int> want_kf, want_scale;
     auto finish_track = [&](int s, Seq &q) {
-      const int i = q.frame;
       q.est.push_back(q.est_now);
       q.aff_last = q.aff_now;
-      if (i % P.kf_every != 0) return frame_done(q);
-      const KeyframeData &k = P.kf.at(i); // makeKeyFrame (FrontEnd.cpp:789-811)
-      q.views.emplace_back();
-      dsm_host::FrameView &ref = q.views.back();
-      ref.shell_id = i, ref.unique_id = left_id(s, i), ref.aff_g2l = q.aff_now;
-      q.nxt->setCoarseTrackingRef(ref, *q.cur, (int)k.pu.size(), k.pu.data(), k.pv.data(), k.pid.data(), k.pw.data());
-      q.n_kf++;
-      if (q.n_kf <= 4) return finish_kf(q); // :806
-      q.state = Seq::SCALING;
-      want_scale.push_back(s);
+      if (q.frame % P.kf_every != 0) return frame_done(q);
+      q.state = Seq::SCALING; // (busy until its keyframe is through)
+      want_kf.push_back(s);
+    };
+    auto make_keyframes = [&]() { // makeKeyFrame (FrontEnd.cpp:789-811) for every sequence whose frame just became one
+      if (want_kf.empty()) return;
+      std::vector<dsm_host::RefRequest> reqs;
+      for (int s : want_kf) {
+        Seq &q = seqs[s];
+        const KeyframeData &k = P.kf.at(q.frame);
+        q.views.emplace_back();
+        dsm_host::FrameView &ref = q.views.back();
+        ref.shell_id = q.frame, ref.unique_id = left_id(s, q.frame), ref.aff_g2l = q.aff_now;
+        reqs.push_back(dsm_host::RefRequest{q.nxt, &ref, q.cur, (int)k.pu.size(), k.pu.data(), k.pv.data(), k.pid.data(), k.pw.data()});
+      }
+      dsm_host::setCoarseTrackingRefs(ctx, reqs);
+      const std::vector<int> made = want_kf;
+      want_kf.clear();
+      for (int s : made) {
+        Seq &q = seqs[s];
+        q.n_kf++;
+        if (q.n_kf <= 4)
+          finish_kf(q); // :806
+        else
+          want_scale.push_back(s);
+      }
     };
     auto submit_scales = [&]() { // the right images of this iteration's new keyframes in ONE hand-over, then their scale guesses
       if (want_scale.empty()) return;
@@ -756,7 +784,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
       std::vector<long long> ids;
       for (int s : want_scale) {
         Seq &q = seqs[s];
-        ts.push_back(q.nxt), slots.push_back(DSM_SLOT_NEW_RIGHT), px.push_back(P.kf.at(q.frame).right.data()), ex.push_back(1.0f);
+        ts.push_back(q.nxt), slots.push_back(DSM_SLOT_NEW_RIGHT), px.push_back(right_px.at(q.frame)), ex.push_back(1.0f);
         ids.push_back(left_id(s, q.frame) + 50000000LL);
       }
       dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
@@ -787,7 +815,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
         for (int s : who) {
           Seq &q = seqs[s];
           q.t_start = t0;
-          ts.push_back(q.cur), slots.push_back(DSM_SLOT_NEW_LEFT), px.push_back(P.left[q.frame].data()), ex.push_back(1.0f), ids.push_back(left_id(s, q.frame));
+          ts.push_back(q.cur), slots.push_back(DSM_SLOT_NEW_LEFT), px.push_back(left_px[q.frame]), ex.push_back(1.0f), ids.push_back(left_id(s, q.frame));
         }
         dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
         bool again = false;
@@ -804,6 +832,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
           owner[stream.submitTrack(*q.cur, q.tries[0], q.aff_last, P.nl - 1, nullptr)] = {s, -1};
           q.state = Seq::TRACKING;
         }
+        make_keyframes();
         if (!again) return;
       }
     };
@@ -873,11 +902,13 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
         else
           on_scale(seqs[s], g, r);
       }
-      submit_scales(); // (keyframes made from this advance's results)
+      make_keyframes(); // (the frames of this advance's results that became keyframes)
+      submit_scales();
     }
     R.wall_ms = ms_since(t_all);
     for (Seq &q : seqs) R.est.push_back(q.est), R.scales.push_back(q.scales);
   }
+  dsm_host_free(pinned);
   dsm_context_destroy(ctx);
   return R;
 }
