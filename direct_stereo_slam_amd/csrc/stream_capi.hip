@@ -257,12 +257,14 @@ int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q) {
 }
 
 int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance) {
-  if (!s || engine < 0 || engine > 1 || ticks_per_advance < 0 || ticks_per_advance > 4096) return invalid("dsm_stream_set_engine: engine 0 / 1, ticks 0 (keep) .. 4096");
+  if (!s || engine < 0 || engine > 1 || ticks_per_advance < -1 || ticks_per_advance > 4096)
+    return invalid("dsm_stream_set_engine: engine 0 / 1, ticks -1 (the stream's own choice), 0 (keep), 1 .. 4096");
   int resident = 0;
   dsm_stream_counts(s, &resident, nullptr, nullptr);
   if (resident && engine != s->engine) return invalid("dsm_stream_set_engine: problems are resident");
   s->engine = engine;
   if (ticks_per_advance > 0) s->ticks = ticks_per_advance, s->auto_ticks = false;
+  if (ticks_per_advance < 0) s->auto_ticks = true;
   return DSM_OK;
 }
 

@@ -370,8 +370,8 @@ int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *r
  *   1  TICKS: every resident problem advances ONE LM round per tick whatever level it stands on -- one evaluation launch over
  *      a device-built list of (problem, chunk) items of all levels mixed, one LM launch that steps the problems, stages the
  *      next tick's items, retires finished problems and refills their slots from the waiting list ON THE DEVICE; an advance
- *      runs ticks_per_advance ticks with one host read-back at its end (0: keep what is in force).  Until a number is named the
- *      stream sizes every advance itself: the ticks that retire 7/8 of what the advance hands over, from the mean life (in
+ *      runs ticks_per_advance ticks with one host read-back at its end (0: keep what is in force; -1: back to the stream's own
+ *      choice).  Until a number is named the stream sizes every advance itself: the ticks that retire 7/8 of what the advance hands over, from the mean life (in
  *      ticks) of the problems retired so far -- the rest stays in the device's waiting ring as the buffer a freed slot is
  *      refilled from (32 until the first problems have retired; with dsm_params.fixed_schedule: one cohort's whole life).
  *      The default.

@@ -106,7 +106,9 @@ def test_stream_results_equal_the_batch_calls_bit_for_bit(ctx, streams):
         # inside one advance
         # (advances are pipelined -- results surface one advance late -- except in the last case, where every advance is read
         # back before the call returns)
-        for slots, sslots, ticks, waves, pipelined in ((20, 20, 16, 1, True), (7, 5, 5, 1, True), (6, 4, 1, 3, True), (3, 2, 200, 2, True), (7, 5, 5, 2, False)):
+        # (ticks = 0: the stream sizes its advances itself from the retired problems' mean life)
+        for slots, sslots, ticks, waves, pipelined in ((20, 20, 16, 1, True), (7, 5, 5, 1, True), (6, 4, 1, 3, True), (3, 2, 200, 2, True), (7, 5, 5, 2, False),
+                                                      (6, 5, 0, 4, True), (20, 8, 0, 1, False)):
             res, passes, sched = _stream_run(ctx, trks, nl, scales.copy(), slots, sslots, None, None, waves, engine=1, ticks=ticks, pipelined=pipelined)
             _check(res, ref, len(trks), nl)
     finally:
@@ -166,6 +168,10 @@ def test_stream_argument_checks(ctx, engine):
     st.submit_track([trk], [S.IDENTITY_POSE], np.zeros((1, 2)), sc.nl - 1)
     with pytest.raises(DsmError):
         st.submit_track([hip_tracker(ctx, other)], [S.IDENTITY_POSE], np.zeros((1, 2)), other.nl - 1)  # another geometry
+    with pytest.raises(DsmError):
+        st.set_engine(engine, -2)
+    st.set_engine(engine, 12)  # a fixed number of ticks per advance ...
+    st.set_engine(engine, -1)  # ... and back to the stream's own choice
     st.advance()  # an empty pass after everything retired is a no-op
     st.drain()
     assert st.counts()[0] == 0 and len(st.results()) == 1
