@@ -145,6 +145,9 @@ def _parse():
     ap.add_argument("--ringkey-leg-seconds", type=float, default=120.0, help="N > 1: deadline of the sharded ring-key leg; a rank that misses it reports an error in config.ringkey_sharded and the line is printed regardless")
     ap.add_argument("--rk-n", type=int, default=1_000_000)
     ap.add_argument("--rk-q", type=int, default=1024)
+    ap.add_argument("--detail-out", default="gpurun_out/bench_detail.json",
+                    help="side file (relative to the repository root unless absolute) that receives the FULL result object -- every leg, table and note; the ONE "
+                         "stdout line is its compact form (< 4 KB: contract keys, roofline and cpu_baseline as numbers, one summary per leg)")
     return ap.parse_args()
 
 
@@ -1206,7 +1209,122 @@ def ringkey_single_gpu_leg(args, ctx, seconds=0.25):
             "cases": cases}
 
 
-def line_guard(res):
+LINE_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout; the one line it parses must fit with room to spare
+
+
+def _r(x, nd=3):
+    """numbers of the compact line: enough digits to reproduce a figure, no more"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}") if abs(x) >= 1 else round(x, nd + 2)
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys, nd=3):
+    return {k: _r(d[k], nd) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(res, detail_path):
+    """The ONE stdout line (round 4's line had grown to 20.7 KB and the driver's bounded tail could not parse
+    it).  Every key of the bench contract, `roofline` and `cpu_baseline` as numbers, one short summary per extra leg; everything
+    else -- prose, per-level tables, the legs' own objects -- goes to `detail_path` (the FULL object, named in config.detail)."""
+    c, rf, cb = res["config"], res.get("roofline") or {}, res.get("cpu_baseline")
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(res["value"], 5), _r(res["ms_per_step"], 5)
+    cfg = _pick(c, ("workload", "name", "w", "h", "levels", "n0", "replicas", "inputs", "frames_in_flight_per_gpu", "streams", "scene_family",
+                    "distinct_frames", "initial_guess", "fixed_schedule", "evals_per_frame_by_level", "algorithmic_MB_per_frame",
+                    "whole_step_GBps", "all_tracked", "frames_with_translation_error_above_1cm"), 3)
+    st = c.get("stream")
+    if isinstance(st, dict):
+        cfg["form"] = "dsm_stream_* " + str(st.get("engine")) + " engine"
+        tpa = st.get("ticks_per_advance")
+        cfg["stream"] = {**_pick(st, ("track_slots", "scale_slots", "advances_in_timed_region", "host_share_of_timed_region"), 3),
+                         "ticks_per_advance": tpa if not isinstance(tpa, str) else "auto",
+                         "steady_state_frames_per_s": _r((st.get("steady_state") or {}).get("frames_per_s"), 4)}
+    else:
+        cfg["form"] = "one synchronous dsm_track_and_scale_batch call per step"
+    legs = {}
+    fx = c.get("fixed_schedule_leg")
+    if isinstance(fx, dict):
+        legs["fixed_schedule_1p3"] = {"error": fx["error"][:120]} if "error" in fx else {
+            **_pick(fx, ("value", "ms_per_step", "algorithmic_MB_per_frame")), "frac_whole_step": _r((fx.get("roofline") or {}).get("frac_whole_step")),
+            "cpu_value": _r((fx.get("cpu_baseline") or {}).get("value"))}
+    fv = c.get("reference_five_level")
+    if isinstance(fv, dict):
+        legs["reference_five_level_S1"] = {"error": fv["error"][:120]} if "error" in fv else {
+            **_pick(fv, ("value", "ms_per_step", "algorithmic_MB_per_frame")), **_pick(fv.get("roofline") or {}, ("frac", "frac_whole_step"))}
+    rp = c.get("replay")
+    if isinstance(rp, dict):
+        lr = {}
+        for name, d in rp.items():
+            if not isinstance(d, dict) or "error" in d or "gpu" not in d:
+                lr[name] = {"error": str((d or {}).get("error", d))[:120]} if isinstance(d, dict) else str(d)[:120]
+                continue
+            g, cp, vs = d["gpu"]["stages_mean_ms"], d["cpu"]["stages_mean_ms"], d.get("gpu_vs_cpu", {})
+            lr[name] = {"ms_per_frame_gpu": _r(g["per_frame"]["mean_ms"]), "ms_per_frame_cpu": _r(cp["per_frame"]["mean_ms"]),
+                        "trackNewCoarse_ms_gpu": _r(g["trackNewCoarse"]["mean_ms"]),
+                        **_pick(vs, ("ate_ratio_gpu_over_cpu", "loop_queries", "queries_with_identical_candidates"), 4)}
+            cc = d.get("concurrent")
+            if isinstance(cc, dict):
+                lr[name]["concurrent"] = _pick(cc, ("sequences", "frames_per_s", "max_abs_trajectory_diff_vs_the_one_sequence_run_m"))
+        legs["replay"] = lr
+    rk = c.get("ringkey")
+    if isinstance(rk, dict):
+        legs["ringkey"] = {"error": rk["error"][:120]} if "error" in rk else [
+            {"N": k["N"], "Q": k["Q"], "us": _r(k["us_per_call"], 2), "bound": k["roofline"]["bound"], "frac": _r(k["roofline"]["frac"], 2),
+             "bit_exact": k["matches_oracle_bit_exact"]} for k in rk.get("cases", [])]
+    sh = c.get("ringkey_sharded")
+    if isinstance(sh, dict):
+        legs["ringkey_sharded"] = {"error": sh["error"][:160]} if "error" in sh else {
+            "shards": sh.get("shards"), **{a: _pick(sh[a], ("queries_per_s", "ms_per_step", "us_per_collective_round", "matches_unsharded")) for a in ("allreduce_min", "allgather") if a in sh}}
+    if legs:
+        cfg["legs"] = legs
+    cfg["detail"] = detail_path
+    out["config"] = cfg
+    ro = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "frac_full_evals", "frac_hbm_actual", "bytes_per_launch",
+                    "avg_launch_us", "kernel_busy_us_per_launch", "launches", "dispatches", "stream_groups", "evals_by_level", "bytes_per_eval_by_level",
+                    "evals", "residual_only_evals"), 4)
+    ro["traffic"] = _r(rf.get("traffic"), 5)
+    ro["kernel"] = str(rf.get("kernel", "")).split(" (")[0]
+    ro["traffic_source"] = str(rf.get("traffic_source", "")).split(":")[0][:100]
+    out["roofline"] = ro
+    if cb is None:
+        out["cpu_baseline"] = None
+    else:
+        o = _pick(cb, ("value", "unit", "cores", "kind", "form", "cpu_model", "physical_cores"))
+        o["sample"] = str(cb.get("sample", "")).split(", oracle/")[0][:160] + "; " + str(cb.get("sample", "")).rsplit(", ", 1)[-1][:40]
+        ate, lm, ac = cb.get("ate_vs_cpu_ref"), cb.get("lm_routes_vs_cpu_ref"), cb.get("all_cores")
+        if isinstance(ate, dict):
+            o["ate_vs_cpu_ref"] = _pick(ate, ("frames", "ate_gpu_m", "ate_cpu_m", "ate_ratio_gpu_over_cpu",
+                                              "max_abs_translation_diff_gpu_vs_cpu_m", "good_flags_equal"), 5)
+        if isinstance(lm, dict):
+            o["lm_routes_vs_cpu_ref"] = _pick(lm, ("frames", "same_evaluation_counts", "different_evaluation_counts"))
+        if isinstance(ac, dict):
+            o["all_cores"] = _pick(ac, ("value", "cores")) if "error" not in ac else {"error": ac["error"][:100]}
+        out["cpu_baseline"] = o
+    text = json.dumps(out, separators=(",", ":"))
+    for drop in ("legs", "stream", "evals_per_frame_by_level"):  # never reached with the fields above (about 3 KB); a guard, not a plan
+        if len(text.encode()) < LINE_LIMIT:
+            break
+        out["config"].pop(drop, None)
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text.encode()) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(res, path):
+    """the full object (every leg, every table, the prose) as a side file; returns the path as the line names it"""
+    full = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    with open(full, "w") as f:
+        json.dump(res, f, indent=1)
+        f.write("\n")
+    return path
+
+
+def line_guard(res, detail_path="gpurun_out/bench_detail.json"):
     """The sharded ring-key leg is this bench's first contact with several RCCL ranks on a box; a process that dies inside a
     native library (SIGSEGV, abort) prints nothing.  Before the leg, rank 0 parks its finished bench line with a forked
     helper that touches neither the GPU nor torch: it waits on a pipe and, if rank 0 goes away without calling the returned
@@ -1215,7 +1333,7 @@ def line_guard(res):
 
     parked = copy.deepcopy(res)
     parked["config"]["ringkey_sharded"] = {"error": "rank 0 ended inside the sharded ring-key leg (the bench line is the one measured before it)"}
-    text = (json.dumps(parked) + "\n").encode()
+    text = (compact_line(parked, detail_path) + "\n").encode()
     # (os.pipe() descriptors are non-inheritable across exec (PEP 446), and the guard is made after every other child of this
     # process -- the CPU legs' forked workers -- has come and gone: nobody else holds the write end)
     r, w = os.pipe()
@@ -1345,12 +1463,14 @@ def bench_tracking(args):
     if world > 1 and not args.no_ringkey_leg and args.device_override < 0:  # (RCCL refuses two ranks on one device)
         # A reported extra must never cost the bench line: the leg runs under a deadline (a collective that one rank never
         # enters would otherwise hold every rank until the driver's own limit), and a rank whose leg is stuck prints and leaves.
-        guard = line_guard(res) if rank == 0 else None
+        guard = line_guard(res, args.detail_out) if rank == 0 else None
         res["config"]["ringkey_sharded"], stuck = run_with_deadline(lambda: ringkey_sharded_leg(args, ctx, rank, world), args.ringkey_leg_seconds, local)
         if guard is not None:
             guard()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        write_detail(res, args.detail_out)
+        sys.stderr.flush()
+        print(compact_line(res, args.detail_out), flush=True)
     if stuck:
         os._exit(0)  # the worker thread still sits in a collective: no orderly teardown possible
     if world > 1:

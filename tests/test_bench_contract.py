@@ -51,28 +51,84 @@ def _line(out):
     return json.loads(lines[0])
 
 
-@pytest.mark.gpu
-def test_bench_line_carries_every_key_of_the_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--scenes", "2", "--steps", "2",
-                          "--warmup", "1", "--cpu-seconds", "0", "--second-leg-steps", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    d = _line(out)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _check_compact(text, d):
+    """the ONE stdout line: strict JSON, under 4 KB, every key the bench contract names"""
+    assert len(text.encode()) < 4096, len(text.encode())
+    assert "\n" not in text and json.loads(text) == d
+    for k in CONTRACT_KEYS:
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    # the headline workload is the one the metric names: 6 levels
-    assert "6-level" in d["metric"] and "6-level" in d["config"]["workload"] and "1248x384" in d["config"]["workload"]
-    five = d["config"]["reference_five_level"]
-    assert "5-level" in five["workload"] and five["value"] > 0 and 0 < five["roofline"]["frac"] < 1
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["detail"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
+    if c is not None:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+
+
+def test_compact_line_of_the_largest_stored_result_fits_the_drivers_tail():
+    """round 4's full object (20.7 KB: the driver's bounded stdout tail could not parse it) through compact_line, with an
+    8-rank sharded ring-key leg added: < 4 KB, every contract key, and the figures the judge recomputes from"""
+    m = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    leg = {"queries_per_s": 812345.678, "ms_per_step": 1.2605, "merge_us_per_call": 61.234, "collectives_per_call": 3,
+           "us_per_collective_round": 20.4113, "matches_unsharded": True}
+    full["config"]["ringkey_sharded"] = {"workload": "x" * 120, "shards": 8, "merge": "y" * 40, "allreduce_min": leg, "allgather": leg}
+    text = m.compact_line(full, "gpurun_out/bench_detail.json")
+    d = json.loads(text)
+    _check_compact(text, d)
+    assert abs(d["value"] - full["value"]) < 1e-4 * full["value"] and abs(d["ms_per_step"] - full["ms_per_step"]) < 1e-4 * full["ms_per_step"]
+    assert d["roofline"]["evals_by_level"] == full["roofline"]["evals_by_level"]
+    assert d["roofline"]["bytes_per_eval_by_level"] == full["roofline"]["bytes_per_eval_by_level"]
+    assert d["config"]["legs"]["ringkey_sharded"]["allreduce_min"]["matches_unsharded"] is True
+    assert d["cpu_baseline"]["ate_vs_cpu_ref"]["good_flags_equal"] is True
+    # an error inside a leg stays an error in the line (never silently dropped)
+    full["config"]["replay"] = {"error": "boom " * 100}
+    full["config"]["ringkey"] = {"error": "bang"}
+    d2 = json.loads(m.compact_line(full, "x.json"))
+    assert "error" in d2["config"]["legs"]["ringkey"] and d2["config"]["legs"]["replay"]
+    # the batch form (no config.stream) and a rank without the CPU leg
+    full["config"].pop("stream")
+    full["cpu_baseline"] = None
+    d3 = json.loads(m.compact_line(full, "x.json"))
+    assert d3["cpu_baseline"] is None and "batch" in d3["config"]["form"]
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_every_key_of_the_contract(tmp_path):
+    detail = str(tmp_path / "detail.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--scenes", "2", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "0", "--second-leg-steps", "1", "--detail-out", detail], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    line = _line(out)
+    _check_compact(last, line)  # the LAST stdout line is the one JSON line
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    # the headline workload is the one the metric names: 6 levels
+    assert "6-level" in line["metric"] and "6-level" in line["config"]["workload"] and "1248x384" in line["config"]["workload"]
+    assert line["config"]["detail"] == detail
+    assert line["value"] > 0 and abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
+    legs = line["config"]["legs"]
+    assert legs["reference_five_level_S1"]["value"] > 0 and legs["fixed_schedule_1p3"]["cpu_value"] > 0
+    assert all(k["bit_exact"] for k in legs["ringkey"]) and len(legs["ringkey"]) == 4
+    assert 0.99 <= line["cpu_baseline"]["ate_vs_cpu_ref"]["ate_ratio_gpu_over_cpu"] <= 1.01
+    # the side file holds the FULL object: the same headline numbers and every leg's own object
+    d = json.load(open(detail))
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    assert abs(d["value"] - line["value"]) < 1e-4 * d["value"]
+    five = d["config"]["reference_five_level"]
+    assert "5-level" in five["workload"] and five["value"] > 0 and 0 < five["roofline"]["frac"] < 1
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["form"] == "sse-restatement" and c["cores"] == 1 and c["value"] > 0
     ate = c["ate_vs_cpu_ref"]
     assert ate["frames"] >= 2 and ate["good_flags_equal"] and 0.99 <= ate["ate_ratio_gpu_over_cpu"] <= 1.01
@@ -85,7 +141,6 @@ def test_bench_line_carries_every_key_of_the_contract():
     assert "same fixed schedule" in fx["cpu_baseline"]["sample"]
     ac = c["all_cores"]
     assert ac["cores"] >= 2 and ac["value"] > 0 and ac["cpu_model"]
-    assert d["value"] > 0 and abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
 @pytest.mark.gpu
@@ -96,8 +151,9 @@ def test_bench_spawns_its_own_ranks():
                           "--batch", "8", "--scenes", "2", "--steps", "2", "--warmup", "1", "--no-second-leg"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     d = _line(out)
+    assert len(out.stdout.strip().splitlines()[-1].encode()) < 4096
     assert d["n_gpus"] == 2 and d["config"]["replicas"] == 2 and d["cpu_baseline"] is None
-    assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
 
 
 def test_frames_are_distinct_and_round_2s_workload_is_reproducible(monkeypatch):
@@ -148,13 +204,15 @@ def test_line_guard_prints_the_parked_line_only_when_rank0_dies():
     import sys
 
     prog = ("import os, sys, json; sys.path.insert(0, %r); import bench; "
-            "g = bench.line_guard({'value': 1.0, 'config': {}}); "
+            "g = bench.line_guard({'metric': 'm', 'value': 1.0, 'unit': 'u', 'n_gpus': 2, 'steps': 1, 'warmup': 1, 'ms_per_step': 1.0, "
+            "'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'config': {'workload': 'w'}, "
+            "'roofline': {'bound': 'hbm', 'achieved': 1.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 1.25e-4, 'traffic': None}, 'cpu_baseline': None}); "
             "%s")
     died = subprocess.run([sys.executable, "-c", prog % (ROOT, "os.kill(os.getpid(), 9)")], capture_output=True, text=True, timeout=120)
     lines = [l for l in died.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["value"] == 1.0 and "error" in d["config"]["ringkey_sharded"]
+    assert d["value"] == 1.0 and "error" in d["config"]["legs"]["ringkey_sharded"]
     fine = subprocess.run([sys.executable, "-c", prog % (ROOT, "g(); print(json.dumps({'value': 2.0}))")], capture_output=True, text=True, timeout=120)
     lines = [l for l in fine.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["value"] == 2.0
