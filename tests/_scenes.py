@@ -101,3 +101,39 @@ def hip_tracker(ctx, sc, params=None):
     trk.upload_frame(0, sc.new_p, 1.0)
     trk.upload_frame(1, sc.right_p, 1.0)
     return trk
+
+
+def make_relief_frames(size, n_frames, n_tex, seed0=0x5EED0000, noise=2.0, u8=False):
+    """Frames of the bench's default scene family (synth.ReliefScene: a smooth relief under a broadband texture -- bench.py:
+    build_frames): `n_tex` textures, each with its keyframe image, dense template and right image; frame f = texture
+    f mod n_tex under its own ground-truth motion and noise.  Returns a list of Scene objects (one per frame; frames of a
+    texture share the template arrays)."""
+    w, h, klvl, nl = SIZES[size]
+    K = S.level_K(S.kitti_K_work(), klvl)
+    T = S.KITTI_T_STEREO
+    if size in CAMERAS:
+        K, baseline = CAMERAS[size]
+        T = S.KITTI_T_STEREO.copy()
+        T[0, 3] = baseline
+    q = (lambda im: np.clip(np.rint(im), 0, 255).astype(np.float32)) if u8 else (lambda im: im)
+    tex = []
+    for k in range(n_tex):
+        scene = S.ReliefScene(seed=seed0 + k, fx_ref=K[0])
+        rng = np.random.default_rng(seed0 + k)
+        ref = q(scene.render(K, w, h, noise=noise, rng=rng))
+        right = q(scene.render(K, w, h, T[:3, :3], T[:3, 3], noise=noise, rng=rng))
+        ref_p, right_p = O.make_images(ref, nl), O.make_images(right, nl)
+        tex.append((scene, ref, right, ref_p, right_p, S.dense_template(scene, K, w, h, nl, ref_p)))
+    out = []
+    for f in range(n_frames):
+        scene, ref, right, ref_p, right_p, tpl = tex[f % n_tex]
+        rng = np.random.default_rng(seed0 + 0x100000 * (1 + f // n_tex) + f % n_tex)
+        R, t = S.random_motion(rng)
+        sc = Scene()
+        sc.w, sc.h, sc.nl, sc.K, sc.T = w, h, nl, K, T
+        sc.ref_img, sc.right_img = ref, right
+        sc.new_img = q(scene.render(K, w, h, R, t, a=0.02, b=3.0, noise=noise, rng=rng))
+        sc.ref_p, sc.right_p, sc.new_p = ref_p, right_p, O.make_images(sc.new_img, nl)
+        sc.tpl, sc.gt_pose, sc.gt_aff, sc.scene, sc.texture = tpl, S.pose_from_Rt(R, t), np.array([0.02, 3.0]), scene, f % n_tex
+        out.append(sc)
+    return out

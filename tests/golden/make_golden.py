@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from direct_stereo_slam_amd import synth as S  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-from _scenes import make_scene, oracle_tracker  # noqa: E402
+from _scenes import make_relief_frames, make_scene, oracle_tracker  # noqa: E402
 from test_oracle_ringkey import ring_keys  # noqa: E402
 
 
@@ -148,8 +148,37 @@ def loop_descriptor_fixture():
                         lidar_range=40.0, kf_keep=keep, sel_idx=sel, pts_spherical=pts, ringkey=rk, sig_idx=si, sig_val=sv, tfm_pca_rig=tfm)
 
 
+def tracker_relief_fixture():
+    """the bench's default scene family (synth.ReliefScene) at 308x92x3: four frames of one texture handed over as camera
+    bytes (mono8), dense template; expected track per frame and the first frame's scale optimisation.  Replayed through the
+    streaming form (tests/test_stream.py) and against the oracle itself (tests/test_golden.py)."""
+    frames = make_relief_frames("small", 4, 1, seed0=0x5EED0200, u8=True)
+    sc = frames[0]
+    out = {"w": sc.w, "h": sc.h, "nl": sc.nl, "K": np.asarray(sc.K, np.float64), "T": sc.T, "n_frames": len(frames),
+           "ref_u8": sc.ref_img.astype(np.uint8), "right_u8": sc.right_img.astype(np.uint8),
+           "new_u8": np.stack([f.new_img.astype(np.uint8) for f in frames]), "gt_pose": np.stack([f.gt_pose for f in frames])}
+    for l in range(sc.nl):
+        for name, arr in zip(("u", "v", "id", "c"), sc.tpl):
+            out[f"tpl_{name}{l}"] = arr[l]
+    res = []
+    for i, f in enumerate(frames):
+        orc = oracle_tracker(f)
+        good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, [0, 0], f.nl - 1)
+        res.append((good, pose, aff, last, flow, np.array(orc.eval_counts()[0])))
+        if i == 0:
+            err, s = orc.optimize_scale(1.0, f.nl - 1)
+            out["scale_err"], out["scale_out"], out["scale_evals"] = np.float32(err), np.float32(s), np.array(orc.eval_counts()[0])
+    for j, name in enumerate(("track_good", "track_pose", "track_aff", "track_last", "track_flow", "track_evals")):
+        out[name] = np.stack([np.asarray(r[j]) for r in res])
+    np.savez_compressed(os.path.join(HERE, "tracker_relief_small.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "relief":  # (adds the round-5 fixture without rewriting the others)
+        tracker_relief_fixture()
+        sys.exit(0)
     tracker_fixture()
+    tracker_relief_fixture()
     ringkey_fixture()
     tracker_small_fixture()
     pose_estimator_fixture()

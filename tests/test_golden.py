@@ -243,3 +243,30 @@ def test_hip_matches_golden_pose_estimator_and_loop_descriptor(ctx):
     np.testing.assert_array_equal(r["ringkey"], j["ringkey"])  # loop-closure keys: bit exact
     np.testing.assert_array_equal(r["sig_idx"], j["sig_idx"])
     np.testing.assert_allclose(r["sig_val"], j["sig_val"], rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_reproduces_golden_relief_frames():
+    """tracker_relief_small.npz (round 5): the bench's default scene family, four camera-byte frames of one texture -- the oracle
+    on the stored inputs reproduces the stored tracks (pins the oracle; the HIP side is tests/test_stream.py's fixture test)"""
+    d = np.load(os.path.join(G, "tracker_relief_small.npz"))
+    w, h, nl, K, T = int(d["w"]), int(d["h"]), int(d["nl"]), tuple(d["K"]), d["T"]
+    tpl = [[d[f"tpl_{n}{l}"] for l in range(nl)] for n in ("u", "v", "id", "c")]
+    # the template's colours are the keyframe's pyramid at the (integer) template positions
+    ref_p = O.make_images(d["ref_u8"].astype(np.float32), nl)
+    for l in range(nl):
+        np.testing.assert_array_equal(tpl[3][l], ref_p[l][tpl[1][l].astype(int), tpl[0][l].astype(int), 0])
+    right_p = O.make_images(d["right_u8"].astype(np.float32), nl)
+    for i in range(int(d["n_frames"])):
+        orc = O.OracleTracker(w, h, nl, T, K)
+        orc.make_k(*K)
+        orc.set_ref(0, 0.0, 0.0, 1.0, *tpl)
+        orc.set_frame(0, O.make_images(d["new_u8"][i].astype(np.float32), nl), 1.0)
+        orc.set_frame(1, right_p, 1.0)
+        good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        assert good == bool(d["track_good"][i]) and orc.eval_counts()[0] == list(d["track_evals"][i])
+        np.testing.assert_allclose(pose, d["track_pose"][i], atol=1e-12)
+        np.testing.assert_allclose(last, d["track_last"][i], rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(pose[4:], d["gt_pose"][i][4:], atol=5e-3)
+        if i == 0:
+            err, s = orc.optimize_scale(1.0, nl - 1)
+            assert np.float32(s) == d["scale_out"] and np.float32(err) == d["scale_err"] and orc.eval_counts()[0] == list(d["scale_evals"])

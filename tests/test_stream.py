@@ -5,7 +5,7 @@ calls' bit for bit, whatever the pool size, the rounds per pass or the stream gr
 import numpy as np
 import pytest
 
-from _scenes import S, hip_tracker, make_scene
+from _scenes import S, hip_tracker, make_relief_frames, make_scene, oracle_tracker
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +177,131 @@ def test_stream_argument_checks(ctx, engine):
     assert st.counts()[0] == 0 and len(st.results()) == 1
     st.advance()
     st.close()
+
+
+def _oracle_results(frames, kf_every):
+    out = []
+    for i, sc in enumerate(frames):
+        orc = oracle_tracker(sc)
+        good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        ev = list(orc.eval_counts()[0])
+        scale = None
+        if i % kf_every == 0:
+            err, s = orc.optimize_scale(1.0, sc.nl - 1)
+            scale = (err, s, list(orc.eval_counts()[0]))
+        out.append((bool(good), np.asarray(pose), np.asarray(aff), np.asarray(last), ev, scale))
+    return out
+
+
+def _stream_vs_oracle(ctx, frames, track_slots, scale_slots, kf_every, waves, max_route_flips):
+    """frames through the tick engine as bench.py drives it (three stream groups, the stream's own tick sizing, pipelined
+    advances, a pool smaller than the job, submissions in waves) against orc.track / orc.optimize_scale frame by frame
+    (TrackerAndScaler.cpp:451-638, 854-964): flags equal, per-level evaluation counts equal, poses and scales to 1e-4.  A frame
+    whose LM route parts from the oracle's (an accept or break test decided by the last bits of a float sum: DESIGN.md 4.4,
+    tests/test_sweep_parity.py's 4 % bar) is listed; at most `max_route_flips` of them, and they must still end at the same pose
+    to 1e-3."""
+    from direct_stereo_slam_amd.tracker import Stream
+
+    nl = frames[0].nl
+    ref = _oracle_results(frames, kf_every)
+    ctx.set_streams(3)
+    try:
+        trks = [hip_tracker(ctx, sc) for sc in frames]
+        st = Stream(ctx, track_slots, scale_slots, 1, 0)
+        owner, got = {}, []
+        per = (len(frames) + waves - 1) // waves
+        for wv in range(waves):
+            idx = list(range(wv * per, min(len(frames), (wv + 1) * per)))
+            for i, tk in zip(idx, st.submit_track([trks[i] for i in idx], np.tile(S.IDENTITY_POSE, (len(idx), 1)), np.zeros((len(idx), 2)), nl - 1)):
+                owner[tk] = ("track", i)
+            kf = [i for i in idx if i % kf_every == 0]
+            if kf:
+                for i, tk in zip(kf, st.submit_scale([trks[i] for i in kf], np.ones(len(kf), np.float32), nl - 1)):
+                    owner[tk] = ("scale", i)
+            st.advance()
+            got += st.results()
+        st.drain()
+        got += st.results()
+        stats = st.stats()
+        st.close()
+    finally:
+        ctx.set_streams(1)
+    res = {}
+    for r in got:
+        assert r.ticket in owner and owner[r.ticket] not in res  # every problem retires exactly once
+        res[owner[r.ticket]] = r
+    assert len(res) == len(owner)
+    flips = []
+    for i, (good, pose, aff, last, ev, scale) in enumerate(ref):
+        r = res[("track", i)]
+        assert r.kind == 0 and bool(r.good) == good, i
+        same = list(r.evals)[:nl] == ev[:nl]
+        if not same:
+            flips.append((i, list(r.evals)[:nl], ev[:nl]))
+        tol = 1e-4 if same else 1e-3
+        np.testing.assert_allclose(np.array(r.pose), pose, rtol=0, atol=tol * max(1.0, np.abs(pose[4:]).max()), err_msg=f"frame {i}")
+        np.testing.assert_allclose(np.array(r.aff), aff, rtol=10 * tol, atol=10 * tol, err_msg=f"frame {i}")
+        if same:
+            np.testing.assert_allclose(np.array(r.last_residuals)[:nl], last[:nl], rtol=1e-4, err_msg=f"frame {i}")
+        assert np.all(np.isnan(np.array(r.last_residuals)[nl:]))
+        # both paths end at the ground truth (relief scenes: the reference algorithm converges from the identity guess)
+        np.testing.assert_allclose(np.array(r.pose)[4:], frames[i].gt_pose[4:], atol=5e-3)
+        if scale is not None:
+            q = res[("scale", i)]
+            err_o, s_o, ev_s = scale
+            assert q.kind == 1 and abs(q.scale - s_o) < 1e-4 * abs(s_o), i
+            # (err: the oracle's E is the reference's sequential float sum, quirk Q1 -- good to n * 2^-24)
+            assert abs(q.err - err_o) < max(5e-4, 0.5 * len(frames[i].tpl[0][0]) * 2.0 ** -24) * err_o, i
+            if list(q.evals)[:nl] != ev_s[:nl]:
+                flips.append((i, "scale", list(q.evals)[:nl], ev_s[:nl]))
+    assert len(flips) <= max_route_flips, flips
+    return flips, stats
+
+
+def test_tick_engine_on_the_bench_workload_equals_the_oracle(ctx):
+    """the path the bench times -- S2 (1248 x 384, six levels, dense template: 472 720 points, 116 chunks of
+    16 points per thread at level 0), RELIEF scenes, dsm_stream_* tick engine with mixed-level item lists, on-device admission,
+    result rings, pipelined read-back, three stream groups, a pool smaller than the job -- next to the CPU oracle, frame by
+    frame; then two S3 frames (1920 x 1080, six floor-halved levels)."""
+    frames = make_relief_frames("kitti6", 16, 3)
+    assert len(frames[0].tpl[0][0]) == 1244 * 380 and frames[0].nl == 6
+    flips, stats = _stream_vs_oracle(ctx, frames, track_slots=6, scale_slots=2, kf_every=5, waves=2, max_route_flips=1)
+    hd = make_relief_frames("hd6", 2, 1, seed0=0x5EED0100)
+    _stream_vs_oracle(ctx, hd, track_slots=1, scale_slots=1, kf_every=1, waves=1, max_route_flips=0)
+
+
+def test_tick_engine_relief_golden_fixture(ctx):
+    """tests/golden/tracker_relief_small.npz (minted from the oracle by make_golden.py: four camera-byte frames of one relief
+    texture, 308 x 92 x 3) through the tick engine with two track slots: the stored flags, poses, residuals, evaluation counts"""
+    import os
+
+    from direct_stereo_slam_amd.tracker import Stream, TrackerAndScaler
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracker_relief_small.npz"))
+    w, h, nl, K, T = int(g["w"]), int(g["h"]), int(g["nl"]), tuple(g["K"]), g["T"]
+    tpl = [[g[f"tpl_{name}{l}"] for l in range(nl)] for name in ("u", "v", "id", "c")]
+    n = int(g["n_frames"])
+    trks = []
+    for i in range(n):
+        trk = TrackerAndScaler(ctx, w, h, nl, T, K)
+        trk.makeK(*K)
+        trk.setCoarseTrackingRef(i, (0.0, 0.0), 1.0, *tpl)
+        trk.upload_image(0, g["new_u8"][i], 1.0)  # camera bytes in, device makeImages
+        trk.upload_image(1, g["right_u8"], 1.0)
+        trks.append(trk)
+    st = Stream(ctx, 2, 1, 1, 0)
+    tk = st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+    ts = st.submit_scale(trks[:1], np.ones(1, np.float32), nl - 1)
+    st.drain()
+    got = {r.ticket: r for r in st.results()}
+    st.close()
+    for i in range(n):
+        r = got[tk[i]]
+        assert bool(r.good) == bool(g["track_good"][i])
+        assert list(r.evals)[:nl] == list(g["track_evals"][i][:nl])
+        np.testing.assert_allclose(np.array(r.pose), g["track_pose"][i], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(np.array(r.aff), g["track_aff"][i], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(np.array(r.last_residuals)[:nl], g["track_last"][i][:nl], rtol=1e-4)
+    q = got[ts[0]]
+    assert abs(q.scale - float(g["scale_out"])) < 1e-4 and abs(q.err - float(g["scale_err"])) < 5e-4 * float(g["scale_err"])
+    assert list(q.evals)[:nl] == list(g["scale_evals"][:nl])
