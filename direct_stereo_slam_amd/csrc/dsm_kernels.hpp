@@ -78,9 +78,11 @@ struct TickSegCtl { // one per segment (stream group / companion): item counts o
   int overflow; // an item list ran over (cannot happen by construction: checked by the host)
   int pad[29];
 };
-struct TickModeCtl { // one per problem kind, shared by the kind's segments; every counter is monotonic over the stream's life
-  int pending_head, pending_count; // waiting problems: admitted so far (device) / handed over so far (host: the only word it writes)
-  int retired, ring;               // results written so far / entries of the waiting and result rings (a power of two)
+struct TickModeCtl { // one per problem kind, shared by the kind's segments; every counter is monotonic over the stream's life (64 bits:
+                     // 2^31 problems are nine hours at the benchmarked rate)
+  long long pending_head, pending_count; // waiting problems: admitted so far (device) / handed over so far (host: the only word it writes)
+  long long retired;                     // results written so far
+  int ring, pad;                         // entries of the waiting and result rings (a power of two)
   long long sched_evals[DSM_MAX_LEVELS], sched_ro[DSM_MAX_LEVELS]; // evaluations staged (they run in the next tick)
   long long sched_items[DSM_MAX_LEVELS];
 };
@@ -112,9 +114,9 @@ struct TickReserveArgs {
   int nseg;
   TickSegDesc seg[kTickMaxSegs];
 };
-void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, int *admit_idx);
+void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, long long *admit_idx);
 void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const int *admit_idx);
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx);
 void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
                       TickSegCtl *seg, int buf);
 void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,

@@ -119,7 +119,7 @@ struct dsm_stream {
   TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr}; // waiting rings (device / pinned staging)
   TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};   // result rings (device / two pinned copies)
   int ring[2] = {0, 0};
-  int *h_count_word = nullptr; // pinned: the pending_count words of the two advances in flight
+  long long *h_count_word = nullptr; // pinned: the pending_count words of the two advances in flight
   hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_end[2] = {nullptr, nullptr};
   bool pipelined = true;       // advance returns once its work is enqueued; results surface one advance late
   // ticks per advance.  auto_ticks (the default until dsm_stream_set_engine names a number): as many as retire 7/8 of what the
@@ -136,9 +136,12 @@ struct dsm_stream {
   int inflight_parity[2] = {0, 0};
   bool inflight_timed[2] = {false, false}; // the advance was enqueued with per-dispatch events (dsm_context_set_timing)
   std::vector<int> ev_lvl;
-  const dsm_params *sched_params = nullptr;
+  // scheduling switches of the problems in flight, BY VALUE (a tracker may be destroyed as soon as its own result is back -- ADVICE r04:
+  // the stream used to keep a pointer into the first submitted tracker's params for its whole life); refreshed at every hand-over
+  bool have_sched = false;
+  int sched_fixed_schedule = 0, sched_speculate = 0;
   unsigned long long *d_slot_ticket = nullptr;
-  int *d_admit_idx = nullptr; // per slot: the waiting-ring entry it takes at the start of this advance, or -1 (tick_reserve_kernel)
+  long long *d_admit_idx = nullptr; // per slot: the waiting-ring entry it takes at the start of this advance, or -1 (tick_reserve_kernel)
   int parity = 0;
   int resident[2] = {0, 0};
   struct Origin {
@@ -149,6 +152,23 @@ struct dsm_stream {
   std::unordered_map<uint64_t, Origin> origin;
   long long advances = 0, total_ticks = 0;
 };
+
+// the tick engine's resources (tick_setup); safe on a partially set-up stream, leaves every pointer null
+static void tick_free(dsm_stream *s) {
+  auto dev = [](auto *&p) { if (p) hipFree(p); p = nullptr; };
+  auto pin = [](auto *&p) { if (p) hipHostFree(p); p = nullptr; };
+  dev(s->d_segctl), pin(s->h_segctl), dev(s->d_modectl), pin(s->h_modectl);
+  for (unsigned *&p : s->d_items) dev(p);
+  s->d_items.clear();
+  for (int m = 0; m < 2; m++) dev(s->d_pending[m]), pin(s->h_pending[m]), dev(s->d_results[m]), pin(s->h_results[m]);
+  dev(s->d_slot_ticket), dev(s->d_admit_idx), pin(s->h_count_word);
+  for (int k = 0; k < 2; k++) {
+    if (s->ev_begin[k]) hipEventDestroy(s->ev_begin[k]);
+    if (s->ev_end[k]) hipEventDestroy(s->ev_end[k]);
+    s->ev_begin[k] = s->ev_end[k] = nullptr;
+  }
+  s->tick_ready = false;
+}
 
 static void stream_free(dsm_stream *s) {
   hipFree(s->d_tracker_ptrs);
@@ -162,24 +182,7 @@ static void stream_free(dsm_stream *s) {
   hipFree(s->d_tickets);
   hipFree(s->d_rowmap);
   if (s->h_rowmap) hipHostFree(s->h_rowmap);
-  hipFree(s->d_segctl);
-  if (s->h_segctl) hipHostFree(s->h_segctl);
-  hipFree(s->d_modectl);
-  if (s->h_modectl) hipHostFree(s->h_modectl);
-  for (unsigned *p : s->d_items) hipFree(p);
-  for (int m = 0; m < 2; m++) {
-    hipFree(s->d_pending[m]);
-    if (s->h_pending[m]) hipHostFree(s->h_pending[m]);
-    hipFree(s->d_results[m]);
-    if (s->h_results[m]) hipHostFree(s->h_results[m]);
-  }
-  hipFree(s->d_slot_ticket);
-  hipFree(s->d_admit_idx);
-  if (s->h_count_word) hipHostFree(s->h_count_word);
-  for (int k = 0; k < 2; k++) {
-    if (s->ev_begin[k]) hipEventDestroy(s->ev_begin[k]);
-    if (s->ev_end[k]) hipEventDestroy(s->ev_end[k]);
-  }
+  tick_free(s);
   delete s;
 }
 
@@ -200,6 +203,7 @@ static int stream_bind_geometry(dsm_stream *s, dsm_tracker *t) {
 }
 
 static int tick_advance(dsm_stream *s);
+static int tick_sync(dsm_stream *s);
 
 extern "C" {
 
@@ -259,9 +263,19 @@ int dsm_stream_set_quantile(dsm_stream *s, int lvl, double q) {
 int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance) {
   if (!s || engine < 0 || engine > 1 || ticks_per_advance < -1 || ticks_per_advance > 4096)
     return invalid("dsm_stream_set_engine: engine 0 / 1, ticks -1 (the stream's own choice), 0 (keep), 1 .. 4096");
-  int resident = 0;
-  dsm_stream_counts(s, &resident, nullptr, nullptr);
-  if (resident && engine != s->engine) return invalid("dsm_stream_set_engine: problems are resident");
+  if (engine != s->engine) {
+    // both engines share the slot states: a switch needs the stream EMPTY on the device -- every advance read back (the pipelined
+    // counts are one advance old), nothing resident, nothing handed to the device's waiting ring and not yet admitted
+    if (s->engine == 1 && s->tick_ready) {
+      DSM_HIP(hipSetDevice(s->ctx->device));
+      const int rc = tick_sync(s);
+      if (rc) return rc;
+    }
+    int resident = 0;
+    dsm_stream_counts(s, &resident, nullptr, nullptr);
+    const bool on_the_way = s->handed[0] != s->seen[0].admitted || s->handed[1] != s->seen[1].admitted || s->collected != s->advances;
+    if (resident || on_the_way) return invalid("dsm_stream_set_engine: problems are resident or on their way to the device (drain the stream first)");
+  }
   s->engine = engine;
   if (ticks_per_advance > 0) s->ticks = ticks_per_advance, s->auto_ticks = false;
   if (ticks_per_advance < 0) s->auto_ticks = true;
@@ -675,6 +689,7 @@ static int tick_setup(dsm_stream *s) {
     }
   if (s->cap[1] > 0) s->tsegs.push_back(Seg{nullptr, cap0, N, 1, true, {}});
   const int nseg = (int)s->tsegs.size();
+  tick_free(s); // (an earlier attempt that failed half way left its allocations behind: ADVICE r04)
   int rc = alloc_dev(&s->d_segctl, nseg);
   if (!rc) rc = alloc_pinned(&s->h_segctl, 2 * (size_t)nseg);
   if (!rc) rc = alloc_dev(&s->d_modectl, 2);
@@ -746,7 +761,7 @@ static int tick_collect(dsm_stream *s, long long k) {
     const TickModeCtl &mc = s->h_modectl[par * 2 + mode];
     dsm_stream::Seen &sn = s->seen[mode];
     const int ring = s->ring[mode];
-    const long long new_ret = (long long)mc.retired - sn.retired;
+    const long long new_ret = mc.retired - sn.retired;
     if (new_ret < 0 || new_ret > ring) {
       set_error("internal: the tick engine's result ring ran over");
       return DSM_ERR_STATE;
@@ -860,13 +875,13 @@ static int tick_advance(dsm_stream *s) {
       pd.trk = wt.trk->d_desc;
       pd.ticket = wt.ticket;
       fresh.push_back(wt.trk);
-      if (!s->sched_params) s->sched_params = &wt.trk->params;
+      s->sched_fixed_schedule = wt.trk->params.fixed_schedule, s->sched_speculate = wt.trk->params.speculate, s->have_sched = true;
       auto it = s->origin.find(wt.ticket);
       if (it != s->origin.end()) it->second.admitted_at = k;
       s->waiting[mode].pop_front();
     }
   }
-  if (!s->sched_params) return invalid("dsm_stream: internal: no problem was ever handed over");
+  if (!s->have_sched) return invalid("dsm_stream: internal: no problem was ever handed over");
   if (!fresh.empty() && (rc = sync_descs(ctx, fresh.data(), (int)fresh.size()))) return rc;
   DSM_HIP(hipEventRecord(s->ev_begin[par], ctx->stream));
   if (ctx->timing) DSM_HIP(hipEventRecord(ctx->ev_total[0], ctx->stream)); // (collect_eval_timing places the dispatches relative to it)
@@ -878,8 +893,8 @@ static int tick_advance(dsm_stream *s) {
     if (n_new[mode] > n1)
       DSM_HIP(hipMemcpyAsync(s->d_pending[mode], s->h_pending[mode], sizeof(TickPending) * (n_new[mode] - n1), hipMemcpyHostToDevice, ctx->stream));
     s->handed[mode] += n_new[mode];
-    s->h_count_word[par * 2 + mode] = (int)s->handed[mode];
-    DSM_HIP(hipMemcpyAsync(&s->d_modectl[mode].pending_count, &s->h_count_word[par * 2 + mode], sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    s->h_count_word[par * 2 + mode] = s->handed[mode];
+    DSM_HIP(hipMemcpyAsync(&s->d_modectl[mode].pending_count, &s->h_count_word[par * 2 + mode], sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
   }
   const bool may_admit[2] = {s->handed[0] > s->seen[0].admitted, s->handed[1] > s->seen[1].admitted}; // (something may be waiting on the device)
   if (may_admit[0] || may_admit[1]) {
@@ -901,7 +916,7 @@ static int tick_advance(dsm_stream *s) {
     // a pool per advance; it is worked off at full occupancy when the caller stops).  Nothing handed over: the residents' own life.
     // (With dsm_params.fixed_schedule every problem lives the same number of ticks and a cohort admitted together stays on one level,
     // which evaluates in larger single-level launches: there an advance is one cohort's whole life.)
-    const double share = s->sched_params->fixed_schedule > 0 ? 1.0 : 0.875;
+    const double share = s->sched_fixed_schedule > 0 ? 1.0 : 0.875;
     const double t = n_new[m] > 0 ? share * (double)n_new[m] * s->life_ticks / (double)s->cap[m] : s->life_ticks;
     T = (int)std::ceil(t);
     T = T < 8 ? 8 : T > 256 ? 256 : T;
@@ -909,7 +924,7 @@ static int tick_advance(dsm_stream *s) {
   s->inflight_ticks[par] = T;
   size_t ev_used = 0;
   s->ev_lvl.clear();
-  const int speculate = s->sched_params->fixed_schedule > 0 ? 0 : s->sched_params->speculate;
+  const int speculate = s->sched_fixed_schedule > 0 ? 0 : s->sched_speculate;
   for (int si = nseg - 1; si >= 0; si--) {
     const Seg &sg = s->tsegs[si];
     const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;

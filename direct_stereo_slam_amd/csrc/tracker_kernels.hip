@@ -376,6 +376,14 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       }
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
+#ifdef DSM_EXP_PAD // EXPERIMENT (not committed): N extra vector instructions per point -- does the loop's time follow the instruction count?
+      {
+        float dummy = W.u;
+#pragma unroll
+        for (int q = 0; q < DSM_EXP_PAD; q++) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(dummy) : "v"(W.v));
+        asm volatile("" ::"v"(dummy));
+      }
+#endif
       float h0, g1, g2;
       taps_interp<false, !RO>(T, h0, g1, g2);
       // makeImages' "non-finite gradient -> 0", the rare path: the taps are fetched again (so that the common path
@@ -2265,7 +2273,7 @@ __device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned 
 
 // wave 0: entry h of the waiting ring goes into slot `prob`: tracker pointer, ticket, state machine started, first items staged.
 // st / trk: LDS scratch of the caller.
-__device__ __forceinline__ void tick_admit_entry(int mode, int h, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
+__device__ __forceinline__ void tick_admit_entry(int mode, long long h, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
                                                  unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, const TickPending *pending,
                                                  unsigned long long *slot_ticket, int lane) {
   const TickPending &Pn = pending[h & (mc->ring - 1)];
@@ -2294,12 +2302,12 @@ __device__ __forceinline__ void tick_try_admit(int mode, int prob, const Tracker
   // device consumes): an index is taken by compare-and-swap so that the head never runs past the count -- an overshoot would skip
   // entries the host appends later.  (Few problems retire in one tick, so the swap is rarely contended; the start of an advance,
   // where every free slot wants an entry at once, goes through tick_reserve_kernel instead.)
-  int h = -1;
+  long long h = -1;
   if (lane == 0) {
-    const int cnt = __hip_atomic_load(&mc->pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int cur = __hip_atomic_load(&mc->pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long cnt = __hip_atomic_load(&mc->pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long cur = __hip_atomic_load(&mc->pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (cur < cnt) {
-      const int seen = atomicCAS(&mc->pending_head, cur, cur + 1);
+      const long long seen = (long long)atomicCAS((unsigned long long *)&mc->pending_head, (unsigned long long)cur, (unsigned long long)(cur + 1));
       if (seen == cur) {
         h = cur;
         break;
@@ -2307,7 +2315,7 @@ __device__ __forceinline__ void tick_try_admit(int mode, int prob, const Tracker
       cur = seen;
     }
   }
-  h = __builtin_amdgcn_readfirstlane(h);
+  h = ((long long)__builtin_amdgcn_readfirstlane((int)(h >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h);
   if (h < 0) return;
   tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, lane);
 }
@@ -2317,8 +2325,9 @@ __device__ __forceinline__ void tick_try_admit(int mode, int prob, const Tracker
 // wait than slots are free, the segments (stream groups) of a kind share them in proportion to their free slots.  (Every free
 // slot taking its entry by compare-and-swap on the one head word cost 250-350 us per advance: a retry per winner.)
 __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, const LMState *__restrict__ states, TickModeCtl *__restrict__ mcs,
-                                                           int *__restrict__ admit_idx) {
-  __shared__ int nfree[kTickMaxSegs], take[kTickMaxSegs], base[kTickMaxSegs], wave_tot[4], running;
+                                                           long long *__restrict__ admit_idx) {
+  __shared__ int nfree[kTickMaxSegs], take[kTickMaxSegs], wave_tot[4], running;
+  __shared__ long long base[kTickMaxSegs];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < kTickMaxSegs) nfree[tid] = 0;
   __syncthreads();
@@ -2333,9 +2342,9 @@ __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, co
       long long F = 0;
       for (int si = 0; si < a.nseg; si++)
         if (a.seg[si].mode == mode) F += nfree[si];
-      const int head = __hip_atomic_load(&mcs[mode].pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int cnt = __hip_atomic_load(&mcs[mode].pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      long long A = (long long)cnt - head;
+      const long long head = __hip_atomic_load(&mcs[mode].pending_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long cnt = __hip_atomic_load(&mcs[mode].pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long A = cnt - head;
       if (A < 0) A = 0;
       long long given = 0;
       for (int si = 0; si < a.nseg; si++)
@@ -2345,7 +2354,7 @@ __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, co
         }
       for (int si = 0; si < a.nseg && F > A && given < A; si++) // (the rounding's remainder: one more each, from the first segment on)
         if (a.seg[si].mode == mode && take[si] < nfree[si]) take[si]++, given++;
-      int b = head;
+      long long b = head;
       for (int si = 0; si < a.nseg; si++)
         if (a.seg[si].mode == mode) base[si] = b, b += take[si];
       __hip_atomic_store(&mcs[mode].pending_head, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2363,7 +2372,7 @@ __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, co
       __syncthreads();
       int r = running + __popcll(m & ((1ull << lane) - 1ull));
       for (int w = 0; w < wv; w++) r += wave_tot[w];
-      if (j < a.seg[si].ns) admit_idx[a.seg[si].i0 + j] = fr && r < take[si] ? base[si] + r : -1;
+      if (j < a.seg[si].ns) admit_idx[a.seg[si].i0 + j] = fr && r < take[si] ? base[si] + r : -1ll;
       __syncthreads();
       if (tid == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
       __syncthreads();
@@ -2374,11 +2383,11 @@ __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, co
 // start of an advance: the free slots take the entries tick_reserve_kernel gave them
 __global__ __launch_bounds__(64) void tick_admit_kernel(int mode, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
                                                         int buf, int cap, TickModeCtl *mc, const TickPending *pending,
-                                                        unsigned long long *slot_ticket, const int *__restrict__ admit_idx) {
+                                                        unsigned long long *slot_ticket, const long long *__restrict__ admit_idx) {
   const int prob = blockIdx.x;
   __shared__ __attribute__((aligned(16))) LMState st;
   __shared__ __attribute__((aligned(16))) TrackerDev trk;
-  const int h = admit_idx[prob];
+  const long long h = admit_idx[prob];
   if (h < 0) return;
   stage_in(st, &states[prob], threadIdx.x, 64); // (fields the start does not write keep their old bits: none is read)
   tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, threadIdx.x);
@@ -2453,7 +2462,7 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   }
   // the problem terminated: its result, then the slot takes the next waiting problem
   if (lane == 0) {
-    const int r = atomicAdd(&mc->retired, 1); // monotonic; the host never lets more problems in than the result ring has room for
+    const long long r = (long long)atomicAdd((unsigned long long *)&mc->retired, 1ull); // monotonic; the host never lets more problems in than the result ring has room for
     {
       TickResult &R = results[r & (mc->ring - 1)];
       const LMState &F = sh.st;
@@ -2472,11 +2481,11 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   tick_try_admit(MODE, prob, trackers, states, sh.st, sh.trk, items_next, seg, buf_next, cap, mc, pending, slot_ticket, lane);
 }
 
-void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, int *admit_idx) {
+void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, long long *admit_idx) {
   hipLaunchKernelGGL(tick_reserve_kernel, dim3(1), dim3(256), 0, s, a, states, mcs, admit_idx);
 }
 void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const int *admit_idx) {
+                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx) {
   hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, items, seg, buf, items_cap, mc, pending, slot_ticket,
                      admit_idx);
 }

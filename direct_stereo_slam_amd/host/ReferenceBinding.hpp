@@ -17,7 +17,7 @@
 //   static int levels();                                             // dso::pyrLevelsUsed
 //   static SE3 make_se3(const double q_xyzw[4], const double t[3]);  // SE3(Eigen::Quaterniond(w,x,y,z), Vec3(t))
 //   static void fill_params(dsm_params &p);                          // setting_huberTH, setting_coarseCutoffTH, SCALE_*, affine modes
-// INTEGRATION.md section 1 shows the ten-line traits struct for the real types.  tests/test_reference_binding.py instantiates
+// INTEGRATION.md section 1 shows the ten-line traits struct for the real types.  tests/test_host_adaptor.py::test_reference_binding_through_standin_types_equals_the_plain_adaptor instantiates
 // the template with minimal stand-ins of those member names (host/reference_binding_check.cpp) and checks that a track + scale
 // optimisation through it returns, bit for bit, what the plain adaptor returns: the conversions are tested code, not prose.
 #pragma once

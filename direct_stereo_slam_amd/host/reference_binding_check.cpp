@@ -2,7 +2,7 @@
 // methods of the reference's dso::TrackerAndScaler) with minimal stand-ins that carry exactly the member names the binding
 // touches on Sophus::SE3 / dso::AffLight / Eigen vectors / dso::FrameHessian / dso::CalibHessian, and drives it the way
 // FrontEnd.cpp does (makeK, setCoarseTrackingRef, trackNewestCoarse, optimizeScale) on the fixture of
-// tests/test_reference_binding.py (same format as host_adaptor_demo.cpp).  Prints the same JSON line as host_adaptor_demo, so
+// tests/test_host_adaptor.py::test_reference_binding_through_standin_types_equals_the_plain_adaptor (same format as host_adaptor_demo.cpp).  Prints the same JSON line as host_adaptor_demo, so
 // the test can require the two to be equal bit for bit: what is tested is the binding's conversion code, not the stand-ins.
 #include <cstdio>
 #include <cstdlib>

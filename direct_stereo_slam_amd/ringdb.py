@@ -5,8 +5,8 @@ The device scan lives in csrc/ringkey_kernels.hip, the cross-shard merge -- the 
 path -- in csrc/comm_capi.hip behind the C ABI: `Comm` wraps dsm_comm (RCCL, loaded by the library itself) and
 `RingKeyDB.merge_topk_device` calls dsm_ringdb_merge_topk: k rounds of all-reduce(min) over packed
 (dist2 << 32 | global index) candidates with winner pop, or one all-gather + local merge.  A slot-wise min of sorted
-triples would NOT be a correct top-k.  `merge_topk_allreduce_min` is the same algorithm on torch tensors, kept for hosts
-without a GPU (the gloo plumbing test); `RingKeyDB.merge_topk_with` runs the C ABI's merge kernels over a caller-supplied
+triples would NOT be a correct top-k.  (The torch restatement of the round algorithm that the gloo plumbing test uses on hosts
+without a GPU lives with the tests: tests/_merge_ref.py.)  `RingKeyDB.merge_topk_with` runs the C ABI's merge kernels over a caller-supplied
 transport (threads or gloo processes sharing one GPU in the tests).
 """
 import ctypes as C
@@ -41,25 +41,6 @@ def candidates_from_packed(packed_row):
         idx = int(p & 0xFFFFFFFF)
         if idx > 0:
             out.append(idx - 1)
-    return out
-
-
-def merge_topk_allreduce_min(local_sorted, k, all_reduce_min):
-    """local_sorted: (nq, k) int64 torch tensor, ascending per row, NO_CANDIDATE padded.
-    all_reduce_min(tensor) performs the in-place element-wise MIN all-reduce over the shards.
-    Returns the global (nq, k) top-k, identical on every rank."""
-    import torch
-
-    nq = local_sorted.shape[0]
-    ptr = torch.zeros(nq, dtype=torch.int64, device=local_sorted.device)
-    padded = torch.cat([local_sorted, torch.full((nq, 1), NO_CANDIDATE, dtype=torch.int64, device=local_sorted.device)], 1)
-    out = torch.empty((nq, k), dtype=torch.int64, device=local_sorted.device)
-    for r in range(k):
-        head = padded.gather(1, ptr[:, None])[:, 0].contiguous()
-        gmin = head.clone()
-        all_reduce_min(gmin)
-        out[:, r] = gmin
-        ptr = ptr + ((head == gmin) & (gmin != NO_CANDIDATE)).to(torch.int64)  # indices are unique: one owner pops
     return out
 
 

@@ -1,7 +1,7 @@
 """world_size 2, gloo: the cross-shard merge of the ring-key DB (the only collective on the path).
 
 Without a GPU (`-m "not gpu"`): the per-shard k-NN is a numpy brute force with the oracle's distance function and the merge
-is the torch restatement of the round algorithm (ringdb.merge_topk_allreduce_min).
+is the torch restatement of the round algorithm (tests/_merge_ref.py: merge_topk_allreduce_min).
 With a GPU (`-m gpu`): two gloo processes share the device; each scans ITS shard with the HIP kernel
 (dsm_ringdb_knn_packed_host) and the merge is the C ABI's own (dsm_ringdb_merge_topk_with: the kernels RCCL drives in
 dsm_ringdb_merge_topk) with gloo as the transport.  N ranks over RCCL / xGMI: bench.py --gpus N."""
@@ -40,7 +40,7 @@ def worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from direct_stereo_slam_amd.ringdb import merge_topk_allreduce_min
+    from _merge_ref import merge_topk_allreduce_min
     from test_oracle_ringkey import ring_keys
 
     keys = ring_keys(600, seed=5)

@@ -61,10 +61,10 @@ def test_ties_and_duplicates(ctx):
 
 def test_sharded_db_merges_to_unsharded_result(ctx):
     """two shards on one GPU, merged on the host with the same k-round min-with-pop protocol the
-    RCCL path uses (ringdb.merge_topk_allreduce_min)"""
+    RCCL path uses (tests/_merge_ref.py: merge_topk_allreduce_min)"""
     import torch
 
-    from direct_stereo_slam_amd.ringdb import merge_topk_allreduce_min
+    from _merge_ref import merge_topk_allreduce_min
 
     keys = ring_keys(3001, seed=77)
     rng = np.random.default_rng(0)

@@ -242,7 +242,11 @@ def _stream_vs_oracle(ctx, frames, track_slots, scale_slots, kf_every, waves, ma
         np.testing.assert_allclose(np.array(r.pose), pose, rtol=0, atol=tol * max(1.0, np.abs(pose[4:]).max()), err_msg=f"frame {i}")
         np.testing.assert_allclose(np.array(r.aff), aff, rtol=10 * tol, atol=10 * tol, err_msg=f"frame {i}")
         if same:
-            np.testing.assert_allclose(np.array(r.last_residuals)[:nl], last[:nl], rtol=1e-4, err_msg=f"frame {i}")
+            # last_residuals[l] = sqrt(E / n) of the level's last accepted evaluation; the oracle's E is the reference's SEQUENTIAL float
+            # sum (quirk Q1), good to n * 2^-24 relative in the worst case (half of that on the square root): 1e-4 on the small
+            # levels, the rounding bound where it is larger (472 720 terms at level 0)
+            n_l = np.array([len(frames[i].tpl[0][l]) for l in range(nl)], np.float64)
+            assert np.all(np.abs(np.array(r.last_residuals)[:nl] - last[:nl]) <= (1e-4 + 0.25 * n_l * 2.0 ** -24) * last[:nl]), (i, r.last_residuals, last)
         assert np.all(np.isnan(np.array(r.last_residuals)[nl:]))
         # both paths end at the ground truth (relief scenes: the reference algorithm converges from the identity guess)
         np.testing.assert_allclose(np.array(r.pose)[4:], frames[i].gt_pose[4:], atol=5e-3)
