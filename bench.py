@@ -119,7 +119,6 @@ def _parse():
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--compact", type=int, default=None, help="dsm_params.compact_tail (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
-    ap.add_argument("--tile", type=int, default=None, help="dsm_params.tile_l0 (default: library default): 1 = tile-ordered level-0 template, warped window staged in LDS")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="upper bound of the frames timed on the CPU baseline (rank 0, N=1); the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the single-core CPU baseline leg once --cpu-min-frames are done")
@@ -345,8 +344,6 @@ def build_workload(args, ctx, config):
         params.speculate = args.speculate
     if args.compact is not None:
         params.compact_tail = args.compact
-    if args.tile is not None:
-        params.tile_l0 = args.tile
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0

@@ -376,6 +376,8 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
     if (params->struct_size != sizeof(dsm_params))
       return invalid("dsm_params.struct_size does not match this library's dsm_params: the caller was built against another "
                      "version of dsm_hotpath.h (use dsm_params_default, compare dsm_abi_version() with DSM_ABI_VERSION)");
+    if (params->tile_l0 != 0)
+      return invalid("dsm_params.tile_l0 is reserved and must be 0 (round 4's tile form of the level-0 evaluation was removed: include/dsm_hotpath.h)");
     t->params = *params;
   } else {
     dsm_params_default(&t->params);
@@ -399,7 +401,8 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
     const int wl = w >> l, hl = h >> l;
     D.lv[l].w = wl;
     D.lv[l].h = hl;
-    DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)wl * hl));
+    DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * ((size_t)wl * hl + kTemplatePad)));
+    DSM_HIP(hipMemset(t->d_pts[l], 0, sizeof(float4) * ((size_t)wl * hl + kTemplatePad)));
     t->pts_cap[l] = wl * hl;
     for (int s = 0; s < 2; s++) {
       DSM_HIP(hipMalloc(&t->d_img[s][l], plane_bytes(wl, hl)));
@@ -433,11 +436,6 @@ int dsm_tracker_destroy(dsm_tracker *t) {
   if (t->ctx->copy_stream) hipStreamSynchronize(t->ctx->copy_stream);
   for (int l = 0; l < t->nlevels; l++) {
     hipFree(t->d_pts[l]);
-    if (l == 0) {
-      hipFree(t->d_pts_tile);
-      hipFree(t->d_tile_range);
-      t->d_pts_tile = nullptr, t->d_tile_range = nullptr;
-    }
     hipFree(t->d_img[0][l]);
     hipFree(t->d_img[1][l]);
   }
@@ -474,29 +472,6 @@ int dsm_tracker_make_k(dsm_tracker *t, float fx, float fy, float cx, float cy) {
   return DSM_OK;
 }
 
-// tile-ordered copy of the (dense, row-major) level-0 template resident in t->d_pts[0], and its per-tile inverse-depth ranges
-static int build_tile_copy(dsm_tracker *t) {
-  dsm_context *ctx = t->ctx;
-  const int tiles_x = (t->w - 4 + kTileEdge - 1) / kTileEdge, tiles_y = (t->h - 4 + kTileEdge - 1) / kTileEdge, tiles = tiles_x * tiles_y;
-  if (!t->d_pts_tile || t->tiles != tiles) {
-    if (t->d_pts_tile) DSM_HIP(hipFree(t->d_pts_tile));
-    if (t->d_tile_range) DSM_HIP(hipFree(t->d_tile_range));
-    t->d_pts_tile = nullptr, t->d_tile_range = nullptr;
-    DSM_HIP(hipMalloc(&t->d_pts_tile, sizeof(float4) * (size_t)tiles * kTileEdge * kTileEdge));
-    DSM_HIP(hipMalloc(&t->d_tile_range, sizeof(float2) * (size_t)tiles));
-    t->tiles = tiles, t->tiles_x = tiles_x;
-  }
-  launch_tile_order(ctx->stream, t->w, t->h, tiles_x, tiles, t->d_pts[0], t->d_pts_tile, t->d_tile_range);
-  DSM_HIP(hipGetLastError());
-  DSM_HIP(hipStreamSynchronize(ctx->stream));
-  t->desc.lv[0].pts_tile = t->d_pts_tile;
-  t->desc.lv[0].tile_range = t->d_tile_range;
-  t->desc.lv[0].n_tile = tiles * kTileEdge * kTileEdge;
-  t->desc.lv[0].tiles_x = tiles_x;
-  t->desc_dirty = true;
-  return DSM_OK;
-}
-
 int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, double ref_aff_b,
                         float ref_exposure, const int *n, const float *const *pc_u,
                         const float *const *pc_v, const float *const *pc_idepth,
@@ -527,17 +502,6 @@ int dsm_tracker_set_ref(dsm_tracker *t, int ref_frame_id, double ref_aff_a, doub
   t->ref_frame_id = ref_frame_id;
   t->have_ref = true;
   t->desc_dirty = true;
-  // dsm_params.tile_l0: a dense level-0 template (every interior pixel, row-major -- checked, not assumed) gets its tile-ordered copy
-  t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr;
-  if (t->params.tile_l0 && n[0] == (t->w - 4) * (t->h - 4) && n[0] > 0) {
-    bool dense = true;
-    const int wi = t->w - 4;
-    for (int i = 0; i < n[0] && dense; i++) dense = pc_u[0][i] == (float)(2 + i % wi) && pc_v[0][i] == (float)(2 + i / wi);
-    if (dense) {
-      rc = build_tile_copy(t);
-      if (rc) return rc;
-    }
-  }
   return DSM_OK;
 }
 
@@ -596,7 +560,6 @@ int dsm_set_refs_from_points(dsm_context *ctx, int n_jobs, const dsm_ref_job *jo
     const int *hn = h_n.data() + (size_t)j * (DSM_MAX_LEVELS + 1);
     for (int l = 0; l < t->nlevels; l++) {
       t->desc.lv[l].n = hn[l];
-      if (l == 0) t->desc.lv[0].tiles_x = 0, t->desc.lv[0].n_tile = 0, t->desc.lv[0].pts_tile = nullptr, t->desc.lv[0].tile_range = nullptr; // a semi-dense template has no tile form
       if (J.n_out) J.n_out[l] = hn[l];
     }
     t->desc.ref_a = J.ref_aff_a; // :323-324
@@ -628,7 +591,6 @@ int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {
   DSM_HIP(hipSetDevice(t->ctx->device));
   for (int l = 0; l < t->nlevels; l++) launch_scale_depth(t->ctx->stream, t->desc.lv[l].n, t->d_pts[l], scale);
   DSM_HIP(hipStreamSynchronize(t->ctx->stream));
-  if (t->desc.lv[0].tiles_x > 0) return build_tile_copy(t); // the copy and its depth ranges follow the scaled template
   return DSM_OK;
 }
 
@@ -1001,8 +963,7 @@ static int prepare_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mo
       return invalid("batch: all trackers must share image size and levels");
     int rc = check_ready(t, i < n ? mode : mode2);
     if (rc) return rc;
-    const int tile_chunks = ((t->w - 4 + kTileEdge - 1) / kTileEdge) * ((t->h - 4 + kTileEdge - 1) / kTileEdge) * kTileEdge * kTileEdge / (kThreads * 16);
-    const int need = 2 * std::max(max_chunks_upto(t->w * t->h), tile_chunks) * kPartialStride; // second half: the speculative candidate's partials
+    const int need = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
     if (need > ps) ps = need;
   }
   int rc = ensure_batch_capacity(ctx, n + n2, ps);
@@ -1655,7 +1616,8 @@ int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const
   for (int l = 1; l < nlevels; l++) {
     hipFree(t->d_pts[l]);
     t->d_pts[l] = nullptr;
-    const hipError_t e = hipMalloc(&t->d_pts[l], sizeof(float4) * (size_t)w * h);
+    hipError_t e = hipMalloc(&t->d_pts[l], sizeof(float4) * ((size_t)w * h + kTemplatePad));
+    if (e == hipSuccess) e = hipMemset(t->d_pts[l], 0, sizeof(float4) * ((size_t)w * h + kTemplatePad));
     if (e != hipSuccess) {
       dsm_tracker_destroy(t);
       DSM_HIP(e);

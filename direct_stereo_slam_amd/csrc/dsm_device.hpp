@@ -33,12 +33,6 @@ struct LevelDev {
   float fx, fy, cx, cy;     // camera 0 (makeK, TrackerAndScaler.cpp:117-133)
   float Ki[9];              // inverse of K at this level (float, :135-140)
   float fx1, fy1, cx1, cy1; // camera 1 (:89-98)
-  // dsm_params.tile_l0, level 0 of a DENSE template only: a second copy of the template in TILE order -- chunk c = the 64 x 64
-  // pixel tile c of the keyframe image, padded to 4096 entries (padding: inverse depth 0, never usable) -- and the inverse-depth
-  // range of every tile (the warped tile's bounding box follows from its eight corners); tiles_x = tiles per row, 0 = none
-  const float4 *pts_tile;
-  const float2 *tile_range;
-  int n_tile, tiles_x;
 };
 
 struct ParamsDev {
@@ -82,12 +76,6 @@ struct EvalIn {
   float scale;  // scale only
   float cutoff; // setting_coarseCutoffTH * levelCutoffRepeat
   float max_energy; // :726-728
-  // tile form of the level-0 evaluation (LevelDev::pts_tile): pts / n above are then the TILE-ordered copy; the flow indicators
-  // (every 32nd template index, :754) still walk the original order
-  const float4 *pts_flow;
-  const float2 *tile_range;
-  int n_flow, tiles_x; // tiles_x = 0: no tile form
-  int pad_tile[2];
 };
 
 enum LMPhase { PH_INIT = 0, PH_ITER = 1 };

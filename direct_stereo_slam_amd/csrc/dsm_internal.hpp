@@ -92,9 +92,6 @@ struct dsm_tracker {
   dsm::TrackerDev desc{}; // host copy of the device descriptor
   dsm::TrackerDev *d_desc = nullptr;
   float4 *d_pts[DSM_MAX_LEVELS] = {};
-  float4 *d_pts_tile = nullptr; // dsm_params.tile_l0: tile-ordered copy of the level-0 template (allocated on first use)
-  float2 *d_tile_range = nullptr;
-  int tiles_x = 0, tiles = 0;
   int pts_cap[DSM_MAX_LEVELS] = {}; // template capacity per level (w_l*h_l; w*h on every level for the pose estimator)
   float *d_img[2][DSM_MAX_LEVELS] = {};
   float *d_raw[2] = {nullptr, nullptr}; // raw level-0 images of dsm_tracker_upload_image, per slot

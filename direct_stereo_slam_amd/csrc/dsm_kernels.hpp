@@ -139,15 +139,11 @@ void launch_interleave_template(hipStream_t s, int n, const float *u, const floa
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
                                   float *c);
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
-// dsm_params.tile_l0: tile-ordered copy (tiles x 4096 entries) of a dense, row-major level-0 template of a w x h keyframe, and the
-// inverse-depth range of every tile
-constexpr int kTileEdge = 64;
-void launch_tile_order(hipStream_t s, int w, int h, int tiles_x, int tiles, const float4 *src, float4 *dst, float2 *range);
-// chunks of an evaluation of level L of a tracker: of the tile-ordered copy where the level has one (the larger count serves both)
-inline int level_chunks(const TrackerDev &d, int L) {
-  const int a = num_chunks(d.lv[L].n), b = d.lv[L].tiles_x > 0 ? num_chunks(d.lv[L].n_tile) : 0;
-  return a > b ? a : b;
-}
+// Template lists are allocated with this many entries of slack (zeroed): the evaluation loop prefetches template entries up to
+// three trips (3 x 256 points) past the end of a chunk without clamping the index; what it reads there is never used (masked)
+constexpr int kTemplatePad = 1024;
+// chunks of an evaluation of level L of a tracker
+inline int level_chunks(const TrackerDev &d, int L) { return num_chunks(d.lv[L].n); }
 // makeImages (upstream DSO): the intensity plane of level 0 from the float image, of level l from level l-1
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img);
 // the reference's (I, dx, dy) texels out of / into an intensity plane; with d_bad != nullptr import counts the texels whose

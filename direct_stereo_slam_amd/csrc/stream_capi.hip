@@ -194,8 +194,7 @@ static int stream_bind_geometry(dsm_stream *s, dsm_tracker *t) {
   }
   DSM_HIP(hipSetDevice(s->ctx->device));
   s->w = t->w, s->h = t->h, s->nlevels = t->nlevels;
-  const int tile_chunks = ((t->w - 4 + kTileEdge - 1) / kTileEdge) * ((t->h - 4 + kTileEdge - 1) / kTileEdge) * kTileEdge * kTileEdge / (kThreads * 16);
-  const int ps = 2 * std::max(max_chunks_upto(t->w * t->h), tile_chunks) * kPartialStride; // second half: the speculative candidate's partials
+  const int ps = 2 * max_chunks_upto(t->w * t->h) * kPartialStride; // second half: the speculative candidate's partials
   int rc = alloc_dev(&s->d_partials, (size_t)s->N * ps);
   if (rc) return rc;
   s->partial_stride = ps;
@@ -699,8 +698,7 @@ static int tick_setup(dsm_stream *s) {
   if (!rc) rc = alloc_dev(&s->d_admit_idx, N);
   if (rc) return rc;
   // an item list holds at most one evaluation (+ its speculative twin) per slot of the segment
-  const int tile_chunks = ((s->w - 4 + kTileEdge - 1) / kTileEdge) * ((s->h - 4 + kTileEdge - 1) / kTileEdge) * kTileEdge * kTileEdge / (kThreads * 16);
-  const int maxpos = 8 * ((std::max(max_chunks_upto(s->w * s->h), tile_chunks) + 7) / 8);
+  const int maxpos = 8 * ((max_chunks_upto(s->w * s->h) + 7) / 8);
   if (maxpos >= (1 << kTickChunkBits)) return invalid("dsm_stream (tick engine): a level has too many chunks for the item encoding");
   if (N >= (1 << (30 - kTickChunkBits))) return invalid("dsm_stream (tick engine): too many slots for the item encoding");
   s->d_items.assign(2 * nseg, nullptr);

@@ -19,10 +19,6 @@
 #include "lm_math.hpp"
 #include "xwg_sync.hpp"
 
-#ifndef DSM_TILE_PACKED
-#define DSM_TILE_PACKED 1 // tile form of the level-0 evaluation: packed FP32 in the warp stage and the Gram update (0: scalar, same bits)
-#endif
-
 
 namespace dsm {
 
@@ -163,13 +159,8 @@ __device__ __forceinline__ void taps_gradients(const Taps &T, float w00, float w
   const float d01 = fix(T.r2[2] - T.r2[0]), d11 = fix(T.r2[3] - T.r2[1]);
   const float e00 = fix(T.r2[1] - T.r0[0]), e10 = fix(T.r2[2] - T.r0[1]);
   const float e01 = fix(T.r3[0] - T.r1[1]), e11 = fix(T.r3[1] - T.r1[2]);
-#ifdef DSM_REF_POINT_OPS // A/B build (tools/experiments/lm_flip_attribution.py): getInterpolatedElement33's own association, unfused
-  g1 = ((w11 * d11 + w01 * d01) + w10 * d10) + w00 * d00;
-  g2 = ((w11 * e11 + w01 * e01) + w10 * e10) + w00 * e00;
-#else
   g1 = __builtin_fmaf(w00, d00, __builtin_fmaf(w10, d10, __builtin_fmaf(w01, d01, w11 * d11)));
   g2 = __builtin_fmaf(w00, e00, __builtin_fmaf(w10, e10, __builtin_fmaf(w01, e01, w11 * e11)));
-#endif
 }
 template <bool EXACT, bool GRAD = true>
 __device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1, float &g2) {
@@ -182,14 +173,6 @@ __device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1,
   else
     g1 = g2 = 0.f;
 }
-
-// Packed FP32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE single operations per lane and issue slot, each half rounded
-// exactly as the scalar instruction rounds it).  Used by the tile form of the level-0 evaluation, whose loop -- its taps coming from
-// LDS -- is bound by vector issue: rows 0 and 1 of the warp, the two quotients, Ku / Kv and the 45 entries of the Gram update two
-// rows at a time are issued as pairs: same operations, same operands, same order per element, hence the same bits as the scalar form.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat2(float a) { return f2{a, a}; }
 
 // per-point state carried from the warp stage to the consume stage
 struct Warped {
@@ -214,20 +197,8 @@ struct EvalConsts {
   float aff0, aff1, b0, scale, cutoff, max_energy;
   int residual_only; // EvalIn::residual_only
   unsigned lds_img, lds_pts; // coarse_kernel: LDS byte addresses of the staged intensity plane / template (else unused)
-  // tile form (dsm_params.tile_l0): see EvalIn; tap_pitch / safe_*: the staged window (eval_chunk_tile)
-  const float4 *pts_flow;
-  const float2 *tile_range;
-  int n_flow, tiles_x;
-  int tap_pitch;        // floats per row of the LDS-staged plane / window (0: the level's width)
-  float safe_x, safe_y; // where unusable lanes fetch their taps (always inside the plane / window)
-  int win_x0, win_y0, win_x1, win_y1; // tile form: texel range the staged window holds (taps outside it are gathered from HBM)
 };
-__device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) {
-  c.lds_img = c.lds_pts = 0;
-  c.tap_pitch = 0;
-  c.safe_x = c.safe_y = 2.5f;
-  c.win_x0 = c.win_y0 = 0, c.win_x1 = c.win_y1 = 0x7FFFFFFF;
-}
+__device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img = c.lds_pts = 0; }
 
 // One chunk of one evaluation by 256 threads (tid = 0..255 inside the chunk's thread group):
 // the per-point loop, the flow-indicator pass and the fixed-order reduction into the chunk's 52-slot
@@ -245,7 +216,7 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) {
 // its first wave's loop and the partial store).
 // DEEP: the two-points-per-trip loop with fixed register roles (level 0 always; the tick engine's kernel, which runs at four
 // waves per SIMD whatever the level, also uses it on the other large levels)
-template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0, bool TILE = false>
+template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                                 float *out, int *arrive = nullptr) {
   const int n = c.n;
@@ -254,11 +225,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   float acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; a++) acc[a] = 0.f;
-  constexpr bool PKS = TILE && DSM_TILE_PACKED != 0, PKA = PKS && MODE != 1 && !RO; // packed warp stage / packed Gram update
-  f2 accp[20]; // the accumulator in its packed arrangement (stage_b); unpacked into acc[] after the loop
-  float accs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 20; a++) accp[a] = f2{0.f, 0.f};
   float E = 0.f;
   int n_terms = 0, n_sat = 0, n_warped = 0;
   float fT = 0.f, fRT = 0.f, fNum = 0.f;
@@ -272,14 +238,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     const float hfx = 0.5f * fxl, hfy = 0.5f * fyl; // the central differences' 0.5 (see taps_interp)
     const int wl = c.w, hl = c.h;
     const float wm3 = (float)(wl - 3), hm3 = (float)(hl - 3);
-    const int pitch = LDSIMG && c.tap_pitch ? c.tap_pitch : wl; // floats per row of what the taps are fetched from
-    const float safe_x = c.safe_x, safe_y = c.safe_y;
+    const int pitch = wl; // floats per row of what the taps are fetched from
     typename TapSel<LDSIMG>::type img;
     if constexpr (LDSIMG)
       img = tap_bases_lds(c.lds_img, pitch);
     else
       img = tap_bases((const DSM_GLOBAL float *)c.img, wl);
-    const TapBases img_g = tap_bases((const DSM_GLOBAL float *)c.img, wl); // TILE: the plane in HBM, for taps outside the window
+    const TapBases img_g = tap_bases((const DSM_GLOBAL float *)c.img, wl); // the plane in HBM (the rare non-finite-gradient path re-fetches from it)
     const DSM_GLOBAL fvec4 *pts = (const DSM_GLOBAL fvec4 *)c.pts;
     // scale mode: (scale * M) is formed once per evaluation, as `scale * rot_f1_f0_K0_i` is (:1061)
     const float sc = c.scale;
@@ -296,11 +261,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     auto stage_a = [&](const fvec4 &p, bool in_list, Warped &W, Taps &T) {
       const float x = p.x, y = p.y, id = p.z;
       float pt0, pt1, pt2;
-      if constexpr (PKS && MODE == 0) { // rows 0 and 1 of the warp as one packed chain (:747)
-        const f2 pt01 = ((f2{M0, M3} * splat2(x) + f2{M1, M4} * splat2(y)) + f2{M2, M5}) + f2{t0, t1} * splat2(id);
-        pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
-        pt0 = pt01.x, pt1 = pt01.y;
-      } else if (MODE == 0) { // :747
+      if (MODE == 0) { // :747
         pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
         pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
         pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
@@ -330,60 +291,23 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         } else {
           const float r0 = __builtin_amdgcn_rcpf(pt2);
           const float r1 = __builtin_fmaf(__builtin_fmaf(-pt2, r0, 1.0f), r0, r0);
-          if constexpr (PKS) {
-            const f2 a = f2{pt0, pt1}, R1 = splat2(r1), NP = splat2(-pt2);
-            const f2 q0 = a * R1;
-            const f2 q1 = pk_fma(pk_fma(NP, q0, a), R1, q0);
-            const f2 q2 = pk_fma(pk_fma(NP, q1, a), R1, q1);
-            W.u = q2.x, W.v = q2.y;
-          } else {
-            auto quot = [pt2, r1](float a) {
-              const float q0 = a * r1;
-              const float q1 = __builtin_fmaf(__builtin_fmaf(-pt2, q0, a), r1, q0);
-              return __builtin_fmaf(__builtin_fmaf(-pt2, q1, a), r1, q1);
-            };
-            W.u = quot(pt0);
-            W.v = quot(pt1);
-          }
-#ifdef DSM_REF_POINT_OPS
-          W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2;
-#else
+          auto quot = [pt2, r1](float a) {
+            const float q0 = a * r1;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-pt2, q0, a), r1, q0);
+            return __builtin_fmaf(__builtin_fmaf(-pt2, q1, a), r1, q1);
+          };
+          W.u = quot(pt0);
+          W.v = quot(pt1);
           W.new_idepth = MODE == 2 ? r1 : id * r1;
-#endif
         }
       }
-      float Ku, Kv;
-      if constexpr (PKS) {
-        const f2 Kuv = f2{fxl, fyl} * f2{W.u, W.v} + f2{cxl, cyl};
-        Ku = Kuv.x, Kv = Kuv.y;
-      } else {
-        Ku = fxl * W.u + cxl;
-        Kv = fyl * W.v + cyl;
-      }
+      const float Ku = fxl * W.u + cxl, Kv = fyl * W.v + cyl;
       W.refColor = p.w;
       W.x = x, W.y = y, W.id = id;
       W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-      bool from_window = W.inb;
-      if (TILE) { // a usable point whose taps leave the staged window (the box has a margin: rare) gathers them from HBM below
-        const int ix = (int)Ku, iy = (int)Kv;
-        from_window = W.inb && ix - 1 >= c.win_x0 && ix + 2 <= c.win_x1 && iy - 1 >= c.win_y0 && iy + 2 <= c.win_y1;
-      }
-      taps_load<!RO>(img, from_window ? Ku : safe_x, from_window ? Kv : safe_y, pitch, T);
-      if (TILE && __builtin_expect(__builtin_amdgcn_ballot_w64(W.inb && !from_window) != 0ull, 0)) {
-        Taps Tg;
-        taps_load<!RO>(img_g, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, wl, Tg);
-        if (W.inb && !from_window) T = Tg;
-      }
+      taps_load<!RO>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, pitch, T); // (unusable lanes fetch around texel (2, 2))
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
-#ifdef DSM_EXP_PAD // EXPERIMENT (not committed): N extra vector instructions per point -- does the loop's time follow the instruction count?
-      {
-        float dummy = W.u;
-#pragma unroll
-        for (int q = 0; q < DSM_EXP_PAD; q++) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(dummy) : "v"(W.v));
-        asm volatile("" ::"v"(dummy));
-      }
-#endif
       float h0, g1, g2;
       taps_interp<false, !RO>(T, h0, g1, g2);
       // makeImages' "non-finite gradient -> 0", the rare path: the taps are fetched again (so that the common path
@@ -401,11 +325,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       // scales this point's terms of E and of the normal equations -- sums that are compared to tolerance, E then
       // entering the LM accept test like any other rounding of the sum -- so the hardware reciprocal (1 ulp)
       // replaces the IEEE division.
-#if defined(DSM_REF_POINT_OPS) || defined(DSM_IEEE_HUBER)
-      const float hw = ar < huber ? 1.0f : huber / ar; // the reference's IEEE division (:794-795)
-#else
       const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
-#endif
       const bool sat = ar > cutoff;                    // :797
       const bool use = fin && !sat;
       const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
@@ -427,51 +347,22 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         float J[9];
         J[0] = nid * dx;
         J[1] = nid * dy;
-#ifdef DSM_REF_POINT_OPS // calcGSSSEPose's unfused SSE sequence (:664-677)
-        J[2] = 0.0f - nid * (u * dx + v * dy);
-        J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
-        J[4] = (u * v) * dy + dx * (1.0f + u * u);
-        J[5] = u * dy - v * dx;
-#else
         J[2] = -(nid * __builtin_fmaf(u, dx, v * dy));
         J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
         J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
         J[5] = __builtin_fmaf(u, dy, -(v * dx));
-#endif
         J[6] = keep(aff0 * (b0 - refColor));
         J[7] = -1.0f;
         J[8] = keep(residual);
-        if constexpr (PKA) {
-          // Accumulator9::updateSSE_eighted, H(r,c) += (J_r w) J_c, two rows per instruction: accp holds (H(2k,c), H(2k+1,c)) for
-          // c > 2k, accs the diagonal entries H(2k,2k) and H(8,8): 20 packed + 5 scalar FMAs for the 45 entries
-          const f2 W2 = splat2(wgt);
-          const f2 PW[4] = {f2{J[0], J[1]} * W2, f2{J[2], J[3]} * W2, f2{J[4], J[5]} * W2, f2{J[6], J[7]} * W2};
-          int pi = 0;
-  #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            accs[k] = __builtin_fmaf(PW[k].x, J[2 * k], accs[k]);
-  #pragma unroll
-            for (int c = 2 * k + 1; c < 9; c++) {
-              accp[pi] = pk_fma(PW[k], splat2(J[c]), accp[pi]);
-              pi++;
-            }
-          }
-          accs[4] = __builtin_fmaf(J[8] * wgt, J[8], accs[4]);
-        } else {
         int idx = 0;
   #pragma unroll
         for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
           const float Jw = J[r] * wgt;
   #pragma unroll
           for (int c = r; c < 9; c++) {
-#ifdef DSM_REF_POINT_OPS // Accumulator9::updateSSE_eighted: _mm_add_ps(acc, _mm_mul_ps(Jw, J)), unfused
-            acc[idx] = acc[idx] + Jw * J[c];
-#else
             acc[idx] = __builtin_fmaf(Jw, J[c], acc[idx]);
-#endif
             idx++;
           }
-        }
         }
       } else {
         // calcResScale :1068 and calcGSSSEScale :983-999
@@ -559,8 +450,8 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     // handles the 8*P such points of this chunk in a single pass.
     if (LVL0 && tid < 8 * P) {
       const int i = chunk_start + 32 * tid;
-      if (i < c.n_flow) {
-        const fvec4 p = ((const DSM_GLOBAL fvec4 *)c.pts_flow)[i];
+      if (i < n) {
+        const fvec4 p = pts[i];
         const float x = p.x, y = p.y, id = p.z;
         const float *Ki = c.Ki;
         if (MODE == 2) {
@@ -617,21 +508,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 
   } // active
-  if constexpr (PKA) { // back to the row-major upper triangle (register renaming)
-    auto at = [](int r, int c) { return r * 9 - r * (r - 1) / 2 + (c - r); };
-    int pi = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      acc[at(2 * k, 2 * k)] = accs[k];
-#pragma unroll
-      for (int c = 2 * k + 1; c < 9; c++) {
-        acc[at(2 * k, c)] = accp[pi].x;
-        acc[at(2 * k + 1, c)] = accp[pi].y;
-        pi++;
-      }
-    }
-    acc[at(8, 8)] = accs[4];
-  }
   // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
   const int lane = tid & 63, wave = tid >> 6;
   const int row = wave * 4 + (lane >> 4);
@@ -683,71 +559,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   }
 }
 
-// ---- tile form of the level-0 pose evaluation (dsm_params.tile_l0) -----------------------------------------------------
-// The chunk is the 64 x 64 pixel tile `chunk` of the keyframe (template in tile order, LevelDev::pts_tile).  The warp
-// pt = M (x, y, 1) + t id is linear-fractional in (x, y, id), so the image of the tile -- a box in (x, y, id) with the tile's
-// inverse-depth range -- lies inside the bounding box of its EIGHT corners' images: the workgroup copies that window of the
-// target plane (a margin around it, 16-byte aligned columns) into LDS with coalesced loads and the per-point loop takes its
-// twelve intensities from there -- the values the gathers would have fetched, so every per-point result is unchanged -- instead
-// of gathering them from HBM through the L1 / L2 latencies.  A window that does not fit, a plane whose rows are not 16-byte
-// multiples, or a tile behind the camera falls back to the gathers (workgroup-uniform); a usable point whose taps leave the
-// window after all (the margin makes that rare) gathers them (eval_chunk_impl<..., TILE>).
-constexpr int kWinPitch = 96, kWinRows = 80; // floats per row / rows of the LDS window: 30 KB
-constexpr int kTile = 64;
-
-template <int MODE>
-__device__ __forceinline__ bool eval_chunk_tile(const EvalConsts &c, int chunk, int tid, float (*red)[kNumSlots], float *out, int *arrive,
-                                                float *win) {
-  const int wl = c.w, hl = c.h;
-  if ((wl & 3) != 0) return false;
-  const int tx = chunk % c.tiles_x, ty = chunk / c.tiles_x;
-  const float x0 = (float)(2 + kTile * tx), y0 = (float)(2 + kTile * ty);
-  const float x1 = fminf(x0 + (kTile - 1), (float)(wl - 3)), y1 = fminf(y0 + (kTile - 1), (float)(hl - 3));
-  const fvec2u rgv = ((const DSM_GLOBAL fvec2u *)c.tile_range)[chunk]; // (min, max) inverse depth of the tile's points
-  struct { float x, y; } rg = {rgv.x, rgv.y};
-  if (!(rg.x <= rg.y)) return false; // no usable point in the tile: the plain path masks everything
-  float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
-  bool front = true;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const float x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0, id = (k & 4) ? rg.y : rg.x;
-    const float p0 = ((c.M[0] * x + c.M[1] * y) + c.M[2]) + c.t[0] * id;
-    const float p1 = ((c.M[3] * x + c.M[4] * y) + c.M[5]) + c.t[1] * id;
-    const float p2 = ((c.M[6] * x + c.M[7] * y) + c.M[8]) + c.t[2] * id;
-    front = front && p2 > 1e-6f;
-    const float Ku = c.fx * (p0 / p2) + c.cx, Kv = c.fy * (p1 / p2) + c.cy;
-    umin = fminf(umin, Ku), umax = fmaxf(umax, Ku), vmin = fminf(vmin, Kv), vmax = fmaxf(vmax, Kv);
-  }
-  if (!front || !(umax - umin < 4096.f) || !(vmax - vmin < 4096.f)) return false; // (a corner behind the camera: the image of the box is not bounded by its corners)
-  // texel range the taps of usable points can touch: ix in [2, w - 4], iy in [2, h - 4] (:786); one texel of margin around the box
-  int bx0 = (int)floorf(umin) - 1, bx1 = (int)floorf(umax) + 1, by0 = (int)floorf(vmin) - 1, by1 = (int)floorf(vmax) + 1;
-  bx0 = bx0 < 2 ? 2 : bx0, by0 = by0 < 2 ? 2 : by0;
-  bx1 = bx1 > wl - 4 ? wl - 4 : bx1, by1 = by1 > hl - 4 ? hl - 4 : by1;
-  if (bx0 > bx1 || by0 > by1) return false; // the whole tile lands outside the image
-  const int wx0 = (bx0 - 1) & ~3, wy0 = by0 - 1;
-  const int cols = bx1 + 2 - wx0 + 1, rows = by1 + 2 - wy0 + 1;
-  if (cols > kWinPitch || rows > kWinRows) return false;
-  // the window, rows of kWinPitch floats, 16-byte loads (reading past the needed columns stays inside the plane's allocation)
-  {
-    const DSM_GLOBAL fvec4 *src = (const DSM_GLOBAL fvec4 *)((const DSM_GLOBAL float *)c.img + (size_t)wy0 * wl + wx0);
-    constexpr int q_per_row = kWinPitch / 4;
-    const int q_used = (cols + 3) >> 2; // 16-byte pieces of a row that hold needed texels
-    for (int i = tid; i < rows * q_used; i += kThreads) {
-      const int r = i / q_used, q = i - r * q_used;
-      ((fvec4 *)win)[r * q_per_row + q] = src[(size_t)r * (wl >> 2) + q];
-    }
-  }
-  __syncthreads();
-  EvalConsts ct = c;
-  ct.tap_pitch = kWinPitch;
-  // address of texel (x, y) = lds_img + 4 (x + y pitch)  ->  lds_img = window base - 4 (wx0 + wy0 pitch)   (unsigned wrap-around is fine)
-  ct.lds_img = (unsigned)(unsigned long long)(DSM_LDS float *)win - 4u * (unsigned)(wx0 + wy0 * kWinPitch);
-  ct.safe_x = (float)(wx0 + 2) + 0.5f, ct.safe_y = (float)(wy0 + 2) + 0.5f;
-  ct.win_x0 = wx0, ct.win_y0 = wy0, ct.win_x1 = wx0 + cols - 1, ct.win_y1 = wy0 + rows - 1;
-  eval_chunk_impl<MODE, true, false, true, false, true, true>(ct, chunk, tid, true, red, out, arrive);
-  return true;
-}
-
 template <int MODE, bool LVL0, bool DEEP = LVL0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                            float *out, int *arrive = nullptr) {
@@ -755,14 +566,6 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
     eval_chunk_impl<MODE, LVL0, true, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
   else
     eval_chunk_impl<MODE, LVL0, false, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
-}
-
-// level-0 pose evaluation of a kernel that carries the LDS window: the tile form where the evaluation has one (workgroup-uniform)
-template <int MODE>
-__device__ __forceinline__ void eval_chunk_win(const EvalConsts &c, int chunk, int tid, float (*red)[kNumSlots], float *out, int *arrive,
-                                               float *win) {
-  if (!c.residual_only && c.tiles_x > 0 && eval_chunk_tile<MODE>(c, chunk, tid, red, out, arrive, win)) return;
-  eval_chunk<MODE, true>(c, chunk, tid, true, red, out, arrive);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -794,11 +597,6 @@ __device__ __forceinline__ void make_eval_pose(const TrackerDev &T, EvalIn &e, i
     e.pts = L.pts;
     e.img = L.img[0]; // new left frame (:709)
     e.n = L.n;
-    e.pts_flow = L.pts, e.n_flow = L.n, e.tile_range = nullptr, e.tiles_x = 0;
-    if (lvl == 0 && L.tiles_x > 0) { // dsm_params.tile_l0: the pose evaluation walks the tile-ordered copy
-      e.pts = L.pts_tile, e.n = L.n_tile;
-      e.tile_range = L.tile_range, e.tiles_x = L.tiles_x;
-    }
     e.w = L.w;
     e.h = L.h;
     e.fx = L.fx;
@@ -841,7 +639,6 @@ __device__ __forceinline__ void make_eval_scale(const TrackerDev &T, EvalIn &e, 
     e.pts = L.pts;
     e.img = L.img[1]; // right frame fh1_ (:1016)
     e.n = L.n;
-    e.pts_flow = L.pts, e.n_flow = L.n, e.tile_range = nullptr, e.tiles_x = 0;
     e.w = L.w;
     e.h = L.h;
     e.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
@@ -888,7 +685,6 @@ __device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &
   e.pts = L.pts;
   e.img = L.img[0];
   e.n = L.n;
-  e.pts_flow = L.pts, e.n_flow = L.n, e.tile_range = nullptr, e.tiles_x = 0;
   e.w = L.w;
   e.h = L.h;
   e.fx = L.fx;
@@ -1661,7 +1457,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
   c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
   c.residual_only = in.residual_only;
-  c.pts_flow = in.pts_flow, c.tile_range = in.tile_range, c.n_flow = in.n_flow, c.tiles_x = in.tiles_x;
   eval_consts_defaults(c);
   asm volatile("" ::"s"(s_status), "s"(s_lvl), "s"(s_kind), "s"(s_spec_valid), "s"(c.pts), "s"(c.img), "s"(c.n), "s"(c.w), "s"(c.h),
                "s"(c.residual_only));
@@ -1692,14 +1487,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   const int spec_off = partial_stride >> 1; // the speculative candidate's partials: second half of the problem's block
   if (chunk < nchunks && have_eval) {
     __shared__ float red[16][kNumSlots];
-    constexpr bool kTileCapable = LVL0 && MODE == 0 && ROSEL != 2 && !FUSED; // the instantiations that may run the tile form
-    __shared__ __attribute__((aligned(16))) float win[kTileCapable ? kWinRows * kWinPitch : 4];
     int *const arr = FUSED ? nullptr : &arrive;
     float *const out = partials_prob + (cand ? spec_off : 0) + (size_t)chunk * kPartialStride;
     if (ROSEL == 2)
       eval_chunk_impl<MODE, LVL0, true>(c, chunk, threadIdx.x, true, red, out, arr);
-    else if constexpr (kTileCapable)
-      eval_chunk_win<MODE>(c, chunk, threadIdx.x, red, out, arr, win); // (ROSEL == 1: every evaluation of the launch is a full one)
     else
       eval_chunk<MODE, LVL0>(c, chunk, threadIdx.x, true, red, out, arr);
     if (FUSED && threadIdx.x < 64) xwg_release(); // wave 0 stored the partial: performed at device scope before the ticket
@@ -1941,15 +1732,6 @@ __device__ __forceinline__ void eval_consts_from_lds(const EvalIn &in, EvalConst
   c.aff0 = rf(in.aff0), c.aff1 = rf(in.aff1), c.b0 = rf(in.b0), c.scale = rf(in.scale);
   c.cutoff = rf(in.cutoff), c.max_energy = rf(in.max_energy);
   c.residual_only = __builtin_amdgcn_readfirstlane(in.residual_only);
-  {
-    const unsigned long long fp = (unsigned long long)in.pts_flow, rp = (unsigned long long)in.tile_range;
-    c.pts_flow = (const float4 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(fp >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)fp));
-    c.tile_range = (const float2 *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rp >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)rp));
-    c.n_flow = __builtin_amdgcn_readfirstlane(in.n_flow);
-    c.tiles_x = __builtin_amdgcn_readfirstlane(in.tiles_x);
-  }
   eval_consts_defaults(c);
 }
 
@@ -2399,7 +2181,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                                                                                                   const unsigned *__restrict__ items,
                                                                                                   TickSegCtl *__restrict__ seg, int buf) {
   __shared__ float red[16][kNumSlots];
-  __shared__ __attribute__((aligned(16))) float win[MODE == 0 ? kWinRows * kWinPitch : 4]; // tile form of the level-0 pose evaluation
   const int n_items = ((const DSM_GLOBAL TickSegCtl *)seg)->count[buf];
   // the other list was consumed by the previous tick's evaluation; this tick's LM launch appends to it
   if (blockIdx.x == 0 && threadIdx.x == 0) seg->count[buf ^ 1] = 0;
@@ -2419,19 +2200,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
     c.residual_only = in.residual_only;
-    c.pts_flow = in.pts_flow, c.tile_range = in.tile_range, c.n_flow = in.n_flow, c.tiles_x = in.tiles_x;
-    eval_consts_defaults(c);
+      eval_consts_defaults(c);
     float *const out = partials + (size_t)prob * partial_stride + (cand ? (partial_stride >> 1) : 0) + (size_t)chunk * kPartialStride;
-    if (lvl == 0) {
-      if constexpr (MODE == 0)
-        eval_chunk_win<MODE>(c, chunk, threadIdx.x, red, out, nullptr, win);
-      else
-        eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
-    }
-#ifdef DSM_TICK_DEEP_L1
-    else if (c.n >= 64 * 1024) // eight or more points per thread: the deep loop (this kernel runs at four waves per SIMD anyway)
-      eval_chunk<MODE, false, true>(c, chunk, threadIdx.x, true, red, out);
-#endif
+    if (lvl == 0)
+      eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
     else
       eval_chunk<MODE, false>(c, chunk, threadIdx.x, true, red, out);
     __syncthreads(); // red[] is reused by the next item
@@ -2534,36 +2306,6 @@ __global__ void deinterleave_kernel(int n, const float4 *__restrict__ in, float 
     c[i] = p.w;
   }
 }
-// dsm_params.tile_l0: the tile-ordered copy of a dense level-0 template.  Tile t = (tx, ty) holds the points of keyframe pixels
-// x in [2 + 64 tx, +64), y in [2 + 64 ty, +64), row by row; positions without a template point (beyond the interior) are padded with
-// inverse depth 0, which no evaluation can use (new_idepth > 0 fails, :786).  range[t] = (min, max) inverse depth of the tile's points.
-__global__ __launch_bounds__(256) void tile_order_kernel(int w, int h, int tiles_x, const float4 *__restrict__ src, float4 *__restrict__ dst,
-                                                         float2 *__restrict__ range) {
-  const int t = blockIdx.x, tx = t % tiles_x, ty = t / tiles_x;
-  const int wi = w - 4;
-  float lo = 3.0e38f, hi = -3.0e38f;
-  for (int l = threadIdx.x; l < kTile * kTile; l += 256) {
-    const int x = 2 + kTile * tx + (l & (kTile - 1)), y = 2 + kTile * ty + (l >> 6);
-    float4 p = make_float4(2.0f, 2.0f, 0.0f, 0.0f);
-    if (x <= w - 3 && y <= h - 3) {
-      p = src[(size_t)(y - 2) * wi + (x - 2)];
-      lo = fminf(lo, p.z), hi = fmaxf(hi, p.z);
-    }
-    dst[(size_t)t * kTile * kTile + l] = p;
-  }
-  __shared__ float slo[256], shi[256];
-  slo[threadIdx.x] = lo, shi[threadIdx.x] = hi;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 256; i++) lo = fminf(lo, slo[i]), hi = fmaxf(hi, shi[i]);
-    range[t] = make_float2(lo, hi);
-  }
-}
-void launch_tile_order(hipStream_t s, int w, int h, int tiles_x, int tiles, const float4 *src, float4 *dst, float2 *range) {
-  static_assert(kTile == 64, "tile_order_kernel decodes 64 x 64 tiles");
-  hipLaunchKernelGGL(tile_order_kernel, dim3(tiles), dim3(256), 0, s, w, h, tiles_x, src, dst, range);
-}
-
 // scaleCoarseDepthL0 (:329-336): lpc_idepth[p] /= scale
 __global__ void scale_depth_kernel(int n, float4 *pts, float scale) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pts[i].z = pts[i].z / scale;

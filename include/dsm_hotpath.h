@@ -115,13 +115,10 @@ typedef struct dsm_params {
                                          cut-off repeat, no small-step break, no abort), so that the evaluations and bytes
                                          per frame do not depend on the input.  Not the reference's algorithm: 0 (default)
                                          runs trackNewestCoarse / optimizeScale as written. */
-  int tile_l0;                        /* 1: level 0 of a DENSE template (every interior pixel, row-major: what a dense keyframe
-                                         gives) is also kept in TILE order -- a chunk of the evaluation = one 64 x 64 pixel tile --
-                                         and its pose evaluations stage the warped tile's window of the target plane in LDS with
-                                         coalesced loads and take their bilinear taps from there instead of gathering them from
-                                         HBM; windows that do not fit fall back to the gathers.  Changes which thread sums which
-                                         point (float sums differ in their last bits from tile_l0 = 0); every scheduling form of one
-                                         setting is still bit-identical to the others.  0 (default): row-major chunks. */
+  int tile_l0;                        /* RESERVED, must be 0.  Round 4's opt-in tile form of the level-0 evaluation (tile-ordered
+                                         template copy, warped window staged in LDS) measured slower than the gathers (4996 ->
+                                         4104 GB/s) and was removed in round 5 (tools/experiments/removed_r05/tile_form_and_ab_switches.patch);
+                                         the field keeps the structure's layout.  A non-zero value is DSM_ERR_INVALID. */
   int frame_check;                    /* dsm_tracker_upload_frame: 1 (default) verify that the caller's gradient channels
                                          are makeImages' central differences of channel 0 (the device stores channel 0 only);
                                          0 trust the caller (channels 1, 2 are ignored) */
