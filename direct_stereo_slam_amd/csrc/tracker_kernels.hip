@@ -34,27 +34,76 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-// after this every lane holds the sum over its 16-lane row
+// after this every lane holds the sum over its 16-lane row: the balanced tree ((l0 + l1) + (l2 + l3)) + ... over the row's lanes.
+// The lane exchange is ds_swizzle (the LDS unit's crossbar, no memory) + a plain v_add_f32 (2.5 cycles) instead of an add with a DPP
+// operand (4.65 cycles, as every DPP form: profiles/r05_valu_issue_cost_w*.json): the 52 row sums of a chunk's reduction were 970
+// vector cycles per wave -- 1.8 points' worth of the loop, 11 % of a level-0 chunk and 45 % of a four-point one -- and are 520.  Same
+// tree, float addition commutes: the same bits as the DPP form (lane ^ 4 / lane ^ 8 exchange the same partial sums as the mirrors).
+template <int PATTERN>
+__device__ __forceinline__ float swz_f(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN)); }
+constexpr int kSwzQuad1032 = 0x80B1, kSwzQuad2301 = 0x804E, kSwzXor4 = 0x101F, kSwzXor8 = 0x201F;
 __device__ __forceinline__ float row16_sum(float v) {
-  v = v + dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
-  v = v + dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
-  v = v + dpp_f<0x141>(v); // row_half_mirror
-  v = v + dpp_f<0x140>(v); // row_mirror
+  v = v + swz_f<kSwzQuad1032>(v);
+  v = v + swz_f<kSwzQuad2301>(v);
+  v = v + swz_f<kSwzXor4>(v);
+  v = v + swz_f<kSwzXor8>(v);
   return v;
 }
 __device__ __forceinline__ int row16_sum(int v) {
-  v = v + dpp_i<0xB1>(v);
-  v = v + dpp_i<0x4E>(v);
-  v = v + dpp_i<0x141>(v);
-  v = v + dpp_i<0x140>(v);
+  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzQuad1032);
+  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzQuad2301);
+  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzXor4);
+  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzXor8);
   return v;
 }
 
 // clang vector types: loads through address_space(1) pointers compile on the host pass too
 typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 typedef float fvec4u __attribute__((ext_vector_type(4), aligned(4))); // four / two neighbouring texels, dword aligned
 typedef float fvec2u __attribute__((ext_vector_type(2), aligned(4)));
 #define DSM_GLOBAL __attribute__((address_space(1)))
+
+// ------------------------------------------------------------------------------------------
+// Lane masks.  What a vector instruction costs on gfx950 depends on its FORM (tools/microbench/valu_issue_cost.hip,
+// profiles/r05_valu_issue_cost_w*.json; cycles a wave64 instruction occupies its SIMD): v_mul / v_add / v_sub / v_fmac / v_and /
+// v_mov / v_add_u32 in the 4-byte encoding with VGPR or inline-constant sources 2.5; their 8-byte encodings and v_fma_f32 3.1;
+// ANYTHING with an SGPR source, every v_cmp, v_cndmask, v_cvt, v_fract, v_min / v_max, shifts, integer multiplies 4.65; v_rcp 8.5.
+// The level-0 loop is bound by exactly that sum (a padding experiment follows it to 1 %: profiles/r05_ab_pad_level0.log), and
+// the compiler's handling of C++ bools was a fifth of it: a bool that crosses a loop edge or feeds a ballot is materialised as
+// v_cndmask 0/1 + v_cmp_ne (two 4.65-cycle instructions per ballot), `cond ? x : 0` is a 4.65-cycle select per value.  The
+// per-point code therefore keeps its predicates as explicit 64-bit lane masks in SGPR pairs -- a compare writes one (its only
+// cost), logic and population counts on them are scalar instructions -- turns a mask into all-ones / zero lane bits ONCE
+// (one v_cndmask) and masks values with v_and (2.5 cycles).
+// ------------------------------------------------------------------------------------------
+typedef unsigned long long lmask;
+// LLVM's compare predicate codes (llvm.amdgcn.fcmp / icmp)
+enum { kOEQ = 1, kOGT = 2, kOGE = 3, kOLT = 4, kSLT = 40 };
+#define DSM_FCMP(a, b, pred) ((lmask)__builtin_amdgcn_fcmpf((a), (b), (pred)))
+__device__ __forceinline__ lmask lanes_finite(float x) { return DSM_FCMP(__builtin_fabsf(x), __builtin_inff(), kOLT); } // false for NaN
+// A lane mask is the same in every lane by construction; where the compiler cannot see that (a mask chosen under a condition it takes
+// for divergent, e.g. the thread group's chunk in coarse_kernel) this pins it to an SGPR pair -- no instruction where it already is one.
+__device__ __forceinline__ lmask mask_sgpr(lmask m) {
+  return ((lmask)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+}
+// bit set -> t, clear -> f  (v_cndmask_b32 with the mask in an SGPR pair)
+__device__ __forceinline__ float sel_f(lmask m, float f, float t) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask_sgpr(m)));
+  return r;
+}
+__device__ __forceinline__ unsigned sel_u(lmask m, unsigned f, unsigned t) {
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask_sgpr(m)));
+  return r;
+}
+// all-ones where the lane's bit is set, zero elsewhere (opaque to the optimiser on purpose: `x & lane_bits(m)` stays a v_and)
+__device__ __forceinline__ unsigned lane_bits(lmask m) {
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(mask_sgpr(m)));
+  return r;
+}
+__device__ __forceinline__ float and_f(float x, unsigned bits) { return __uint_as_float(__float_as_uint(x) & bits); }
 
 // getInterpolatedElement33 (upstream DSO), call sites TrackerAndScaler.cpp:790,1106, split in two
 // so that the tap loads of one point can be in flight while the previous point is consumed.
@@ -90,15 +139,21 @@ __device__ __forceinline__ TapBasesL tap_bases_lds(unsigned img, int w) {
   const unsigned pitch = 4u * (unsigned)w;
   return TapBasesL{img - pitch, img - 4u, img + pitch - 4u, img + 2u * pitch};
 }
+// byte offset of the taps of position (x, y): texel (floor x, floor y), or the safe texel (2, 2) for lanes outside `ok` -- ONE
+// select, on the finished offset (an unusable lane's x / y may be anything, NaN included: its fractions and values are masked later)
+__device__ __forceinline__ unsigned tap_offset(float x, float y, int w, lmask ok, unsigned safe_off, float &dx, float &dy) {
+  const int ix = (int)x, iy = (int)y;
+  // x - (float)(int)x for x >= 0 is exact and equals v_fract_f32(x) (= x - floor(x))
+  dx = __builtin_amdgcn_fractf(x);
+  dy = __builtin_amdgcn_fractf(y);
+  const unsigned off = 4u * ((unsigned)ix + (unsigned)iy * (unsigned)w);
+  return sel_u(ok, safe_off, off);
+}
 template <bool L> struct TapSel { typedef TapBases type; };
 template <> struct TapSel<true> { typedef TapBasesL type; };
 template <bool GRAD = true>
-__device__ __forceinline__ void taps_load(const TapBasesL &B, float x, float y, int w, Taps &T) {
-  const int ix = (int)x;
-  const int iy = (int)y;
-  T.dx = __builtin_amdgcn_fractf(x);
-  T.dy = __builtin_amdgcn_fractf(y);
-  const unsigned off = 4u * (unsigned)(ix + iy * w);
+__device__ __forceinline__ void taps_load(const TapBasesL &B, float x, float y, int w, lmask ok, unsigned safe_off, Taps &T) {
+  const unsigned off = tap_offset(x, y, w, ok, safe_off, T.dx, T.dy);
   if (GRAD) {
     const fvec4u a = *(const DSM_LDS fvec4u *)(size_t)(B.r1 + off);
     const fvec4u b = *(const DSM_LDS fvec4u *)(size_t)(B.r2 + off);
@@ -119,14 +174,8 @@ __device__ __forceinline__ void taps_load(const TapBasesL &B, float x, float y, 
 }
 // GRAD = false (residual-only evaluations): the intensity needs columns x, x+1 of rows y, y+1 only -- two 8-byte loads.
 template <bool GRAD = true>
-__device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, int w, Taps &T) {
-  const int ix = (int)x;
-  const int iy = (int)y;
-  // x - (float)(int)x for x >= 0 is exact and equals v_fract_f32(x) (= x - floor(x))
-  T.dx = __builtin_amdgcn_fractf(x);
-  T.dy = __builtin_amdgcn_fractf(y);
-  // (Shift-add / 24-bit forms of this multiply were measured: no gain.)
-  const unsigned off = 4u * (unsigned)(ix + iy * w);
+__device__ __forceinline__ void taps_load(const TapBases &B, float x, float y, int w, lmask ok, unsigned safe_off, Taps &T) {
+  const unsigned off = tap_offset(x, y, w, ok, safe_off, T.dx, T.dy);
   if (GRAD) {
     const fvec4u a = *(const DSM_GLOBAL fvec4u *)(B.r1 + off); // (x-1 .. x+2, y)
     const fvec4u b = *(const DSM_GLOBAL fvec4u *)(B.r2 + off); // (x-1 .. x+2, y+1)
@@ -178,7 +227,7 @@ __device__ __forceinline__ void taps_interp(const Taps &T, float &h0, float &g1,
 struct Warped {
   float u, v, new_idepth, refColor;
   float x, y, id; // scale mode only (rx = M (x,y,1) / id, :1068)
-  bool inb;
+  lmask inb;      // lanes whose point is usable (:786 / :1102): wave-uniform, lives in an SGPR pair
 };
 
 // ------------------------------------------------------------------------------------------
@@ -216,7 +265,11 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img 
 // its first wave's loop and the partial store).
 // DEEP: the two-points-per-trip loop with fixed register roles (level 0 always; the tick engine's kernel, which runs at four
 // waves per SIMD whatever the level, also uses it on the other large levels)
-template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0>
+// VC: which wave-uniform constants the loop keeps in VGPRs (an SGPR source costs an instruction 4.65 instead of 2.5 cycles): 0 none
+// (the 96-register kernels of five waves per SIMD), 1 the warp's twelve (the two-point loop at four waves per SIMD: 128 registers hold
+// these and no more), 2 the camera, gradient-scale and brightness constants as well (the one-point loop inside a kernel that is
+// allocated 128 registers anyway: tick_eval_kernel)
+template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                                 float *out, int *arrive = nullptr) {
   const int n = c.n;
@@ -232,7 +285,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     const float M0 = c.M[0], M1 = c.M[1], M2 = c.M[2], M3 = c.M[3], M4 = c.M[4], M5 = c.M[5],
                 M6 = c.M[6], M7 = c.M[7], M8 = c.M[8];
     const float t0 = c.t[0], t1 = c.t[1], t2 = c.t[2];
-    const float cutoff = c.cutoff, max_energy = c.max_energy;
+    const float cutoff = c.cutoff;
     const float huber = c.huber;
     const float fxl = c.fx, fyl = c.fy, cxl = c.cx, cyl = c.cy;
     const float hfx = 0.5f * fxl, hfy = 0.5f * fyl; // the central differences' 0.5 (see taps_interp)
@@ -256,15 +309,24 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
     // Software-pipelined, branch-free loop.  Stage A warps template point k+1 and issues its four
     // bilinear tap loads; stage B consumes the taps of point k (residual, Huber, Jacobian, 45 FMAs)
-    // while those loads are in flight.  Out-of-range lanes are clamped to a safe address and masked
-    // by selects, so the accumulators never cross a divergent join.
-    auto stage_a = [&](const fvec4 &p, bool in_list, Warped &W, Taps &T) {
+    // while those loads are in flight.  Predicates are lane masks (see "Lane masks" above): unusable lanes fetch from a safe
+    // address and their values are ANDed to zero, so the accumulators never cross a divergent join.
+    const lmask full = __builtin_amdgcn_ballot_w64(true);
+    unsigned safe_off = 4u * (2u + 2u * (unsigned)pitch); // byte offset of texel (2, 2): held in a VGPR (a select takes no SGPR besides its mask)
+    asm volatile("" : "+v"(safe_off));
+    // The warp's twelve constants in VGPRs: an SGPR source costs an instruction 4.65 instead of 2.5 cycles (level-0 loop: 1163 -> 1111
+    // cycles per two points).  The register budget of four waves per SIMD (128) has room for these and no more.
+    float vM0 = M0, vM1 = M1, vM2 = M2, vM3 = M3, vM4 = M4, vM5 = M5, vM6 = M6, vM7 = M7, vM8 = M8, vt0 = t0, vt1 = t1, vt2 = t2;
+    if (VC >= 1 && MODE == 0) asm volatile("" : "+v"(vM0), "+v"(vM1), "+v"(vM2), "+v"(vM3), "+v"(vM4), "+v"(vM5), "+v"(vM6), "+v"(vM7), "+v"(vM8), "+v"(vt0), "+v"(vt1), "+v"(vt2));
+    float vfx = fxl, vfy = fyl, vcx = cxl, vcy = cyl, vhfx = hfx, vhfy = hfy, vaff0 = aff0, vaff1 = aff1, vb0 = b0;
+    if (VC >= 2 && MODE == 0) asm volatile("" : "+v"(vfx), "+v"(vfy), "+v"(vcx), "+v"(vcy), "+v"(vhfx), "+v"(vhfy), "+v"(vaff0), "+v"(vaff1), "+v"(vb0));
+    auto stage_a = [&](const fvec4 &p, lmask in_list, Warped &W, Taps &T) {
       const float x = p.x, y = p.y, id = p.z;
       float pt0, pt1, pt2;
       if (MODE == 0) { // :747
-        pt0 = ((M0 * x + M1 * y) + M2) + t0 * id;
-        pt1 = ((M3 * x + M4 * y) + M5) + t1 * id;
-        pt2 = ((M6 * x + M7 * y) + M8) + t2 * id;
+        pt0 = ((vM0 * x + vM1 * y) + vM2) + vt0 * id;
+        pt1 = ((vM3 * x + vM4 * y) + vM5) + vt1 * id;
+        pt2 = ((vM6 * x + vM7 * y) + vM8) + vt2 * id;
       } else if (MODE == 2) { // PoseEstimator.cpp:192: pt = R (x,y,z) + t ; the float4 is (x, y, z, refColor[lvl])
         pt0 = ((M0 * x + M1 * y) + M2 * id) + t0;
         pt1 = ((M3 * x + M4 * y) + M5 * id) + t1;
@@ -278,13 +340,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       // taps and decide in/out, so they must equal the IEEE quotients bit for bit; new_idepth only
       // enters the sign test and the Jacobian.  The three quotients share one refined reciprocal
       // and use the hardware's own correction sequence (what `a / d` expands to) without the
-      // range scaling / fix-up instructions, which are identities for ordinary operands.  A wave
-      // that holds a lane outside that range takes the full IEEE divisions instead.
+      // range scaling / fix-up instructions, which are identities for ordinary operands: 2^-33 <= |pt2| < 2^32 and
+      // |id| >= 2^-64 or id = 0.  A wave that holds a lane outside that range takes the full IEEE divisions instead.
       {
-        const int ex = __builtin_amdgcn_frexp_expf(pt2); // pt2 = m * 2^ex, |m| in [0.5,1); 0/inf/nan give 0 or garbage
-        const bool ordinary = (unsigned)(ex + 32) <= 64u && (MODE == 2 || __builtin_fabsf(id) >= 0x1p-64f || id == 0.0f) &&
-                              __builtin_fabsf(pt2) >= 0x1p-34f;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ordinary) != 0ull, 0)) {
+        const float apt2 = __builtin_fabsf(pt2);
+        lmask ordinary = DSM_FCMP(apt2, 0x1p-33f, kOGE) & DSM_FCMP(apt2, 0x1p32f, kOLT);
+        if (MODE != 2) ordinary &= DSM_FCMP(__builtin_fabsf(id), 0x1p-64f, kOGE) | DSM_FCMP(id, 0.0f, kOEQ);
+        if (__builtin_expect(ordinary != full, 0)) {
           W.u = pt0 / pt2;
           W.v = pt1 / pt2;
           W.new_idepth = (MODE == 2 ? 1.0f : id) / pt2; // PoseEstimator.cpp:197: 1 / pt[2]
@@ -301,49 +363,51 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
           W.new_idepth = MODE == 2 ? r1 : id * r1;
         }
       }
-      const float Ku = fxl * W.u + cxl, Kv = fyl * W.v + cyl;
+      const float Ku = vfx * W.u + vcx, Kv = vfy * W.v + vcy;
       W.refColor = p.w;
       W.x = x, W.y = y, W.id = id;
-      W.inb = in_list && (Ku > 2 && Kv > 2 && Ku < wm3 && Kv < hm3 && W.new_idepth > 0); // :786 / :1102
-      taps_load<!RO>(img, W.inb ? Ku : 2.5f, W.inb ? Kv : 2.5f, pitch, T); // (unusable lanes fetch around texel (2, 2))
+      // :786 / :1102 (every comparison is false for a NaN, as in the reference)
+      W.inb = in_list & DSM_FCMP(Ku, 2.0f, kOGT) & DSM_FCMP(Kv, 2.0f, kOGT) & DSM_FCMP(Ku, wm3, kOLT) & DSM_FCMP(Kv, hm3, kOLT) &
+              DSM_FCMP(W.new_idepth, 0.0f, kOGT);
+      taps_load<!RO>(img, Ku, Kv, pitch, W.inb, safe_off, T); // (unusable lanes fetch around texel (2, 2))
     };
     auto stage_b = [&](const Warped &W, const Taps &T) {
       float h0, g1, g2;
       taps_interp<false, !RO>(T, h0, g1, g2);
       // makeImages' "non-finite gradient -> 0", the rare path: the taps are fetched again (so that the common path
       // does not keep twelve registers alive for it) and the replacement is applied tap by tap
-      if (!RO && __builtin_expect(__builtin_amdgcn_ballot_w64(W.inb && !(__builtin_isfinite(g1) && __builtin_isfinite(g2))) != 0ull, 0)) {
+      if (!RO && __builtin_expect((W.inb & ~(lanes_finite(g1) & lanes_finite(g2))) != 0ull, 0)) {
         Taps Tx; // (always from the plane in HBM: the same values as a staged copy holds)
-        taps_load(img_g, W.inb ? fxl * W.u + cxl : 2.5f, W.inb ? fyl * W.v + cyl : 2.5f, wl, Tx);
+        taps_load(img_g, fxl * W.u + cxl, fyl * W.v + cyl, wl, W.inb, safe_off, Tx);
         taps_interp<true>(Tx, h0, g1, g2);
       }
       const float refColor = W.refColor;
-      const bool fin = W.inb && __builtin_isfinite(h0); // :791
-      const float residual = MODE != 1 ? h0 - (aff0 * refColor + aff1) : h0 - refColor; // :793 / :1109
+      const lmask fin = W.inb & lanes_finite(h0); // :791
+      const float residual = MODE != 1 ? h0 - (vaff0 * refColor + vaff1) : h0 - refColor; // :793 / :1109
       const float ar = __builtin_fabsf(residual);
-      // Huber weight (:794-795).  It is off the per-point decision path (in/out, cut-off, Huber branch): it only
-      // scales this point's terms of E and of the normal equations -- sums that are compared to tolerance, E then
-      // entering the LM accept test like any other rounding of the sum -- so the hardware reciprocal (1 ulp)
-      // replaces the IEEE division.
-      const float hw = ar < huber ? 1.0f : huber * __builtin_amdgcn_rcpf(ar);
-      const bool sat = ar > cutoff;                    // :797
-      const bool use = fin && !sat;
-      const float e_term = sat ? max_energy : hw * residual * residual * (2 - hw); // :800 / :809
-      E += fin ? e_term : 0.0f;
+      // Huber weight (:794-795): 1 for |r| < huber, huber / |r| beyond.  It is off the per-point decision path (in/out, cut-off):
+      // it only scales this point's terms of E and of the normal equations -- sums that are compared to tolerance, E then
+      // entering the LM accept test like any other rounding of the sum -- so the hardware reciprocal (1 ulp) replaces the IEEE
+      // division and the branch is a minimum (huber / |r| > 1 exactly where |r| < huber, up to that ulp; 1 for r = 0).
+      const float hw = __builtin_fminf(1.0f, huber * __builtin_amdgcn_rcpf(ar));
+      const lmask sat = DSM_FCMP(ar, cutoff, kOGT); // :797
+      const lmask use = fin & ~sat;
       // integer outputs are counted per wave on the scalar unit (s_bcnt1 of the lane masks)
-      n_terms += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fin));
-      n_sat += __builtin_popcountll(__builtin_amdgcn_ballot_w64(fin && sat));
-      n_warped += __builtin_popcountll(__builtin_amdgcn_ballot_w64(use));
-      const float wgt = use ? hw : 0.0f;
+      n_terms += __builtin_popcountll(fin);
+      n_sat += __builtin_popcountll(fin & sat);
+      n_warped += __builtin_popcountll(use);
+      const unsigned m = lane_bits(use);
+      // :809 for the usable lanes; a saturated lane's term is the constant max_energy (:800): n_sat x max_energy joins E where the
+      // partials are reduced (build_rs)
+      E += and_f(hw * residual * residual * (2 - hw), m);
+      const float wgt = and_f(hw, m);
       if (RO) {
         // nothing else: the sums below feed calcGSSSE*, whose output the ending loop never reads
       } else if (MODE != 1) {
         // calcGSSSEPose :658-678 on the values calcResPose would have buffered (:812-819); masked
         // lanes get all-zero inputs so that they add exact zeros
-        const unsigned m = use ? 0xFFFFFFFFu : 0u;
-        auto keep = [m](float f) { return __uint_as_float(__float_as_uint(f) & m); };
-        const float u = keep(W.u), v = keep(W.v), nid = keep(W.new_idepth);
-        const float dx = keep(g1 * hfx), dy = keep(g2 * hfy); // dxInterp = hitColor[1] * fx (:814), 0.5 folded
+        const float u = and_f(W.u, m), v = and_f(W.v, m), nid = and_f(W.new_idepth, m);
+        const float dx = and_f(g1 * vhfx, m), dy = and_f(g2 * vhfy, m); // dxInterp = hitColor[1] * fx (:814), 0.5 folded
         float J[9];
         J[0] = nid * dx;
         J[1] = nid * dy;
@@ -351,9 +415,9 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         J[3] = -__builtin_fmaf(u * v, dx, dy * __builtin_fmaf(v, v, 1.0f));
         J[4] = __builtin_fmaf(u * v, dy, dx * __builtin_fmaf(u, u, 1.0f));
         J[5] = __builtin_fmaf(u, dy, -(v * dx));
-        J[6] = keep(aff0 * (b0 - refColor));
+        J[6] = and_f(vaff0 * (vb0 - refColor), m);
         J[7] = -1.0f;
-        J[8] = keep(residual);
+        J[8] = and_f(residual, m);
         int idx = 0;
   #pragma unroll
         for (int r = 0; r < 9; r++) { // Accumulator9::updateSSE_eighted: H(r,c) += (J_r w) J_c
@@ -375,8 +439,8 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         const float deno = 1.0f / (deno_sqrt * deno_sqrt);
         const float xno = rx1 * t2 - rx3 * t0;
         const float yno = rx2 * t2 - rx3 * t1;
-        const float J0 = use ? dxfx * (deno * xno) + dyfy * (deno * yno) : 0.0f;
-        const float J1 = use ? residual : 0.0f;
+        const float J0 = and_f(dxfx * (deno * xno) + dyfy * (deno * yno), m);
+        const float J1 = and_f(residual, m);
         const float J0w = J0 * wgt;
         acc[0] = __builtin_fmaf(J0w, J0, acc[0]);
         acc[1] = __builtin_fmaf(J0w, J1, acc[1]);
@@ -385,15 +449,32 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     };
 
     {
-      const DSM_GLOBAL char *pb = (const DSM_GLOBAL char *)pts;
+      // Template stream: entry (start + tid) of the list = one coalesced 16-byte load per lane from a wave-uniform base (SGPR pair)
+      // plus this thread's constant byte offset -- no per-point index arithmetic.  Entries past the chunk (the loop prefetches up to
+      // three trips ahead) or past the list are never used: their lanes are masked; the list's allocation has kTemplatePad entries
+      // of slack (dsm_kernels.hpp), the LDS copy (coarse_kernel) is read with a clamped index instead.
+      const unsigned voff = 16u * (unsigned)tid;
       const unsigned lds_pts = c.lds_pts;
-      auto load_pt = [=](int idx) {
-        const unsigned o = 16u * (unsigned)(idx < n ? idx : n - 1);
-        if constexpr (LDSPTS) return *(const DSM_LDS fvec4 *)(size_t)(lds_pts + o);
-        // streamed once: non-temporal, so the template does not evict target rows from the 32 KiB L1 (+2.5 %)
-        else return __builtin_nontemporal_load((const DSM_GLOBAL fvec4 *)(pb + o));
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.pts, 0, 16 * n, 0x00020000);
+      auto load_pt = [=](int start) {
+        if constexpr (LDSPTS) {
+          const int idx = start + tid;
+          return *(const DSM_LDS fvec4 *)(size_t)(lds_pts + 16u * (unsigned)(idx < n ? idx : n - 1));
+        } else {
+          // streamed once: non-temporal (aux = 2), so the template does not evict target rows from the 32 KiB L1 (+2.5 %).
+          // buffer_load ... offen: descriptor and the trip's byte offset in SGPRs, this thread's constant offset in a VGPR -- no vector
+          // address arithmetic at all; an entry beyond the list reads as zeros (range-checked by the descriptor).
+          const uvec4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * start, 2);
+          return fvec4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
       };
-      const int i = chunk_start + tid;
+      // lanes whose entry `start + tid` exists and whose trip belongs to the chunk: every lane except in the list's last chunk
+      const bool tail = chunk_start + kThreads * P > n;
+      auto listed = [=](int start, bool trip) -> lmask {
+        if (!trip) return 0ull;
+        return mask_sgpr(tail ? (lmask)__builtin_amdgcn_sicmp(tid, n - start, kSLT) : full);
+      };
+      const int i = chunk_start;
       const fvec4 p0 = load_pt(i);
       if (DEEP) {
         // Level 0 (long loops, HBM-resident targets): two points per trip with FIXED register roles (sets a / b).
@@ -409,29 +490,29 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
         Warped Wa, Wb;
         Taps Ta, Tb;
-        stage_a(p0, i < n, Wa, Ta);
-        int ia = i + kThreads; // index of the entry held in ea (eb: ia + kThreads)
+        stage_a(p0, listed(i, true), Wa, Ta);
+        int ia = i + kThreads; // start of the entries held in ea (eb: ia + kThreads)
         for (int k = 0; k < P; k += 2) {
-          stage_a(ea, ia < n && k + 1 < P, Wb, Tb); // point k+1
+          stage_a(ea, listed(ia, k + 1 < P), Wb, Tb); // point k+1
           ea = load_pt(ia + 2 * kThreads);
           stage_b(Wa, Ta); // point k
-          stage_a(eb, ia + kThreads < n && k + 2 < P, Wa, Ta); // point k+2
+          stage_a(eb, listed(ia + kThreads, k + 2 < P), Wa, Ta); // point k+2
           eb = load_pt(ia + 3 * kThreads);
           stage_b(Wb, Tb); // point k+1 (masked when k+1 == P)
           ia += 2 * kThreads;
         }
       } else {
-        // Template stream: one coalesced 16-byte load per lane and point, prefetched one point ahead.
+        // Template stream prefetched one point ahead.
         int i2 = i + kThreads;
         fvec4 p_next = load_pt(i2);
         __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
         Warped Wc;
         Taps Tc;
-        stage_a(p0, i < n, Wc, Tc);
+        stage_a(p0, listed(i, true), Wc, Tc);
         for (int k = 0; k < P; k++) {
           // stage A for point k+1 (its template entry was prefetched one iteration ago)
           const fvec4 p = p_next;
-          const bool in_next = i2 < n && k + 1 < P;
+          const lmask in_next = listed(i2, k + 1 < P);
           const int i3 = i2 + kThreads;
           p_next = load_pt(i3);
           Warped Wn;
@@ -508,7 +589,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 
   } // active
-  // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
+  // ---- workgroup reduction: row sums (lane exchanges through the LDS crossbar) -> LDS [16 rows][slots] -> fixed-order sum ----
   const int lane = tid & 63, wave = tid >> 6;
   const int row = wave * 4 + (lane >> 4);
   const bool writer = (lane & 15) == 0;
@@ -518,10 +599,10 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     if (writer) red[row][i] = s;
   }
   {
-    const float sE = row16_sum(E), sT = row16_sum(fT), sRT = row16_sum(fRT), sN = row16_sum(fNum);
+    const float sE = row16_sum(E), sT = LVL0 ? row16_sum(fT) : 0.f, sRT = LVL0 ? row16_sum(fRT) : 0.f, sN = LVL0 ? row16_sum(fNum) : 0.f; // (flow indicators: level 0 only)
     // n_terms / n_sat / n_warped are wave totals (identical in every lane): count them once per wave
     const bool first = lane == 0;
-    const int iT = row16_sum(first ? n_terms : 0), iS = row16_sum(first ? n_sat : 0), iW = row16_sum(first ? n_warped : 0);
+    const int iT = first ? n_terms : 0, iS = first ? n_sat : 0, iW = first ? n_warped : 0; // (a row's writer is its lane 0: the wave's first row carries the totals)
     if (writer) {
       red[row][kSlotE] = sE;
       red[row][kSlotFlowT] = sT;
@@ -559,13 +640,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   }
 }
 
-template <int MODE, bool LVL0, bool DEEP = LVL0>
+template <int MODE, bool LVL0, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
                                            float *out, int *arrive = nullptr) {
   if (c.residual_only) // wave-uniform
-    eval_chunk_impl<MODE, LVL0, true, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
+    eval_chunk_impl<MODE, LVL0, true, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
   else
-    eval_chunk_impl<MODE, LVL0, false, false, false, DEEP>(c, chunk, tid, active, red, out, arrive);
+    eval_chunk_impl<MODE, LVL0, false, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -731,8 +812,10 @@ __device__ __forceinline__ void begin_level(const TrackerDev &T, LMState &S, int
 __device__ __forceinline__ int level_max_it(const ParamsDev &p, int lvl) { return p.fixed_schedule > 0 ? p.fixed_schedule : p.max_iterations[lvl]; }
 
 // Vec6 rs of calcResPose / calcResScale (:843-851) from the reduced sums
-__device__ __forceinline__ void build_rs(const double *sums, const long long *isums, double rs[6]) {
-  const float E = (float)sums[kSlotE];
+// The E slot of the partials holds the energy of the USABLE lanes; every saturated lane contributes the evaluation's constant
+// max_energy (:800 / :809), added here as n_sat x max_energy (no per-point select for it in the loop).
+__device__ __forceinline__ void build_rs(const double *sums, const long long *isums, float max_energy, double rs[6]) {
+  const float E = (float)(sums[kSlotE] + (double)max_energy * (double)isums[1]);
   const float sT = (float)sums[kSlotFlowT], sRT = (float)sums[kSlotFlowRT], sN = (float)sums[kSlotFlowNum];
   const int n_terms = (int)isums[0], n_sat = (int)isums[1];
   rs[0] = E;
@@ -1195,7 +1278,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   const double *sums = sh.red.sums;
   const long long *isums = sh.red.isums;
   double rs[6];
-  build_rs(sums, isums, rs);
+  build_rs(sums, isums, S.in.max_energy, rs);
   const int n_warped = (int)isums[2];
   const int n4 = (n_warped + 3) & ~3; // :824-835 padding counts in n (quirk Q3)
   const int r = lane >> 3, c = lane & 7;
@@ -1279,7 +1362,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
       const double *sums2 = sp->red.sums;
       const long long *isums2 = sp->red.isums;
       double rs2[6];
-      build_rs(sums2, isums2, rs2);
+      build_rs(sums2, isums2, S.spec_in.max_energy, rs2);
       const int n4b = ((int)isums2[2] + 3) & ~3;
       const bool accept2 = (rs2[0] / rs2[1]) < old_ratio; // res_old is unchanged by the rejection
       const bool small2 = pose_like ? !(S.spec_inc_norm > 1e-3) : !(S.spec_inc_f > 1e-3);
@@ -1641,7 +1724,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   const double *sums = sh.red.sums;
   const long long *isums = sh.red.isums;
   double rs[6];
-  build_rs(sums, isums, rs);
+  build_rs(sums, isums, S.in.max_energy, rs);
   const int n_warped = (int)isums[2];
   const int n4 = (n_warped + 3) & ~3;
   const int r = lane >> 3, c = lane & 7;
@@ -2205,7 +2288,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     if (lvl == 0)
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
     else
-      eval_chunk<MODE, false>(c, chunk, threadIdx.x, true, red, out);
+      eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out); // (this kernel is allocated 128 registers by its level-0 loop)
     __syncthreads(); // red[] is reused by the next item
   }
 }

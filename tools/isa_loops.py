@@ -13,7 +13,7 @@ def main():
     min_n = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     lines = open(path).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(name) and l.split(":")[0].startswith(name))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end + 1]
     labels = {}
     for i, l in enumerate(body):
