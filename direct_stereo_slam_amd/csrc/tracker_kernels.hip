@@ -35,25 +35,15 @@ __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
 // after this every lane holds the sum over its 16-lane row: the balanced tree ((l0 + l1) + (l2 + l3)) + ... over the row's lanes.
-// The lane exchange is ds_swizzle (the LDS unit's crossbar, no memory) + a plain v_add_f32 (2.5 cycles) instead of an add with a DPP
-// operand (4.65 cycles, as every DPP form: profiles/r05_valu_issue_cost_w*.json): the 52 row sums of a chunk's reduction were 970
-// vector cycles per wave -- 1.8 points' worth of the loop, 11 % of a level-0 chunk and 45 % of a four-point one -- and are 520.  Same
-// tree, float addition commutes: the same bits as the DPP form (lane ^ 4 / lane ^ 8 exchange the same partial sums as the mirrors).
-template <int PATTERN>
-__device__ __forceinline__ float swz_f(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN)); }
-constexpr int kSwzQuad1032 = 0x80B1, kSwzQuad2301 = 0x804E, kSwzXor4 = 0x101F, kSwzXor8 = 0x201F;
+// (An add with a DPP operand costs 4.65 cycles where a plain v_add_f32 costs 2.5, and a chunk's 52 row sums are 970 vector cycles per
+// wave -- 1.8 points' worth of the loop.  Round 5 tried the exchange through the LDS crossbar instead (ds_swizzle + plain add: the same
+// tree, the same bits): level 0 5.2 -> 4.7 TB/s, 61.1 k -> 54.7 k frames/s -- four dependent LDS round trips per sum cost more than they
+// save; profiles/r05_ab_swizzle_row_sums.log.)
 __device__ __forceinline__ float row16_sum(float v) {
-  v = v + swz_f<kSwzQuad1032>(v);
-  v = v + swz_f<kSwzQuad2301>(v);
-  v = v + swz_f<kSwzXor4>(v);
-  v = v + swz_f<kSwzXor8>(v);
-  return v;
-}
-__device__ __forceinline__ int row16_sum(int v) {
-  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzQuad1032);
-  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzQuad2301);
-  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzXor4);
-  v = v + __builtin_amdgcn_ds_swizzle(v, kSwzXor8);
+  v = v + dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = v + dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
+  v = v + dpp_f<0x141>(v); // row_half_mirror
+  v = v + dpp_f<0x140>(v); // row_mirror
   return v;
 }
 
@@ -589,7 +579,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 
   } // active
-  // ---- workgroup reduction: row sums (lane exchanges through the LDS crossbar) -> LDS [16 rows][slots] -> fixed-order sum ----
+  // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
   const int lane = tid & 63, wave = tid >> 6;
   const int row = wave * 4 + (lane >> 4);
   const bool writer = (lane & 15) == 0;

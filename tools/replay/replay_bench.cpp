@@ -673,6 +673,7 @@ struct ConcurrentResult {
   double wall_ms = 0, latency_ms_sum = 0, latency_ms_max = 0;
   std::vector<std::vector<SE3>> est;
   std::vector<std::vector<float>> scales;
+  std::map<std::string, double> host_ms; // host wall time inside each kind of call, summed over the run
 };
 
 static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
@@ -695,6 +696,11 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
   };
   ConcurrentResult R;
   R.sequences = S;
+  auto timed = [&R](const char *what, auto &&fn) {
+    const auto t0 = Clock::now();
+    fn();
+    R.host_ms[what] += ms_since(t0);
+  };
   dsm_context *ctx = nullptr;
   dsm_host::check(dsm_context_create(0, &ctx), "dsm_context_create");
   // the camera frames in page-locked memory (dsm_host_alloc), as a node's capture buffers would be: the hand-over of the frames that
@@ -763,7 +769,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
         ref.shell_id = q.frame, ref.unique_id = left_id(s, q.frame), ref.aff_g2l = q.aff_now;
         reqs.push_back(dsm_host::RefRequest{q.nxt, &ref, q.cur, (int)k.pu.size(), k.pu.data(), k.pv.data(), k.pid.data(), k.pw.data()});
       }
-      dsm_host::setCoarseTrackingRefs(ctx, reqs);
+      timed("setCoarseTrackingRefs", [&] { dsm_host::setCoarseTrackingRefs(ctx, reqs); });
       const std::vector<int> made = want_kf;
       want_kf.clear();
       for (int s : made) {
@@ -787,7 +793,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
         ts.push_back(q.nxt), slots.push_back(DSM_SLOT_NEW_RIGHT), px.push_back(right_px.at(q.frame)), ex.push_back(1.0f);
         ids.push_back(left_id(s, q.frame) + 50000000LL);
       }
-      dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
+      timed("hand-over right images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids); });
       for (int s : want_scale) {
         Seq &q = seqs[s];
         if (q.trapped)
@@ -817,7 +823,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
           q.t_start = t0;
           ts.push_back(q.cur), slots.push_back(DSM_SLOT_NEW_LEFT), px.push_back(left_px[q.frame]), ex.push_back(1.0f), ids.push_back(left_id(s, q.frame));
         }
-        dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids);
+        timed("hand-over left images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids); });
         bool again = false;
         for (int s : who) {
           Seq &q = seqs[s];
@@ -877,7 +883,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
       q.scale_fails = ok ? 0 : q.scale_fails + 1;
       if (q.scale_fails > 5) q.trapped = false;
       if (ok) {
-        q.nxt->scaleCoarseDepthL0(new_scale);
+        timed("scaleCoarseDepthL0", [&] { q.nxt->scaleCoarseDepthL0(new_scale); });
         q.trapped = true;
       }
       finish_kf(q);
@@ -888,10 +894,10 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
       if (iter > 100 * P.n_frames * 8) throw std::runtime_error("concurrent replay: no progress");
       start_frames(iter);
       submit_scales();
-      stream.advance();
+      timed("stream.advance", [&] { stream.advance(); });
       R.advances++;
       res.clear();
-      stream.results(res);
+      timed("stream.results", [&] { stream.results(res); });
       for (const dsm_stream_result &r : res) {
         const auto it = owner.find(r.ticket);
         if (it == owner.end()) throw std::runtime_error("concurrent replay: unknown ticket");
@@ -1029,10 +1035,14 @@ int main(int argc, char **argv) {
            "(a frame's first hypothesis, or its keyframe's scale guesses), hand-over, setCoarseTrackingRef and tracker swap as in the one-sequence run; no loop descriptors\", "
            "\"sequences\": %d, \"pipelined_advances\": %s, \"frames\": %lld, \"wall_ms\": %.3f, \"frames_per_s\": %.1f, \"ms_per_frame_of_one_sequence\": %.4f, "
            "\"mean_frame_latency_ms\": %.4f, \"max_frame_latency_ms\": %.4f, \"advances\": %d, \"frames_through_the_whole_hypothesis_list\": %d, \"frames_lost\": %d, "
-           "\"max_ate_vs_ground_truth_m\": %.6g, \"max_abs_trajectory_diff_vs_the_one_sequence_run_m\": %.6g, \"scales_equal_the_one_sequence_run\": %s}",
+           "\"max_ate_vs_ground_truth_m\": %.6g, \"max_abs_trajectory_diff_vs_the_one_sequence_run_m\": %.6g, \"scales_equal_the_one_sequence_run\": %s",
            cc.sequences, cc.sequences, conc_pipelined ? "true" : "false", cc.frames, cc.wall_ms, 1e3 * (double)cc.frames / cc.wall_ms,
            cc.wall_ms * cc.sequences / (double)cc.frames, cc.latency_ms_sum / (double)cc.frames, cc.latency_ms_max, cc.advances, cc.fallbacks, cc.lost, ate_max, dmax,
            scales_equal ? "true" : "false");
+    printf(", \"host_ms_per_advance_by_call\": {");
+    bool first = true;
+    for (const auto &kv : cc.host_ms) printf("%s\"%s\": %.4f", first ? "" : ", ", kv.first.c_str(), kv.second / std::max(1, cc.advances)), first = false;
+    printf("%s\"whole loop\": %.4f}}", first ? "" : ", ", cc.wall_ms / std::max(1, cc.advances));
   }
   printf("}\n");
   return 0;
