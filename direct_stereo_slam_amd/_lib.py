@@ -151,6 +151,7 @@ SYMBOLS = {
     "dsm_tracker_upload_image": (C.c_int, [_vp, C.c_int, c_float_p, C.c_float]),
     "dsm_upload_images": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
     "dsm_upload_images_async": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
+    "dsm_upload_images_enqueue": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p, C.POINTER(_vp), c_float_p, C.c_int, C.c_size_t]),
     "dsm_upload_wait": (C.c_int, [_vp]),
     "dsm_frames_advance": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), c_int_p]),
     "dsm_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),

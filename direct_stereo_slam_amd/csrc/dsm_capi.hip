@@ -293,6 +293,8 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipHostFree(ctx->h_queue);
   hipHostFree(ctx->h_status);
   hipFree(ctx->d_stage);
+  if (ctx->h_tpl_stage) hipHostFree(ctx->h_tpl_stage);
+  if (ctx->h_tpl_counts) hipHostFree(ctx->h_tpl_counts);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->join_events) hipEventDestroy(ev);
   if (ctx->companion_stream) hipStreamDestroy(ctx->companion_stream);
@@ -528,29 +530,72 @@ int dsm_set_refs_from_points(dsm_context *ctx, int n_jobs, const dsm_ref_job *jo
     const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, J.npts);
     off[j + 1] = off[j] + ((floats + 63) & ~(size_t)63);
   }
-  int rc = ensure_stage(ctx, off[n_jobs]);
+  // ONE launch sequence for all jobs (template_kernels.hip: blockIdx.y = job), ONE host->device copy for their points and the job table
+  // (staged in page-locked memory), ONE copy back for their counts.  Device layout of the staging area: [workspaces | points | counts |
+  // job table]; the pinned mirror holds [points | job table] and, separately, the counts.
+  dsm_tracker *t0 = jobs[0].t;
+  for (int j = 1; j < n_jobs; j++)
+    if (jobs[j].t->w != t0->w || jobs[j].t->h != t0->h || jobs[j].t->nlevels != t0->nlevels)
+      return invalid("dsm_set_refs_from_points: trackers of different geometry in one call");
+  std::vector<size_t> poff((size_t)n_jobs + 1, 0);
+  int max_npts = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    poff[j + 1] = poff[j] + ((4 * (size_t)jobs[j].npts + 3) & ~(size_t)3);
+    if (jobs[j].npts > max_npts) max_npts = jobs[j].npts;
+  }
+  const size_t ws_floats = off[n_jobs], pt_floats = poff[n_jobs], cnt_floats = ((size_t)n_jobs * (DSM_MAX_LEVELS + 2) + 3) & ~(size_t)3;
+  const size_t tab_floats = (sizeof(TplJob) * (size_t)n_jobs + 3) / 4;
+  int rc = ensure_stage(ctx, ws_floats + pt_floats + cnt_floats + tab_floats + 16);
   if (rc) return rc;
-  std::vector<int> h_n((size_t)n_jobs * (DSM_MAX_LEVELS + 1), 0);
+  const size_t host_floats = pt_floats + tab_floats + 16;
+  if (host_floats > ctx->tpl_stage_floats) {
+    if (ctx->h_tpl_stage) DSM_HIP(hipHostFree(ctx->h_tpl_stage));
+    ctx->h_tpl_stage = nullptr, ctx->tpl_stage_floats = 0;
+    DSM_HIP(hipHostMalloc(&ctx->h_tpl_stage, sizeof(float) * host_floats * 2, hipHostMallocDefault));
+    ctx->tpl_stage_floats = host_floats * 2;
+  }
+  if ((size_t)n_jobs * (DSM_MAX_LEVELS + 2) > ctx->tpl_counts_cap) {
+    if (ctx->h_tpl_counts) DSM_HIP(hipHostFree(ctx->h_tpl_counts));
+    ctx->h_tpl_counts = nullptr, ctx->tpl_counts_cap = 0;
+    DSM_HIP(hipHostMalloc(&ctx->h_tpl_counts, sizeof(int) * (size_t)n_jobs * (DSM_MAX_LEVELS + 2) * 2, hipHostMallocDefault));
+    ctx->tpl_counts_cap = (size_t)n_jobs * (DSM_MAX_LEVELS + 2) * 2;
+  }
+  float *d_ws = ctx->d_stage, *d_pt = d_ws + ws_floats;
+  int *d_cnt = (int *)(d_pt + pt_floats);
+  TplJob *d_tab = (TplJob *)((float *)d_cnt + cnt_floats);
+  float *h_pt = ctx->h_tpl_stage;
+  TplJob *h_tab = (TplJob *)(h_pt + pt_floats);
   for (int j = 0; j < n_jobs; j++) {
     const dsm_ref_job &J = jobs[j];
     dsm_tracker *t = J.t;
     t->have_ref = false; // (until its counts are back)
-    float *ws = ctx->d_stage + off[j];
-    const size_t floats = make_coarse_depth_workspace_floats(t->w, t->h, t->nlevels, J.npts), np_ = (size_t)J.npts;
-    if (J.npts > 0) {
-      DSM_HIP(hipMemcpyAsync(ws, J.pu, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
-      DSM_HIP(hipMemcpyAsync(ws + np_, J.pv, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
-      DSM_HIP(hipMemcpyAsync(ws + 2 * np_, J.pidepth, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
-      DSM_HIP(hipMemcpyAsync(ws + 3 * np_, J.pweight, sizeof(float) * np_, hipMemcpyHostToDevice, ctx->stream));
+    const size_t np_ = (size_t)J.npts;
+    float *hp = h_pt + poff[j];
+    if (np_) {
+      memcpy(hp, J.pu, sizeof(float) * np_);
+      memcpy(hp + np_, J.pv, sizeof(float) * np_);
+      memcpy(hp + 2 * np_, J.pidepth, sizeof(float) * np_);
+      memcpy(hp + 3 * np_, J.pweight, sizeof(float) * np_);
     }
-    int *d_n = (int *)(ws + floats - 64);
-    const float *ref[DSM_MAX_LEVELS];
-    for (int l = 0; l < t->nlevels; l++) ref[l] = J.frame_owner->d_img[J.slot][l];
-    launch_make_coarse_depth(ctx->stream, t->w, t->h, t->nlevels, J.npts, ws, ref, kTexel, t->d_pts, d_n);
-    DSM_HIP(hipMemcpyAsync(h_n.data() + (size_t)j * (DSM_MAX_LEVELS + 1), d_n, sizeof(int) * (t->nlevels + 1), hipMemcpyDeviceToHost, ctx->stream));
+    TplJob &T = h_tab[j];
+    memset(&T, 0, sizeof T);
+    T.npts = J.npts;
+    T.pt = d_pt + poff[j];
+    T.ws = d_ws + off[j];
+    T.d_n = d_cnt + (size_t)j * (DSM_MAX_LEVELS + 2);
+    for (int l = 0; l < t->nlevels; l++) T.ref[l] = J.frame_owner->d_img[J.slot][l], T.pts[l] = t->d_pts[l];
   }
+  // (points and job table are contiguous in the pinned mirror and on the device up to the counts in between: two copies)
+  if (pt_floats) DSM_HIP(hipMemcpyAsync(d_pt, h_pt, sizeof(float) * pt_floats, hipMemcpyHostToDevice, ctx->stream));
+  DSM_HIP(hipMemcpyAsync(d_tab, h_tab, sizeof(TplJob) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+  launch_make_coarse_depth(ctx->stream, t0->w, t0->h, t0->nlevels, d_tab, n_jobs, max_npts, kTexel);
   DSM_HIP(hipGetLastError());
+  int *h_cnt = ctx->h_tpl_counts;
+  DSM_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int) * (size_t)n_jobs * (DSM_MAX_LEVELS + 2), hipMemcpyDeviceToHost, ctx->stream));
   DSM_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> h_n((size_t)n_jobs * (DSM_MAX_LEVELS + 1), 0);
+  for (int j = 0; j < n_jobs; j++)
+    for (int l = 0; l <= jobs[j].t->nlevels; l++) h_n[(size_t)j * (DSM_MAX_LEVELS + 1) + l] = h_cnt[(size_t)j * (DSM_MAX_LEVELS + 2) + l];
   for (int j = 0; j < n_jobs; j++)
     if (h_n[(size_t)j * (DSM_MAX_LEVELS + 1) + jobs[j].t->nlevels]) // a point projected outside the image: the reference would corrupt memory (:160)
       return invalid("dsm_tracker_set_ref_from_points: point outside the level-0 image");
@@ -589,8 +634,18 @@ int dsm_tracker_scale_depth(dsm_tracker *t, float scale) {
     return DSM_ERR_STATE;
   }
   DSM_HIP(hipSetDevice(t->ctx->device));
-  for (int l = 0; l < t->nlevels; l++) launch_scale_depth(t->ctx->stream, t->desc.lv[l].n, t->d_pts[l], scale);
-  DSM_HIP(hipStreamSynchronize(t->ctx->stream));
+  // one launch over all levels, enqueued on the context's stream and NOT waited for: everything that reads the template afterwards --
+  // evaluations, the streaming form's advances (their stream groups fork from this stream), dsm_tracker_get_template -- is ordered
+  // behind it there (eight keyframes' calls were 0.24 of the 1.9 ms between two advances of 128 concurrent sequences)
+  ScaleDepthArgs a;
+  a.nlevels = t->nlevels;
+  int max_n = 0;
+  for (int l = 0; l < t->nlevels; l++) {
+    a.n[l] = t->desc.lv[l].n, a.pts[l] = t->d_pts[l];
+    if (a.n[l] > max_n) max_n = a.n[l];
+  }
+  launch_scale_depth_levels(t->ctx->stream, a, max_n, scale);
+  DSM_HIP(hipGetLastError());
   return DSM_OK;
 }
 
@@ -725,7 +780,7 @@ static void upload_mark(dsm_tracker *t, int slot, float exposure) {
 // async = false: copies and pyramids ordered on the context's stream, returns when the copies are through.
 // async = true: everything on the context's upload stream, returns at once; dsm_upload_wait waits for the copies.
 static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
-                              const float *ab_exposures, int pixel_type, size_t row_pitch_bytes, bool async) {
+                              const float *ab_exposures, int pixel_type, size_t row_pitch_bytes, bool async, bool nowait = false) {
   if (!ctx || n < 0 || (n > 0 && (!trackers || !slots || !images)))
     return invalid("dsm_upload_images: bad argument");
   if (pixel_type != DSM_PIXEL_F32 && pixel_type != DSM_PIXEL_U8) return invalid("dsm_upload_images: bad pixel type");
@@ -755,6 +810,10 @@ static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *track
   if (ctx->upload_pending) {
     DSM_HIP(hipEventSynchronize(ctx->upload_copies_event));
     ctx->upload_pending = false;
+  }
+  if (ctx->enqueue_pending) { // (dsm_upload_images_enqueue: its copy kernel still reads the job table and the caller's buffers)
+    DSM_HIP(hipEventSynchronize(ctx->copy_event));
+    ctx->enqueue_pending = false;
   }
   if (n > ctx->pyr_jobs_cap) {
     if (ctx->upload_stream) DSM_HIP(hipStreamSynchronize(ctx->upload_stream)); // pyramid kernels read the old table
@@ -806,7 +865,10 @@ static int upload_images_impl(dsm_context *ctx, int n, dsm_tracker *const *track
     DSM_HIP(hipEventRecord(async ? ctx->upload_copies_event : ctx->copy_event, work));
     launch_pyramid_batched(work, t0->w, t0->h, t0->nlevels, ctx->d_pyr_jobs, n, u8);
     DSM_HIP(hipGetLastError());
-    if (!async) DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
+    if (!async && nowait)
+      ctx->enqueue_pending = true; // (waited for by the next hand-over or dsm_upload_wait)
+    else if (!async)
+      DSM_HIP(hipEventSynchronize(ctx->copy_event)); // the caller's buffers are free; the pyramid kernels run on behind
   } else {
     // the staging buffers may still be read by the pyramid kernels of the previous hand-over
     DSM_HIP(hipEventRecord(ctx->copy_event, work));
@@ -857,12 +919,24 @@ int dsm_upload_images_async(dsm_context *ctx, int n, dsm_tracker *const *tracker
   return upload_images_impl(ctx, n, trackers, slots, images, ab_exposures, pixel_type, row_pitch_bytes, true);
 }
 
+int dsm_upload_images_enqueue(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                              const float *ab_exposures, int pixel_type, size_t row_pitch_bytes) {
+  for (int i = 0; trackers && slots && i < n; i++)
+    if (slots[i] > 1) return invalid("dsm_upload_images_enqueue: front buffers only (slots 0 / 1)");
+  return upload_images_impl(ctx, n, trackers, slots, images, ab_exposures, pixel_type, row_pitch_bytes, false, true);
+}
+
 int dsm_upload_wait(dsm_context *ctx) {
   if (!ctx) return invalid("dsm_upload_wait: null context");
   if (ctx->upload_pending) {
     DSM_HIP(hipSetDevice(ctx->device));
     DSM_HIP(hipEventSynchronize(ctx->upload_copies_event));
     ctx->upload_pending = false;
+  }
+  if (ctx->enqueue_pending) {
+    DSM_HIP(hipSetDevice(ctx->device));
+    DSM_HIP(hipEventSynchronize(ctx->copy_event));
+    ctx->enqueue_pending = false;
   }
   return DSM_OK;
 }

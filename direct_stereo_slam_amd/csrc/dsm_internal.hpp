@@ -43,6 +43,7 @@ struct dsm_context {
   hipStream_t upload_stream = nullptr;
   hipEvent_t upload_copies_event = nullptr, upload_done_event = nullptr;
   bool upload_pending = false;
+  bool enqueue_pending = false; // dsm_upload_images_enqueue: copy_event not yet waited for
   int async_copy_blocks = 48;  // workgroups of the host-read kernel of the asynchronous hand-over (measured: DESIGN.md section 2)
   std::vector<hipEvent_t> upload_events;
   dsm::PyrJob *d_pyr_jobs = nullptr, *h_pyr_jobs = nullptr; // h: pinned
@@ -70,6 +71,11 @@ struct dsm_context {
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;
+  // dsm_set_refs_from_points: page-locked mirror of the jobs' points and job table, and of their counts
+  float *h_tpl_stage = nullptr;
+  size_t tpl_stage_floats = 0;
+  int *h_tpl_counts = nullptr;
+  size_t tpl_counts_cap = 0;
   // speculative launch schedule per mode (0 = track, 1 = scale, 2 = loop-closure pose) and level, adapted after every call
   int sched[3][DSM_MAX_LEVELS] = {{6, 8, 10, 12, 16, 16}, {4, 4, 4, 4, 4, 4}, {6, 8, 10, 12, 16, 16}};
   // ... and the number of launches after which only a level's stragglers are still at work (the third quartile of the

@@ -129,16 +129,29 @@ void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *
                    int *status_out, int max_px, bool spec);
 bool coarse_level_fits(int w, int h, int n, int max_px);
 
-// row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip)
+// row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip), batched over the keyframes of a call
+struct TplJob {
+  int npts, pad;
+  const float *pt; // [pu | pv | pidepth | pweight], npts each
+  float *ws;       // make_coarse_depth_workspace_floats() floats
+  const float *ref[DSM_MAX_LEVELS];
+  float4 *pts[DSM_MAX_LEVELS];
+  int *d_n; // nlevels + 1 ints: template points per level, then the out-of-bounds flag
+};
 size_t make_coarse_depth_workspace_floats(int w, int h, int nlevels, int npts);
-void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, int npts, float *ws, const float *const *ref,
-                              int texel_floats, float4 *const *pts, int *d_n);
+void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, const TplJob *jobs, int njobs, int max_npts, int texel_floats);
 
 void launch_interleave_template(hipStream_t s, int n, const float *u, const float *v, const float *id,
                                 const float *c, float4 *out);
 void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float *u, float *v, float *id,
                                   float *c);
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale);
+struct ScaleDepthArgs { // every level of one template in one launch (blockIdx.y = level)
+  int nlevels;
+  int n[DSM_MAX_LEVELS];
+  float4 *pts[DSM_MAX_LEVELS];
+};
+void launch_scale_depth_levels(hipStream_t s, const ScaleDepthArgs &a, int max_n, float scale);
 // Template lists are allocated with this many entries of slack (zeroed): the evaluation loop prefetches template entries up to
 // three trips (3 x 256 points) past the end of a chunk without clamping the index; what it reads there is never used (masked)
 constexpr int kTemplatePad = 1024;

@@ -15,44 +15,75 @@
 
 namespace dsm {
 
-__global__ void tpl_splat_link_kernel(int npts, const float *__restrict__ pu, const float *__restrict__ pv, int w, int h,
-                                      int *__restrict__ head, int *__restrict__ next, int *__restrict__ err) {
+// One job = one keyframe's template (dsm_set_refs_from_points builds the templates of every sequence that made a keyframe in the same
+// advance with ONE launch sequence: blockIdx.y = job; a per-job launch sequence was 26 launches x the jobs of a call, 1.1 of the 1.9 ms a
+// node serving 128 sequences spent between two advances).  All jobs of a call share w, h and the level count.
+struct TplView { // the pieces of a job's workspace (TplJob::ws), as launch_make_coarse_depth lays them out
+  const float *pu, *pv, *pid, *pw;
+  int *next, *head;
+  float *idA, *wsA, *idB, *wsB;
+  int *block_count;
+};
+__device__ __forceinline__ TplView tpl_view(const TplJob &J, int w, int h, int px_total) {
+  TplView V;
+  V.pu = J.pt, V.pv = V.pu + J.npts, V.pid = V.pv + J.npts, V.pw = V.pid + J.npts;
+  V.next = (int *)J.ws;
+  V.head = V.next + J.npts;
+  V.idA = (float *)(V.head + (size_t)w * h);
+  V.wsA = V.idA + px_total, V.idB = V.wsA + px_total, V.wsB = V.idB + px_total;
+  V.block_count = (int *)(V.wsB + px_total);
+  return V;
+}
+
+__global__ void tpl_init_kernel(const TplJob *__restrict__ jobs, int w, int h, int nlevels, int px_total) {
+  const TplJob J = jobs[blockIdx.y];
+  const TplView V = tpl_view(J, w, h, px_total);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < w * h) V.head[p] = -1;
+  if (p <= nlevels) J.d_n[p] = 0;
+}
+
+__global__ void tpl_splat_link_kernel(const TplJob *__restrict__ jobs, int w, int h, int nlevels, int px_total) {
+  const TplJob J = jobs[blockIdx.y];
+  const TplView V = tpl_view(J, w, h, px_total);
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= npts) return;
-  const int u = (int)(pu[k] + 0.5f); // :151-152
-  const int v = (int)(pv[k] + 0.5f);
+  if (k >= J.npts) return;
+  const int u = (int)(V.pu[k] + 0.5f); // :151-152
+  const int v = (int)(V.pv[k] + 0.5f);
   if (u < 0 || v < 0 || u >= w || v >= h) { // the reference would write out of bounds
-    atomicOr(err, 1);
-    next[k] = -2;
+    atomicOr(J.d_n + nlevels, 1);
+    V.next[k] = -2;
     return;
   }
-  next[k] = atomicExch(&head[u + w * v], k);
+  V.next[k] = atomicExch(&V.head[u + w * v], k);
 }
 
 // one thread per level-0 pixel: sum this pixel's points in ascending point index (:160-161)
-__global__ void tpl_splat_sum_kernel(int npix, const int *__restrict__ head, const int *__restrict__ next,
-                                     const float *__restrict__ pidepth, const float *__restrict__ pweight,
-                                     float *__restrict__ idepth0, float *__restrict__ wsum0) {
+__global__ void tpl_splat_sum_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total) {
+  const TplJob J = jobs[blockIdx.y];
+  const TplView V = tpl_view(J, w, h, px_total);
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
+  if (p >= w * h) return;
   float sid = 0.f, sw = 0.f;
-  const int hd = head[p];
+  const int hd = V.head[p];
   int last = -1;
   while (hd >= 0) {
     int best = 0x7FFFFFFF;
-    for (int j = hd; j >= 0; j = next[j])
+    for (int j = hd; j >= 0; j = V.next[j])
       if (j > last && j < best) best = j;
     if (best == 0x7FFFFFFF) break;
-    sid += pidepth[best] * pweight[best];
-    sw += pweight[best];
+    sid += V.pid[best] * V.pw[best];
+    sw += V.pw[best];
     last = best;
   }
-  idepth0[p] = sid;
-  wsum0[p] = sw;
+  V.idA[p] = sid;
+  V.wsA[p] = sw;
 }
 
-__global__ void tpl_pyr_sum_kernel(int wl, int hl, int wlm1, const float *__restrict__ idm, const float *__restrict__ wsm,
-                                   float *__restrict__ idl, float *__restrict__ wsl) {
+__global__ void tpl_pyr_sum_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total, int wl, int hl, int wlm1, int prev, int off) {
+  const TplView V = tpl_view(jobs[blockIdx.y], w, h, px_total);
+  const float *idm = V.idA + prev, *wsm = V.wsA + prev;
+  float *idl = V.idA + off, *wsl = V.wsA + off;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= wl * hl) return;
   const int x = i % wl, y = i / wl;
@@ -62,21 +93,23 @@ __global__ void tpl_pyr_sum_kernel(int wl, int hl, int wlm1, const float *__rest
 }
 
 // :190-233 (levels 0-1, diagonal neighbours) / :236-275 (levels >= 2, axis neighbours)
-__global__ void tpl_dilate_kernel(int wl, int hl, int diagonal, const float *__restrict__ idl_in, const float *__restrict__ bak,
-                                  float *__restrict__ idl_out, float *__restrict__ ws_out) {
+__global__ void tpl_dilate_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total, int wl, int hl, int diagonal, int off) {
+  const TplView V = tpl_view(jobs[blockIdx.y], w, h, px_total);
+  const float *idl_in = V.idA + off, *bak = V.wsA + off;
+  float *idl_out = V.idB + off, *ws_out = V.wsB + off;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int npix = wl * hl;
   if (i >= npix) return;
   float id = idl_in[i], ws = bak[i];
   if (i >= wl && i < npix - wl && ws <= 0) {
     const int o0 = diagonal ? 1 + wl : 1, o1 = diagonal ? -1 - wl : -1, o2 = diagonal ? wl - 1 : wl, o3 = diagonal ? -wl + 1 : -wl;
-    const int off[4] = {o0, o1, o2, o3};
+    const int offs[4] = {o0, o1, o2, o3};
     float sum = 0, num = 0, numn = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (bak[i + off[k]] > 0) {
-        sum += idl_in[i + off[k]];
-        num += bak[i + off[k]];
+      if (bak[i + offs[k]] > 0) {
+        sum += idl_in[i + offs[k]];
+        num += bak[i + offs[k]];
         numn++;
       }
     if (numn > 0) {
@@ -103,9 +136,11 @@ __device__ __forceinline__ bool tpl_emit_item(int item, int wi, int wl, const fl
   return __builtin_isfinite(color) && id > 0;
 }
 
-__global__ __launch_bounds__(kEmitThreads) void tpl_emit_count_kernel(int nitems, int wi, int wl, const float *__restrict__ idl,
-                                                                      const float *__restrict__ ws, const float *__restrict__ ref,
-                                                                      int texel_floats, int *__restrict__ block_count) {
+__global__ __launch_bounds__(kEmitThreads) void tpl_emit_count_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total, int lvl,
+                                                                      int nitems, int wi, int wl, int off, int texel_floats) {
+  const TplJob J = jobs[blockIdx.y];
+  const TplView V = tpl_view(J, w, h, px_total);
+  const float *idl = V.idB + off, *ws = V.wsB + off, *ref = J.ref[lvl];
   __shared__ int wave_cnt[kEmitThreads / 64];
   const int base = blockIdx.x * kEmitBlock;
   int c = 0;
@@ -117,11 +152,13 @@ __global__ __launch_bounds__(kEmitThreads) void tpl_emit_count_kernel(int nitems
   }
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) block_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  if (threadIdx.x == 0) V.block_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-// exclusive scan of the block counts by one workgroup (<= 1024 counts per pass, carried), total -> *n_out
-__global__ __launch_bounds__(1024) void tpl_emit_scan_kernel(int nblocks, int *__restrict__ block_count, int *__restrict__ n_out) {
+// exclusive scan of the block counts by one workgroup per job (<= 1024 counts per pass, carried), total -> d_n[lvl]
+__global__ __launch_bounds__(1024) void tpl_emit_scan_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total, int lvl, int nblocks) {
+  const TplJob J = jobs[blockIdx.y];
+  int *block_count = tpl_view(J, w, h, px_total).block_count;
   __shared__ int s[1024];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
@@ -142,13 +179,16 @@ __global__ __launch_bounds__(1024) void tpl_emit_scan_kernel(int nblocks, int *_
     if (threadIdx.x == 1023) carry += s[1023];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_out = carry;
+  if (threadIdx.x == 0) J.d_n[lvl] = carry;
 }
 
-__global__ __launch_bounds__(kEmitThreads) void tpl_emit_write_kernel(int nitems, int wi, int wl, const float *__restrict__ idl,
-                                                                      const float *__restrict__ ws, const float *__restrict__ ref,
-                                                                      int texel_floats, const int *__restrict__ block_offset,
-                                                                      float4 *__restrict__ pts) {
+__global__ __launch_bounds__(kEmitThreads) void tpl_emit_write_kernel(const TplJob *__restrict__ jobs, int w, int h, int px_total, int lvl,
+                                                                      int nitems, int wi, int wl, int off, int texel_floats) {
+  const TplJob J = jobs[blockIdx.y];
+  const TplView V = tpl_view(J, w, h, px_total);
+  const float *idl = V.idB + off, *ws = V.wsB + off, *ref = J.ref[lvl];
+  const int *block_offset = V.block_count;
+  float4 *pts = J.pts[lvl];
   __shared__ int wave_cnt[kEmitItems][kEmitThreads / 64];
   const int base = blockIdx.x * kEmitBlock;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,62 +207,52 @@ __global__ __launch_bounds__(kEmitThreads) void tpl_emit_write_kernel(int nitems
   int pos = block_offset[blockIdx.x];
 #pragma unroll
   for (int j = 0; j < kEmitItems; j++) {
-    int off = pos;
-    for (int w2 = 0; w2 < wave; w2++) off += wave_cnt[j][w2];
-    if (v[j]) pts[off + before[j]] = e[j];
+    int off2 = pos;
+    for (int w2 = 0; w2 < wave; w2++) off2 += wave_cnt[j][w2];
+    if (v[j]) pts[off2 + before[j]] = e[j];
     pos += wave_cnt[j][0] + wave_cnt[j][1] + wave_cnt[j][2] + wave_cnt[j][3];
   }
 }
 
+// floats of a job's workspace (everything but its points, which live in the call's point region)
 size_t make_coarse_depth_workspace_floats(int w, int h, int nlevels, int npts) {
   size_t px = 0;
   for (int l = 0; l < nlevels; l++) px += (size_t)(w >> l) * (h >> l);
   const size_t blocks = ((size_t)w * h + kEmitBlock - 1) / kEmitBlock + 1;
-  return 4 * px + (size_t)w * h + 5 * (size_t)npts + blocks + 64;
+  return 4 * px + (size_t)w * h + (size_t)npts + blocks + 64;
 }
 
-// ws: workspace of make_coarse_depth_workspace_floats() floats.  d_pt: [pu | pv | pidepth | pweight] (npts each), already
-// on the device at the start of ws.  ref[l]: the keyframe's pyramid level l (texel_floats = kTexel: the intensity plane).  pts[l]: float4
-// template buffers.  d_n: nlevels + 1 ints on the device: n per level, then the out-of-bounds flag.
-void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, int npts, float *ws, const float *const *ref,
-                              int texel_floats, float4 *const *pts, int *d_n) {
-  float *pu = ws, *pv = pu + npts, *pid = pv + npts, *pw = pid + npts;
-  int *next = (int *)(pw + npts);
-  int *head = next + npts;
-  float *lvl_base = (float *)(head + (size_t)w * h);
-  size_t px = 0;
-  for (int l = 0; l < nlevels; l++) px += (size_t)(w >> l) * (h >> l);
-  float *idA = lvl_base, *wsA = idA + px, *idB = wsA + px, *wsB = idB + px;
-  int *block_count = (int *)(wsB + px);
-  int *err = d_n + nlevels;
-  hipMemsetAsync(head, 0xFF, sizeof(int) * (size_t)w * h, s);
-  hipMemsetAsync(d_n, 0, sizeof(int) * (nlevels + 1), s);
-  if (npts > 0) hipLaunchKernelGGL(tpl_splat_link_kernel, dim3((npts + 255) / 256), dim3(256), 0, s, npts, pu, pv, w, h, head, next, err);
-  hipLaunchKernelGGL(tpl_splat_sum_kernel, dim3((w * h + 255) / 256), dim3(256), 0, s, w * h, head, next, pid, pw, idA, wsA);
-  size_t off = 0;
+// jobs: device table of njobs entries (ws = make_coarse_depth_workspace_floats() floats each; pt = [pu | pv | pidepth | pweight], npts
+// each, on the device; ref[l] = the keyframe's pyramid level l (texel_floats = kTexel: the intensity plane); pts[l] = the float4
+// template buffers; d_n = nlevels + 1 ints: n per level, then the out-of-bounds flag).  max_npts = the largest npts of the table.
+void launch_make_coarse_depth(hipStream_t s, int w, int h, int nlevels, const TplJob *jobs, int njobs, int max_npts, int texel_floats) {
+  if (njobs <= 0) return;
+  int px = 0;
+  for (int l = 0; l < nlevels; l++) px += (w >> l) * (h >> l);
+  const unsigned J = (unsigned)njobs;
+  hipLaunchKernelGGL(tpl_init_kernel, dim3((w * h + 255) / 256, J), dim3(256), 0, s, jobs, w, h, nlevels, px);
+  if (max_npts > 0) hipLaunchKernelGGL(tpl_splat_link_kernel, dim3((max_npts + 255) / 256, J), dim3(256), 0, s, jobs, w, h, nlevels, px);
+  hipLaunchKernelGGL(tpl_splat_sum_kernel, dim3((w * h + 255) / 256, J), dim3(256), 0, s, jobs, w, h, px);
+  int off = 0;
   for (int l = 1; l < nlevels; l++) {
-    const size_t prev = off;
-    off += (size_t)(w >> (l - 1)) * (h >> (l - 1));
+    const int prev = off;
+    off += (w >> (l - 1)) * (h >> (l - 1));
     const int wl = w >> l, hl = h >> l;
-    hipLaunchKernelGGL(tpl_pyr_sum_kernel, dim3((wl * hl + 255) / 256), dim3(256), 0, s, wl, hl, w >> (l - 1), idA + prev, wsA + prev,
-                       idA + off, wsA + off);
+    hipLaunchKernelGGL(tpl_pyr_sum_kernel, dim3((wl * hl + 255) / 256, J), dim3(256), 0, s, jobs, w, h, px, wl, hl, w >> (l - 1), prev, off);
   }
   off = 0;
   for (int l = 0; l < nlevels; l++) {
     const int wl = w >> l, hl = h >> l;
-    hipLaunchKernelGGL(tpl_dilate_kernel, dim3((wl * hl + 255) / 256), dim3(256), 0, s, wl, hl, l < 2 ? 1 : 0, idA + off, wsA + off,
-                       idB + off, wsB + off);
+    hipLaunchKernelGGL(tpl_dilate_kernel, dim3((wl * hl + 255) / 256, J), dim3(256), 0, s, jobs, w, h, px, wl, hl, l < 2 ? 1 : 0, off);
     const int wi = wl - 4, hi = hl - 4;
     const int nitems = wi > 0 && hi > 0 ? wi * hi : 0;
     if (nitems > 0) {
       const int nblocks = (nitems + kEmitBlock - 1) / kEmitBlock;
-      hipLaunchKernelGGL(tpl_emit_count_kernel, dim3(nblocks), dim3(kEmitThreads), 0, s, nitems, wi, wl, idB + off, wsB + off, ref[l],
-                         texel_floats, block_count);
-      hipLaunchKernelGGL(tpl_emit_scan_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_count, d_n + l);
-      hipLaunchKernelGGL(tpl_emit_write_kernel, dim3(nblocks), dim3(kEmitThreads), 0, s, nitems, wi, wl, idB + off, wsB + off, ref[l],
-                         texel_floats, block_count, pts[l]);
+      hipLaunchKernelGGL(tpl_emit_count_kernel, dim3(nblocks, J), dim3(kEmitThreads), 0, s, jobs, w, h, px, l, nitems, wi, wl, off, texel_floats);
+      hipLaunchKernelGGL(tpl_emit_scan_kernel, dim3(1, J), dim3(1024), 0, s, jobs, w, h, px, l, nblocks);
+      hipLaunchKernelGGL(tpl_emit_write_kernel, dim3(nblocks, J), dim3(kEmitThreads), 0, s, jobs, w, h, px, l, nitems, wi, wl, off, texel_floats);
     }
-    off += (size_t)wl * hl;
+    off += wl * hl;
   }
 }
 

@@ -2399,6 +2399,14 @@ void launch_deinterleave_template(hipStream_t s, int n, const float4 *in, float 
 void launch_scale_depth(hipStream_t s, int n, float4 *pts, float scale) {
   if (n > 0) hipLaunchKernelGGL(scale_depth_kernel, dim3(grid_for(n)), dim3(256), 0, s, n, pts, scale);
 }
+__global__ void scale_depth_levels_kernel(ScaleDepthArgs a, float scale) {
+  const int l = blockIdx.y, n = a.n[l];
+  float4 *pts = a.pts[l];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pts[i].z = pts[i].z / scale; // (:333, as scale_depth_kernel)
+}
+void launch_scale_depth_levels(hipStream_t s, const ScaleDepthArgs &a, int max_n, float scale) {
+  if (max_n > 0) hipLaunchKernelGGL(scale_depth_levels_kernel, dim3(grid_for(max_n), a.nlevels), dim3(256), 0, s, a, scale);
+}
 
 // ------------------------------------------------------------------------------------------
 // makeImages (upstream DSO FrameHessian::makeImages; call sites FrontEnd.cpp:605,680)

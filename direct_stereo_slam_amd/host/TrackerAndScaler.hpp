@@ -205,15 +205,20 @@ inline void setCoarseTrackingRefs(dsm_context *ctx, const std::vector<RefRequest
 
 // uploadImage for many trackers in ONE hand-over (dsm_upload_images: one staging copy, one pyramid launch sequence, one host
 // synchronisation for all of them) -- what a node serving several sequences does with the frames that arrived together
+// enqueue = true: dsm_upload_images_enqueue -- stream-ordered, no host wait; for page-locked capture buffers that stay untouched until
+// the next hand-over (a frame ring)
 inline void uploadImages(dsm_context *ctx, const std::vector<TrackerAndScaler *> &trackers, const std::vector<int> &slots,
                          const std::vector<const void *> &pixels, int pixel_type, const std::vector<float> &ab_exposures,
-                         const std::vector<long long> &unique_ids, size_t row_pitch_bytes = 0) {
+                         const std::vector<long long> &unique_ids, size_t row_pitch_bytes = 0, bool enqueue = false) {
   const size_t n = trackers.size();
   if (!n) return;
   if (slots.size() != n || pixels.size() != n || ab_exposures.size() != n || unique_ids.size() != n) throw std::runtime_error("uploadImages: sizes differ");
   std::vector<dsm_tracker *> ts(n);
   for (size_t i = 0; i < n; i++) ts[i] = trackers[i]->handle();
-  check(dsm_upload_images(ctx, (int)n, ts.data(), slots.data(), pixels.data(), ab_exposures.data(), pixel_type, row_pitch_bytes), "uploadImages");
+  if (enqueue)
+    check(dsm_upload_images_enqueue(ctx, (int)n, ts.data(), slots.data(), pixels.data(), ab_exposures.data(), pixel_type, row_pitch_bytes), "uploadImages");
+  else
+    check(dsm_upload_images(ctx, (int)n, ts.data(), slots.data(), pixels.data(), ab_exposures.data(), pixel_type, row_pitch_bytes), "uploadImages");
   for (size_t i = 0; i < n; i++) trackers[i]->noteResident(slots[i], unique_ids[i]);
 }
 

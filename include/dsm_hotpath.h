@@ -272,6 +272,13 @@ enum { DSM_SLOT_NEXT_LEFT = 2, DSM_SLOT_NEXT_RIGHT = 3 };
 int dsm_upload_images_async(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
                             const float *ab_exposures, int pixel_type, size_t row_pitch_bytes);
 int dsm_upload_wait(dsm_context *ctx);
+/* dsm_upload_images into the FRONT buffers, stream-ordered: copies and pyramid kernels are enqueued on the context's stream -- every
+ * track / scale call and every dsm_stream_advance issued afterwards finds the frames in place -- and the call returns WITHOUT waiting
+ * for the copies.  For page-locked capture buffers that outlive the hand-over (a node's frame ring): the caller's buffers must stay
+ * untouched until dsm_upload_wait, the next dsm_upload_images* call on the context or any call that synchronises its stream.
+ * Pageable buffers are handed over as dsm_upload_images does (the call then waits for their copies).  No reference counterpart. */
+int dsm_upload_images_enqueue(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots, const void *const *images,
+                              const float *ab_exposures, int pixel_type, size_t row_pitch_bytes);
 int dsm_frames_advance(dsm_context *ctx, int n, dsm_tracker *const *trackers, const int *slots);
 /* pinned host memory for images handed to dsm_tracker_upload_image (straight DMA instead of a staged copy); no reference
  * counterpart -- the reference keeps its images in ordinary host memory */

@@ -793,7 +793,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
         ts.push_back(q.nxt), slots.push_back(DSM_SLOT_NEW_RIGHT), px.push_back(right_px.at(q.frame)), ex.push_back(1.0f);
         ids.push_back(left_id(s, q.frame) + 50000000LL);
       }
-      timed("hand-over right images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids); });
+      timed("hand-over right images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids, 0, true); });
       for (int s : want_scale) {
         Seq &q = seqs[s];
         if (q.trapped)
@@ -823,7 +823,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
           q.t_start = t0;
           ts.push_back(q.cur), slots.push_back(DSM_SLOT_NEW_LEFT), px.push_back(left_px[q.frame]), ex.push_back(1.0f), ids.push_back(left_id(s, q.frame));
         }
-        timed("hand-over left images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids); });
+        timed("hand-over left images", [&] { dsm_host::uploadImages(ctx, ts, slots, px, DSM_PIXEL_U8, ex, ids, 0, true); });
         bool again = false;
         for (int s : who) {
           Seq &q = seqs[s];
