@@ -53,7 +53,17 @@ def test_gpu_leg_matches_the_cpu_leg(ctx, tmp_path):
     g, c, x = d["gpu"], d["cpu"], d["gpu_vs_cpu"]
     assert g["frames_lost"] == 0 and g["hypothesis_tries"] == c["hypothesis_tries"]
     assert x["max_abs_trajectory_diff_m"] < 2e-4 and abs(x["ate_ratio_gpu_over_cpu"] - 1) < 0.01
-    assert x["queries_with_identical_candidates"] >= x["loop_queries"] - 1
+    # end-to-end search parity on EQUAL inputs, no allowance: the device loop detector fed with the clouds the CPU path recorded returns
+    # the CPU path's ring keys, candidates and search_sc matches bit for bit (search_place.h:25-84, ScanContext.cpp:96-141)
+    e = d["device_search_on_the_cpu_paths_clouds"]
+    assert e["queries"] == x["loop_queries"] > 0
+    assert e["ring_keys_bit_equal"] == e["identical_candidates"] == e["identical_search_sc_match"] == e["queries"]
+    # the full replay describes every place from its OWN trajectory (micrometres apart): a query whose candidates differ is listed with
+    # the ring-key entries and the points that changed their polar bin
+    diffs = d["candidate_differences_of_the_full_replay"]
+    assert x["queries_with_identical_candidates"] + len(diffs) >= x["loop_queries"]
+    for q in diffs:
+        assert q["ringkey_entries_that_differ"] or q["points"] or "note" in q
 
 
 @pytest.mark.gpu

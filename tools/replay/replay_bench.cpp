@@ -434,9 +434,16 @@ struct CpuBackend {
 };
 
 // ---- the driver: FrontEnd + LoopHandler reduced to the calls that reach the hot path ----
+struct LoopQuery { // what one marginalised keyframe hands to the loop detector (LoopHandler.cpp:186-262), and the ring key it got
+  std::vector<int> ids, pk;
+  std::vector<double> poses, xyz;
+  double cw[12];
+  std::vector<float> key;
+};
 struct RunResult {
   Timers tm;
   std::vector<SE3> est; // x_cam = T x_w per frame
+  std::vector<LoopQuery> queries;
   std::vector<std::vector<int>> candidates;
   std::vector<int> matched;
   std::vector<float> scales;
@@ -485,19 +492,11 @@ struct WindowKf {
   std::vector<double> world_pts;
 };
 
+// Lap one: the sequence is treated as the SECOND pass over the same places; the first pass's descriptors (the same clouds
+// under 2 cm of noise) are searched and enqueued before the clock starts, followed by LOOP_MARGIN filler keys that flush
+// the delay queue (search_place.h:41-56), so that the timed pass finds candidates and runs search_sc.
 template <class B>
-static RunResult run(B &be, const Pack &P) {
-  RunResult R;
-  SE3 T_kf;
-  AffLight aff_last;
-  double last_rmse0 = 100;
-  bool trapped = false;
-  int scale_fails = 0, n_kf = 0;
-  std::deque<WindowKf> window;
-  std::vector<SigType> signatures; // loop_frames_[i]->signature in search order
-  // Lap one: the sequence is treated as the SECOND pass over the same places; the first pass's descriptors (the same clouds
-  // under 2 cm of noise) are searched and enqueued before the clock starts, followed by LOOP_MARGIN filler keys that flush
-  // the delay queue (search_place.h:41-56), so that the timed pass finds candidates and runs search_sc.
+static void seed_first_pass(B &be, const Pack &P, std::vector<SigType> &signatures) {
   {
     unsigned lcg = 12345u;
     auto noise = [&]() {
@@ -556,6 +555,19 @@ static RunResult run(B &be, const Pack &P) {
       signatures.push_back(SigType());
     }
   }
+}
+
+template <class B>
+static RunResult run(B &be, const Pack &P) {
+  RunResult R;
+  SE3 T_kf;
+  AffLight aff_last;
+  double last_rmse0 = 100;
+  bool trapped = false;
+  int scale_fails = 0, n_kf = 0;
+  std::deque<WindowKf> window;
+  std::vector<SigType> signatures; // loop_frames_[i]->signature in search order
+  seed_first_pass(be, P, signatures);
   for (int i = 0; i < P.n_frames; i++) {
     const auto t_frame = Clock::now();
     auto t0 = Clock::now();
@@ -638,6 +650,12 @@ static RunResult run(B &be, const Pack &P) {
         std::vector<float> key;
         SigType sig;
         be.descriptors(ids, poses, cw, pk, xyz, key, sig, R.tm);
+        {
+          LoopQuery lq;
+          lq.ids = ids, lq.pk = pk, lq.poses = poses, lq.xyz = xyz, lq.key = key;
+          memcpy(lq.cw, cw, sizeof lq.cw);
+          R.queries.push_back(std::move(lq));
+        }
         std::vector<int> cand;
         t0 = Clock::now();
         be.search_ringkey(key, cand);
@@ -919,6 +937,129 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
   return R;
 }
 
+// The loop detector alone, on the inputs ANOTHER run recorded: descriptors, search_ringkey, search_sc query by query from the same seeded
+// index.  With the CPU path's clouds the device search must return the CPU path's ring keys, candidates and matches bit for bit --
+// end-to-end search parity on equal inputs (search_place.h:25-84, ScanContext.cpp:96-141); the candidates of a full replay differ
+// only where the two paths' own trajectories (micrometres apart) put a point on either side of a bin edge.
+struct LoopReplay {
+  std::vector<std::vector<float>> keys;
+  std::vector<std::vector<int>> candidates;
+  std::vector<int> matched;
+};
+template <class B>
+static LoopReplay replay_loop(B &be, const Pack &P, const std::vector<LoopQuery> &qs) {
+  LoopReplay L;
+  std::vector<SigType> signatures;
+  seed_first_pass(be, P, signatures);
+  Timers scratch;
+  for (const LoopQuery &q0 : qs) {
+    LoopQuery q = q0;
+    std::vector<float> key;
+    SigType sig;
+    be.descriptors(q.ids, q.poses, q.cw, q.pk, q.xyz, key, sig, scratch);
+    std::vector<int> cand;
+    be.search_ringkey(key, cand);
+    int matched = -1;
+    float diff = -1;
+    if (!cand.empty()) be.search_sc(sig, signatures, cand, matched, diff);
+    signatures.push_back(sig);
+    L.keys.push_back(key), L.candidates.push_back(cand), L.matched.push_back(matched);
+  }
+  return L;
+}
+
+// Which point changed which polar bin: the two paths' inputs of one query through the product's HOST functions (generate_spherical_points,
+// the PCA frame of ScanContext::generate) and ScanContext.cpp:96-117's binning restated with the frame those functions return.
+struct BinOfPoint {
+  int si, ri;
+  double theta_s, rho_r, x, y, z; // position in units of a sector / a ring, and in the window's frame
+};
+static bool bins_of_query(const LoopQuery &q, double lidar_range, std::vector<BinOfPoint> &out, std::string &why) {
+  const int n_kf = (int)q.ids.size(), n_pts = (int)q.pk.size();
+  std::vector<int> keep(n_kf), sel(n_pts);
+  std::vector<double> sph(3 * (size_t)n_pts);
+  int n_out = 0;
+  if (dsm_generate_spherical_points(n_kf, q.ids.data(), q.poses.data(), q.cw, lidar_range, n_pts, q.pk.data(), q.xyz.data(), keep.data(), &n_out, sel.data(),
+                                    sph.data()) != DSM_OK || n_out < 1) {
+    why = "generate_spherical_points failed";
+    return false;
+  }
+  std::vector<float> key(20);
+  std::vector<int> sidx(1200);
+  std::vector<double> sval(1200);
+  int n_sig = 0;
+  double tfm[16];
+  if (dsm_scancontext_generate(sph.data(), n_out, lidar_range, 60, 20, key.data(), sidx.data(), sval.data(), &n_sig, tfm) != DSM_OK) {
+    why = "scancontext_generate failed";
+    return false;
+  }
+  double mx = 0, my = 0, mz = 0; // (as dsm_scancontext_generate: align_points_PCA, ScanContext.cpp:19-66)
+  for (int i = 0; i < n_out; i++) mx += sph[3 * i], my += sph[3 * i + 1], mz += sph[3 * i + 2];
+  mx /= n_out, my /= n_out, mz /= n_out;
+  double V[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) V[c * 3 + r] = tfm[r * 4 + c];
+  out.clear();
+  for (int i = 0; i < n_out; i++) {
+    const double x = sph[3 * i] - mx, y = sph[3 * i + 1] - my, z = sph[3 * i + 2] - mz;
+    const double yp = x * V[1] + y * V[4] + z * V[7], zp = x * V[2] + y * V[5] + z * V[8];
+    const double rho = std::sqrt(yp * yp + zp * zp);
+    double theta = std::atan2(zp, yp);
+    while (theta < 0) theta += 2.0 * M_PI;
+    while (theta >= 2.0 * M_PI) theta -= 2.0 * M_PI;
+    BinOfPoint b;
+    b.theta_s = theta / (2.0 * M_PI) * 60, b.rho_r = rho / lidar_range * 20;
+    b.si = (int)b.theta_s, b.ri = (int)b.rho_r;
+    b.x = sph[3 * i], b.y = sph[3 * i + 1], b.z = sph[3 * i + 2];
+    out.push_back(b);
+  }
+  return true;
+}
+static void print_candidate_difference(size_t qi, const LoopQuery &g, const LoopQuery &c, double lidar_range) {
+  printf("{\"query\": %d, \"ringkey_entries_that_differ\": [", (int)qi);
+  bool first = true;
+  for (size_t r = 0; r < g.key.size() && r < c.key.size(); r++)
+    if (g.key[r] != c.key[r]) printf("%s{\"ring\": %d, \"occupied_sectors_gpu\": %d, \"occupied_sectors_cpu\": %d}", first ? "" : ", ", (int)r, (int)std::lround(g.key[r] * 60),
+                                     (int)std::lround(c.key[r] * 60)), first = false;
+  printf("], \"points\": [");
+  std::vector<BinOfPoint> bg, bc;
+  std::string why;
+  if (!bins_of_query(g, lidar_range, bg, why) || !bins_of_query(c, lidar_range, bc, why)) {
+    printf("], \"note\": \"%s\"}", why.c_str());
+    return;
+  }
+  // occupancy of the 60 x 20 polar grid on both paths; for every bin only one path fills: its point there and the nearest point of the other path
+  std::vector<int> og(1200, 0), oc(1200, 0);
+  for (const BinOfPoint &b : bg)
+    if (b.ri < 20 && b.si < 60) og[b.si * 20 + b.ri]++;
+  for (const BinOfPoint &b : bc)
+    if (b.ri < 20 && b.si < 60) oc[b.si * 20 + b.ri]++;
+  first = true;
+  int shown = 0;
+  for (int bin = 0; bin < 1200 && shown < 6; bin++) {
+    if ((og[bin] > 0) == (oc[bin] > 0)) continue;
+    const bool on_gpu = og[bin] > 0;
+    const std::vector<BinOfPoint> &A = on_gpu ? bg : bc, &B = on_gpu ? bc : bg;
+    for (const BinOfPoint &a : A) {
+      if (a.ri >= 20 || a.si * 20 + a.ri != bin) continue;
+      double best = 1e300;
+      const BinOfPoint *nb = nullptr;
+      for (const BinOfPoint &b : B) {
+        const double d = (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z);
+        if (d < best) best = d, nb = &b;
+      }
+      if (!nb) continue;
+      printf("%s{\"bin_sector_ring\": [%d, %d], \"filled_on\": \"%s\", \"sector_coordinate\": %.9f, \"ring_coordinate\": %.9f, "
+             "\"same_point_on_the_other_path\": {\"moved_m\": %.3g, \"bin_sector_ring\": [%d, %d], \"sector_coordinate\": %.9f, \"ring_coordinate\": %.9f}}",
+             first ? "" : ", ", a.si, a.ri, on_gpu ? "gpu" : "cpu", a.theta_s, a.rho_r, std::sqrt(best), nb->si, nb->ri, nb->theta_s, nb->rho_r);
+      first = false;
+      shown++;
+      break;
+    }
+  }
+  printf("], \"spherical_points_gpu\": %d, \"spherical_points_cpu\": %d}", (int)bg.size(), (int)bc.size());
+}
+
 static double ate(const std::vector<SE3> &a, const std::vector<SE3> &b) {
   double s = 0;
   for (size_t i = 0; i < a.size(); i++) {
@@ -957,6 +1098,8 @@ int main(int argc, char **argv) {
   const int n_concurrent = argc > 4 ? atoi(argv[4]) : 0;
   const bool conc_pipelined = argc > 5 ? atoi(argv[5]) != 0 : true;
   RunResult rg, rc;
+  LoopReplay eq;
+  bool have_eq = false;
   ConcurrentResult cc;
   bool have_g = false, have_c = false;
   std::vector<int> ids(P.n_frames);
@@ -993,6 +1136,11 @@ int main(int argc, char **argv) {
       have_c = true;
       dsm_host::save_trajectory((prefix + "_dslam_cpu.txt").c_str(), ids, centres(rc.est));
     }
+    if (have_g && have_c) { // the device loop detector on the CPU path's recorded clouds
+      GpuBackend be(P);
+      eq = replay_loop(be, P, rc.queries);
+      have_eq = true;
+    }
   } catch (const std::exception &e) {
     fprintf(stderr, "replay_bench: %s\n", e.what());
     return 3;
@@ -1019,6 +1167,26 @@ int main(int argc, char **argv) {
     printf(", \"gpu_vs_cpu\": {\"max_abs_trajectory_diff_m\": %.6g, \"ate_ratio_gpu_over_cpu\": %.6f, \"loop_queries\": %d, \"queries_with_identical_candidates\": %d, "
            "\"queries_with_identical_search_sc_match\": %d}",
            dmax, ate(rg.est, P.gt) / std::fmax(ate(rc.est, P.gt), 1e-30), (int)rg.candidates.size(), same_cand, same_match);
+    if (have_eq) {
+      int keys_eq = 0, cand_eq = 0, match_eq = 0;
+      for (size_t i = 0; i < eq.candidates.size() && i < rc.candidates.size(); i++) {
+        keys_eq += eq.keys[i].size() == rc.queries[i].key.size() && memcmp(eq.keys[i].data(), rc.queries[i].key.data(), sizeof(float) * eq.keys[i].size()) == 0;
+        cand_eq += eq.candidates[i] == rc.candidates[i];
+        match_eq += eq.matched[i] == rc.matched[i];
+      }
+      printf(", \"device_search_on_the_cpu_paths_clouds\": {\"what\": \"descriptors + search_ringkey + search_sc of the device path fed with the inputs the CPU path recorded "
+             "(equal inputs: must be equal bit for bit)\", \"queries\": %d, \"ring_keys_bit_equal\": %d, \"identical_candidates\": %d, \"identical_search_sc_match\": %d}",
+             (int)eq.candidates.size(), keys_eq, cand_eq, match_eq);
+    }
+    printf(", \"candidate_differences_of_the_full_replay\": [");
+    bool first_diff = true;
+    for (size_t i = 0; i < rg.candidates.size() && i < rc.candidates.size(); i++)
+      if (rg.candidates[i] != rc.candidates[i] || rg.queries[i].key != rc.queries[i].key) {
+        if (!first_diff) printf(", ");
+        first_diff = false;
+        print_candidate_difference(i, rg.queries[i], rc.queries[i], P.lidar_range);
+      }
+    printf("]");
   }
   if (have_g && cc.sequences > 0) {
     double dmax = 0, ate_max = 0;
