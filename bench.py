@@ -135,7 +135,7 @@ def _parse():
     ap.add_argument("--replay", action="store_true", help="run the replay-mode leg alone (config.replay of the default line): one sequence, one frame in flight, C++ adaptors, per-stage ms for the GPU and the CPU path; "
                                                              "then --replay-concurrent sequences through one dsm_host::Stream")
     ap.add_argument("--no-replay-leg", action="store_true", help="skip config.replay in the default line")
-    ap.add_argument("--replay-concurrent", type=int, default=64, help="config.replay.<first shape>.concurrent: this many sequences through ONE dsm_host::Stream from C++ (0: skip)")
+    ap.add_argument("--replay-concurrent", type=int, default=128, help="config.replay.<first shape>.concurrent: this many sequences through ONE dsm_host::Stream from C++ (0: skip)")
     ap.add_argument("--replay-frames", type=int, default=200)
     ap.add_argument("--replay-kf-every", type=int, default=4)
     ap.add_argument("--replay-active", type=int, default=2000, help="active points per keyframe (the semi-dense template grows to ~10^4 points by dilation)")
@@ -1138,6 +1138,57 @@ def replay_leg(args, names=("kitti00", "malaga06")):
     return out
 
 
+def loop_chain_leg(ctx, seqs=64, n_pts=16000, reps=20):
+    """config.loop_chain (VERDICT r04 item 6): the per-keyframe loop chain -- generate_spherical_points, ScanContext::generate,
+    search_ringkey (LoopHandler.cpp:186,236,247) -- through dsm_loop_detect_batch: ONE enqueue and ONE read-back per call, the ring keys
+    handed to the index's k-NN on the device.  Timed for one keyframe per call (one sequence) and for `seqs` keyframes per call (one per
+    concurrent sequence, BASELINE configs[4]); the unfused pair of calls of round 4 beside it.  Clouds: 8 keyframes x 2000 points."""
+    from direct_stereo_slam_amd.ringdb import RingKeyDB, loop_descriptors_batch
+
+    def job(seed):
+        rng = np.random.default_rng(seed)
+        n_kf = 8
+        kf_ids = np.arange(100, 100 + n_kf)
+        poses = np.hstack([rng.normal(0, 5, (n_kf, 3)), rng.normal(0, 0.08, (n_kf, 3))])
+        cur_cw = np.hstack([np.eye(3), rng.normal(0, 1, (3, 1))])
+        pt_kf = rng.choice(kf_ids, n_pts)
+        g = np.stack([rng.uniform(-55, 55, n_pts), 1.6 + rng.normal(0, 0.05, n_pts), rng.uniform(-55, 55, n_pts)], 1)
+        walls = rng.random(n_pts) < 0.35
+        g[walls, 0] = np.where(rng.random(walls.sum()) < 0.5, 8.0, -9.0)
+        g[walls, 1] = rng.uniform(-5, 1.6, walls.sum())
+        return kf_ids, poses, cur_cw, pt_kf, g - cur_cw[:, 3]
+
+    jobs = [job(900 + s) for s in range(seqs)]
+    out = {"workload": f"{seqs} concurrent sequences marginalise a keyframe each: clouds of {n_pts} points (8 keyframes x {n_pts // 8}), lidar_range 40, 60 x 20 polar bins, "
+                       "k = 3 ring-key search in one index"}
+
+    def timed(fn, n):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    # (the job tables are built once, as a node keeps its window's clouds: the C calls alone are timed)
+    from direct_stereo_slam_amd.ringdb import LoopBatch
+
+    db = RingKeyDB(ctx, capacity=1 << 16)
+    one, many = LoopBatch(ctx, jobs[:1], 40.0, db=db, selected_points=False), LoopBatch(ctx, jobs, 40.0, db=db, selected_points=False)
+    out["one_keyframe_per_call_ms"] = timed(one.run, reps * 4)
+    out[f"{seqs}_keyframes_per_call_ms_per_keyframe"] = timed(many.run, reps) / seqs
+    db2 = RingKeyDB(ctx, capacity=1 << 16)
+    desc = LoopBatch(ctx, jobs[:1], 40.0)
+
+    def unfused():
+        desc.run()
+        db2.search_ringkey(desc.outs[0][0]["ringkey"])
+
+    out["one_keyframe_descriptor_call_then_search_call_ms"] = timed(unfused, reps * 4)
+    db.close()
+    db2.close()
+    return out
+
+
 VALU_PEAK_TOPS = 78.6  # MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector counts an FMA as two; unfused add / mul / sub issue at half of that
 
 
@@ -1272,6 +1323,10 @@ def compact_line(res, detail_path):
         legs["ringkey"] = {"error": rk["error"][:120]} if "error" in rk else [
             {"N": k["N"], "Q": k["Q"], "us": _r(k["us_per_call"], 2), "bound": k["roofline"]["bound"], "frac": _r(k["roofline"]["frac"], 2),
              "bit_exact": k["matches_oracle_bit_exact"]} for k in rk.get("cases", [])]
+    lc = c.get("loop_chain")
+    if isinstance(lc, dict):
+        legs["loop_chain_ms_per_keyframe"] = {"error": lc["error"][:120]} if "error" in lc else {
+            ("S1" if k.startswith("one_keyframe_per") else "S64" if "keyframes_per_call" in k else "S1_unfused"): _r(v, 2) for k, v in lc.items() if k != "workload"}
     sh = c.get("ringkey_sharded")
     if isinstance(sh, dict):
         legs["ringkey_sharded"] = {"error": sh["error"][:160]} if "error" in sh else {
@@ -1456,6 +1511,10 @@ def bench_tracking(args):
             res["config"]["ringkey"] = ringkey_single_gpu_leg(args, ctx)
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["ringkey"] = {"error": repr(e)}
+        try:
+            res["config"]["loop_chain"] = loop_chain_leg(ctx)
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            res["config"]["loop_chain"] = {"error": repr(e)}
     stuck = False
     if world > 1 and not args.no_ringkey_leg and args.device_override < 0:  # (RCCL refuses two ranks on one device)
         # A reported extra must never cost the bench line: the leg runs under a deadline (a collective that one rank never

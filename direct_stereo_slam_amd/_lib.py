@@ -193,6 +193,7 @@ SYMBOLS = {
     "dsm_scancontext_generate": (C.c_int, [c_double_p, C.c_int, C.c_double, C.c_int, C.c_int, c_float_p, c_int_p, c_double_p, c_int_p, c_double_p]),
     "dsm_generate_spherical_points": (C.c_int, [C.c_int, c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p]),
     "dsm_loop_descriptors_batch": (C.c_int, [_vp, C.c_int, C.POINTER(LoopJob), C.c_double, C.c_int, C.c_int]),
+    "dsm_loop_detect_batch": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(LoopJob), C.c_double, C.c_int, C.c_int, c_int_p, c_int_p]),
     "dsm_write_trajectory": (C.c_int, [C.c_char_p, C.c_int, c_int_p, c_double_p]),
     "dsm_make_coarse_depth_l0": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, _pp_f, c_int_p, _pp_f, _pp_f, _pp_f, _pp_f]),
     "dsm_sc_distance": (C.c_float, [c_int_p, c_double_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),

@@ -294,6 +294,8 @@ int dsm_context_destroy(dsm_context *ctx) {
   hipHostFree(ctx->h_status);
   hipFree(ctx->d_stage);
   if (ctx->h_tpl_stage) hipHostFree(ctx->h_tpl_stage);
+  hipFree(ctx->loop_dev);
+  if (ctx->loop_pin) hipHostFree(ctx->loop_pin);
   if (ctx->h_tpl_counts) hipHostFree(ctx->h_tpl_counts);
   for (hipEvent_t ev : ctx->ev_pool) hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->join_events) hipEventDestroy(ev);

@@ -71,6 +71,9 @@ struct dsm_context {
   // staging for host->device template / frame uploads
   float *d_stage = nullptr;
   size_t stage_floats = 0;
+  // dsm_loop_descriptors_batch / dsm_loop_detect_batch: device arena and its page-locked mirror (grown on demand)
+  void *loop_dev = nullptr, *loop_pin = nullptr;
+  size_t loop_dev_bytes = 0, loop_pin_bytes = 0;
   // dsm_set_refs_from_points: page-locked mirror of the jobs' points and job table, and of their counts
   float *h_tpl_stage = nullptr;
   size_t tpl_stage_floats = 0;

@@ -26,6 +26,7 @@
 
 #include "dsm_internal.hpp"
 #include "loopdet_internal.hpp"
+#include "ringdb_internal.hpp"
 
 using namespace dsm;
 
@@ -67,7 +68,7 @@ struct JobDev {             // one keyframe
   // ScanContext
   double *moments;            // [0..2] mean, [3..8] cov (xx, xy, xz, yy, yz, zz)
   double mean[3], V[9];       // sc_pca_kernel: centroid and eigenvectors (ScanContext.cpp:41-47)
-  double tfm[16];             // ... and tfm_pca_rig (:55-64)
+  double *tfm_out;            // ... and tfm_pca_rig (:55-64), 16 doubles in the output region
   unsigned long long *bins;   // num_s * num_r order-preserving keys of max_height
   float *ringkey;             // num_r
   int *sig_idx;               // num_s * num_r capacity
@@ -274,14 +275,6 @@ __global__ void sc_finish_kernel(const JobDev *jobs, double lidar_range, int num
   if (t == 0) *J.n_sig = base_sh;
 }
 
-template <class T>
-int dev_alloc(std::vector<void *> &owned, T **p, size_t n) {
-  *p = nullptr;
-  DSM_HIP(hipMalloc((void **)p, sizeof(T) * (n ? n : 1)));
-  owned.push_back(*p);
-  return DSM_OK;
-}
-
 } // namespace
 
 // ScanContext::generate, between the halves (ScanContext.cpp:41-64): 3 x 3 eigen-decomposition of the covariance (the host
@@ -298,16 +291,59 @@ __global__ void sc_pca_kernel(JobDev *jobs, int n_jobs) {
   dsm::eig3_sym(cov, ev, V);
   for (int i = 0; i < 3; i++) J.mean[i] = m[i];
   for (int i = 0; i < 9; i++) J.V[i] = V[i];
-  double *tfm = J.tfm;
+  double *tfm = J.tfm_out;
   for (int i = 0; i < 16; i++) tfm[i] = (i % 5 == 0) ? 1.0 : 0.0;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) tfm[r * 4 + c] = V[c * 3 + r];
   for (int r = 0; r < 3; r++) tfm[r * 4 + 3] = -(tfm[r * 4 + 0] * m[0] + tfm[r * 4 + 1] * m[1] + tfm[r * 4 + 2] * m[2]);
 }
 
-extern "C" {
+// ---- host side: ONE enqueue and ONE read-back per call -------------------------------------------------------------------------------
+// Round 4's form allocated thirteen device buffers per job and freed them at the end (hipFree synchronises), staged its inputs from
+// pageable memory job by job, synchronised three times and copied every small output back on its own: 0.9 ms of host time for ONE
+// keyframe around ~60 us of kernels.  Now: a device arena and a page-locked mirror that live in the context (grown on demand), the
+// inputs of all jobs packed into one host->device copy, the outputs of all jobs packed into one device->host copy, and -- for
+// dsm_loop_detect_batch -- the ring keys handed to the ring-key search ON THE DEVICE between the two.
+namespace {
 
-int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r) {
+struct Arena { // linear sub-allocation of a region that is laid out identically on the device and in the pinned mirror
+  size_t used = 0;
+  size_t take(size_t bytes) {
+    const size_t o = used;
+    used = (used + bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+struct LoopPlan {
+  int n_jobs = 0, nbins = 0, num_r = 0, nblocks = 0;
+  long long cells = 0;
+  std::vector<JobDev> hj;
+  // offsets (bytes) into the input region (pinned + device), the work region (device only), the output region (device + pinned)
+  std::vector<size_t> in_xyz, in_keep, out_small, out_sig_idx, out_sig_val, out_sel, out_sph;
+  size_t in_tab = 0, in_bytes = 0, work_bytes = 0, out_bytes = 0, out_keys = 0, out_cand = 0;
+  bool any_sc = false;
+};
+// per job "small" outputs: [n_out, n_sig, pad, pad][tfm 16 doubles] -- ring keys of all jobs are one contiguous array (out_keys)
+constexpr size_t kSmallBytes = 16 + 16 * sizeof(double);
+
+int grow(dsm_context *ctx, size_t dev_bytes, size_t pin_bytes) {
+  if (dev_bytes > ctx->loop_dev_bytes) {
+    if (ctx->loop_dev) DSM_HIP(hipFree(ctx->loop_dev));
+    ctx->loop_dev = nullptr, ctx->loop_dev_bytes = 0;
+    DSM_HIP(hipMalloc(&ctx->loop_dev, dev_bytes + dev_bytes / 2));
+    ctx->loop_dev_bytes = dev_bytes + dev_bytes / 2;
+  }
+  if (pin_bytes > ctx->loop_pin_bytes) {
+    if (ctx->loop_pin) DSM_HIP(hipHostFree(ctx->loop_pin));
+    ctx->loop_pin = nullptr, ctx->loop_pin_bytes = 0;
+    DSM_HIP(hipHostMalloc(&ctx->loop_pin, pin_bytes + pin_bytes / 2, hipHostMallocDefault));
+    ctx->loop_pin_bytes = pin_bytes + pin_bytes / 2;
+  }
+  return DSM_OK;
+}
+
+int check_jobs(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r, long long *cells_out) {
   if (!ctx || n_jobs < 1 || !jobs || !(lidar_range > 0) || num_s < 1 || num_r < 1 || num_s > kLdThreads || num_r > kLdThreads)
     return invalid("dsm_loop_descriptors_batch: bad argument");
   const long long vs0 = (long long)std::floor(2 * lidar_range * 1.0) + 1, vs1 = (long long)std::floor(2 * lidar_range * 2.0) + 1,
@@ -316,133 +352,249 @@ int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job 
   if (cells > (1ll << 26)) return invalid("dsm_loop_descriptors_batch: lidar_range too large for the dense voxel grid (use the host form)");
   for (int j = 0; j < n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
-    if (J.n_pts < 0 || J.n_kf < 0 || !J.cur_cw || !J.n_out || (J.n_kf && (!J.kf_ids || !J.kf_pose_wc || !J.kf_keep)) ||
-        (J.n_pts && (!J.pt_kf_id || !J.pt_xyz || !J.sel_idx || !J.pts_spherical)) ||
-        (J.ringkey && (!J.sig_idx || !J.sig_val || !J.n_sig || !J.tfm_pca_rig)))
+    if (J.n_pts < 0 || J.n_kf < 0 || !J.cur_cw || !J.n_out || (J.n_kf && (!J.kf_ids || !J.kf_pose_wc || !J.kf_keep)) || (J.n_pts && (!J.pt_kf_id || !J.pt_xyz)) ||
+        ((J.sel_idx == nullptr) != (J.pts_spherical == nullptr)) || (J.ringkey && (!J.sig_idx || !J.sig_val || !J.n_sig || !J.tfm_pca_rig)))
       return invalid("dsm_loop_descriptors_batch: bad job");
   }
+  *cells_out = cells;
+  return DSM_OK;
+}
+
+// everything up to (and without) the read-back: inputs staged and copied, kernels enqueued.  extra_out_bytes: room at the end of the
+// output region for the caller's own device results (the ring-key search's packed candidates); *d_keys / *d_extra: where they live
+int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r, size_t extra_out_bytes, LoopPlan &P,
+                 float **d_keys, void **d_extra) {
+  long long cells = 0;
+  int rc = check_jobs(ctx, n_jobs, jobs, lidar_range, num_s, num_r, &cells);
+  if (rc) return rc;
+  const long long vs0 = (long long)std::floor(2 * lidar_range * 1.0) + 1, vs1 = (long long)std::floor(2 * lidar_range * 2.0) + 1;
   DSM_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  std::vector<void *> owned;
-  struct Free {
-    std::vector<void *> &v;
-    ~Free() {
-      for (void *p : v) hipFree(p);
-    }
-  } guard{owned};
-  const int nbins = num_s * num_r, nblocks = (int)((cells + kLdThreads - 1) / kLdThreads);
-  std::vector<JobDev> hj(n_jobs);
-  std::vector<std::vector<unsigned char>> keep(n_jobs);
+  P.n_jobs = n_jobs, P.nbins = num_s * num_r, P.num_r = num_r, P.cells = cells, P.nblocks = (int)((cells + kLdThreads - 1) / kLdThreads);
+  P.hj.assign(n_jobs, JobDev());
+  P.in_xyz.resize(n_jobs), P.in_keep.resize(n_jobs), P.out_small.resize(n_jobs), P.out_sig_idx.resize(n_jobs), P.out_sig_val.resize(n_jobs);
+  P.out_sel.resize(n_jobs), P.out_sph.resize(n_jobs);
+  Arena in, work, out, side;
+  std::vector<size_t> w_gy(n_jobs), w_gi(n_jobs), w_bc(n_jobs), w_mom(n_jobs), w_bins(n_jobs), w_sel(n_jobs), w_sph(n_jobs);
   int max_pts = 1;
   for (int j = 0; j < n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
-    JobDev &D = hj[j];
+    if (J.n_pts > max_pts) max_pts = J.n_pts;
+    P.any_sc = P.any_sc || J.ringkey;
+    P.in_xyz[j] = in.take(sizeof(double) * 3 * (size_t)J.n_pts);
+    P.in_keep[j] = in.take((size_t)J.n_pts);
+    w_gy[j] = work.take(sizeof(unsigned long long) * (size_t)cells);
+    w_gi[j] = work.take(sizeof(int) * (size_t)cells);
+    w_bc[j] = work.take(sizeof(int) * (size_t)P.nblocks);
+    w_mom[j] = work.take(sizeof(double) * 9);
+    w_bins[j] = work.take(sizeof(unsigned long long) * (size_t)P.nbins);
+    P.out_small[j] = out.take(kSmallBytes);
+    P.out_sig_idx[j] = out.take(sizeof(int) * (size_t)P.nbins);
+    P.out_sig_val[j] = out.take(sizeof(double) * (size_t)P.nbins);
+    // the selected points: read back only where the caller asks for them (0.45 MB per keyframe)
+    if (J.sel_idx) {
+      P.out_sel[j] = out.take(sizeof(int) * (size_t)J.n_pts);
+      P.out_sph[j] = out.take(sizeof(double) * 3 * (size_t)J.n_pts);
+    } else {
+      w_sel[j] = work.take(sizeof(int) * (size_t)J.n_pts);
+      w_sph[j] = work.take(sizeof(double) * 3 * (size_t)J.n_pts);
+    }
+  }
+  P.in_tab = in.take(sizeof(JobDev) * (size_t)n_jobs);
+  P.out_keys = out.take(sizeof(float) * (size_t)num_r * n_jobs);
+  P.out_cand = out.take(extra_out_bytes);
+  P.in_bytes = in.used, P.work_bytes = work.used, P.out_bytes = out.used;
+  // device arena: [in | work | out]; pinned mirror: [in | out]
+  rc = grow(ctx, P.in_bytes + P.work_bytes + P.out_bytes, P.in_bytes + P.out_bytes);
+  if (rc) return rc;
+  unsigned char *d_in = (unsigned char *)ctx->loop_dev, *d_work = d_in + P.in_bytes, *d_out = d_work + P.work_bytes;
+  unsigned char *h_in = (unsigned char *)ctx->loop_pin;
+  for (int j = 0; j < n_jobs; j++) {
+    const dsm_loop_job &J = jobs[j];
+    JobDev &D = P.hj[j];
     memset(&D, 0, sizeof D);
     D.n_pts = J.n_pts;
-    if (J.n_pts > max_pts) max_pts = J.n_pts;
     memcpy(D.cw, J.cur_cw, sizeof D.cw);
     // :33-41 on the host (a handful of keyframes): which keyframes survive, hence which points
     trim_keyframes(J.n_kf, J.kf_pose_wc, J.cur_cw, J.kf_keep);
     std::vector<std::pair<int, int>> ids;
     for (int k = 0; k < J.n_kf; k++) ids.push_back(std::make_pair(J.kf_ids[k], J.kf_keep[k]));
     std::sort(ids.begin(), ids.end());
-    keep[j].resize(J.n_pts ? J.n_pts : 1);
+    unsigned char *keep = h_in + P.in_keep[j];
     for (int i = 0; i < J.n_pts; i++) {
       auto it = std::lower_bound(ids.begin(), ids.end(), std::make_pair(J.pt_kf_id[i], 0));
       unsigned char k = 0;
       for (; it != ids.end() && it->first == J.pt_kf_id[i]; ++it)
         if (it->second) k = 1;
-      keep[j][i] = k; // unknown keyframe: `find == end` (:55)
+      keep[i] = k; // unknown keyframe: `find == end` (:55)
     }
-    double *xyz;
-    unsigned char *kp;
-    int rc;
-    if ((rc = dev_alloc(owned, &xyz, 3 * (size_t)J.n_pts))) return rc;
-    if ((rc = dev_alloc(owned, &kp, (size_t)J.n_pts))) return rc;
-    if (J.n_pts) {
-      DSM_HIP(hipMemcpyAsync(xyz, J.pt_xyz, sizeof(double) * 3 * (size_t)J.n_pts, hipMemcpyHostToDevice, st));
-      DSM_HIP(hipMemcpyAsync(kp, keep[j].data(), (size_t)J.n_pts, hipMemcpyHostToDevice, st));
-    }
-    D.xyz = xyz, D.keep = kp;
-    if ((rc = dev_alloc(owned, &D.grid_y, (size_t)cells))) return rc;
-    if ((rc = dev_alloc(owned, &D.grid_idx, (size_t)cells))) return rc;
-    if ((rc = dev_alloc(owned, &D.block_count, (size_t)nblocks))) return rc;
-    if ((rc = dev_alloc(owned, &D.sel_idx, (size_t)J.n_pts))) return rc;
-    if ((rc = dev_alloc(owned, &D.sph, 3 * (size_t)J.n_pts))) return rc;
-    if ((rc = dev_alloc(owned, &D.n_out, 2))) return rc;
+    if (J.n_pts) memcpy(h_in + P.in_xyz[j], J.pt_xyz, sizeof(double) * 3 * (size_t)J.n_pts);
+    D.xyz = (const double *)(d_in + P.in_xyz[j]), D.keep = d_in + P.in_keep[j];
+    D.grid_y = (unsigned long long *)(d_work + w_gy[j]), D.grid_idx = (int *)(d_work + w_gi[j]), D.block_count = (int *)(d_work + w_bc[j]);
+    D.moments = (double *)(d_work + w_mom[j]), D.bins = (unsigned long long *)(d_work + w_bins[j]);
+    D.sel_idx = (int *)(J.sel_idx ? d_out + P.out_sel[j] : d_work + w_sel[j]);
+    D.sph = (double *)(J.sel_idx ? d_out + P.out_sph[j] : d_work + w_sph[j]);
+    D.n_out = (int *)(d_out + P.out_small[j]);
     D.n_sig = D.n_out + 1;
-    if ((rc = dev_alloc(owned, &D.moments, 9))) return rc;
-    if ((rc = dev_alloc(owned, &D.bins, (size_t)nbins))) return rc;
-    if ((rc = dev_alloc(owned, &D.ringkey, (size_t)num_r))) return rc;
-    if ((rc = dev_alloc(owned, &D.sig_idx, (size_t)nbins))) return rc;
-    if ((rc = dev_alloc(owned, &D.sig_val, (size_t)nbins))) return rc;
+    D.tfm_out = (double *)(d_out + P.out_small[j] + 16);
+    D.ringkey = J.ringkey ? (float *)(d_out + P.out_keys) + (size_t)j * num_r : nullptr;
+    D.sig_idx = (int *)(d_out + P.out_sig_idx[j]), D.sig_val = (double *)(d_out + P.out_sig_val[j]);
   }
-  JobDev *dj;
-  int rc = dev_alloc(owned, &dj, (size_t)n_jobs);
-  if (rc) return rc;
-  DSM_HIP(hipMemcpyAsync(dj, hj.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
-
+  memcpy(h_in + P.in_tab, P.hj.data(), sizeof(JobDev) * (size_t)n_jobs);
+  DSM_HIP(hipMemcpyAsync(d_in, h_in, P.in_bytes, hipMemcpyHostToDevice, st));
+  JobDev *dj = (JobDev *)(d_in + P.in_tab);
+  // a job without a descriptor leaves its key slot untouched: zero the key array so that the search sees defined values
+  DSM_HIP(hipMemsetAsync(d_out + P.out_keys, 0, sizeof(float) * (size_t)num_r * n_jobs, st));
   // ---- generate_spherical_points: all jobs side by side (blockIdx.y = job)
-  const int gx_cells = (int)std::min<long long>(nblocks, 4096), gx_pts = std::min((max_pts + kLdThreads - 1) / kLdThreads, 1024);
+  const int gx_cells = (int)std::min<long long>(P.nblocks, 4096), gx_pts = std::min((max_pts + kLdThreads - 1) / kLdThreads, 1024);
   hipLaunchKernelGGL(voxel_clear_kernel, dim3(gx_cells, n_jobs), dim3(kLdThreads), 0, st, dj, cells);
   hipLaunchKernelGGL(voxel_min_y_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, vs0, vs1);
   hipLaunchKernelGGL(voxel_min_idx_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, vs0, vs1);
-  hipLaunchKernelGGL(voxel_count_kernel, dim3(nblocks, n_jobs), dim3(kLdThreads), 0, st, dj, cells);
-  hipLaunchKernelGGL(voxel_scan_kernel, dim3(n_jobs), dim3(kLdThreads), 0, st, dj, nblocks);
-  hipLaunchKernelGGL(voxel_emit_kernel, dim3(nblocks, n_jobs), dim3(kLdThreads), 0, st, dj, cells);
-  // ---- ScanContext::generate, first half: PCA moments
-  bool any_sc = false;
-  for (int j = 0; j < n_jobs; j++) any_sc = any_sc || jobs[j].ringkey;
-  if (any_sc) {
+  hipLaunchKernelGGL(voxel_count_kernel, dim3(P.nblocks, n_jobs), dim3(kLdThreads), 0, st, dj, cells);
+  hipLaunchKernelGGL(voxel_scan_kernel, dim3(n_jobs), dim3(kLdThreads), 0, st, dj, P.nblocks);
+  hipLaunchKernelGGL(voxel_emit_kernel, dim3(P.nblocks, n_jobs), dim3(kLdThreads), 0, st, dj, cells);
+  if (P.any_sc) {
+    // ---- ScanContext::generate: PCA moments, the eigen-decomposition (:41-47) and tfm_pca_rig (:55-64), then binning, ring key and
+    // signature: nothing leaves the device between the halves (jobs without points are skipped by every kernel and reported at the end)
     hipLaunchKernelGGL(sc_moments_kernel, dim3(n_jobs), dim3(64), 0, st, dj);
-    // ---- the eigen-decomposition (:41-47) and tfm_pca_rig (:55-64), then the second half (binning, ring key, signature):
-    // nothing leaves the device between the halves (jobs without points are skipped by every kernel and reported below)
     hipLaunchKernelGGL(sc_pca_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, st, dj, n_jobs);
-    hipLaunchKernelGGL(sc_clear_kernel, dim3((nbins + kLdThreads - 1) / kLdThreads, n_jobs), dim3(kLdThreads), 0, st, dj, nbins, lidar_range);
+    hipLaunchKernelGGL(sc_clear_kernel, dim3((P.nbins + kLdThreads - 1) / kLdThreads, n_jobs), dim3(kLdThreads), 0, st, dj, P.nbins, lidar_range);
     hipLaunchKernelGGL(sc_bin_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, num_s, num_r);
     hipLaunchKernelGGL(sc_finish_kernel, dim3(n_jobs), dim3(kLdThreads), sizeof(double) * num_s, st, dj, lidar_range, num_s, num_r);
   }
   DSM_HIP(hipGetLastError());
-  std::vector<int> n_out(n_jobs);
-  std::vector<JobDev> back(any_sc ? n_jobs : 0);
-  for (int j = 0; j < n_jobs; j++) DSM_HIP(hipMemcpyAsync(&n_out[j], hj[j].n_out, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (any_sc) DSM_HIP(hipMemcpyAsync(back.data(), dj, sizeof(JobDev) * n_jobs, hipMemcpyDeviceToHost, st)); // tfm of every job
+  if (d_keys) *d_keys = (float *)(d_out + P.out_keys);
+  if (d_extra) *d_extra = d_out + P.out_cand;
+  return DSM_OK;
+}
+
+// the ONE read-back and the scatter into the caller's arrays; h_extra: where the caller's own results arrived
+int loop_finish(dsm_context *ctx, const dsm_loop_job *jobs, const LoopPlan &P, const void **h_extra) {
+  hipStream_t st = ctx->stream;
+  unsigned char *d_out = (unsigned char *)ctx->loop_dev + P.in_bytes + P.work_bytes;
+  unsigned char *h_out = (unsigned char *)ctx->loop_pin + P.in_bytes;
+  DSM_HIP(hipMemcpyAsync(h_out, d_out, P.out_bytes, hipMemcpyDeviceToHost, st));
   DSM_HIP(hipStreamSynchronize(st));
-  for (int j = 0; j < n_jobs; j++) {
+  if (h_extra) *h_extra = h_out + P.out_cand;
+  for (int j = 0; j < P.n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
-    *J.n_out = n_out[j];
-    if (n_out[j] > 0) {
-      DSM_HIP(hipMemcpyAsync(J.sel_idx, hj[j].sel_idx, sizeof(int) * n_out[j], hipMemcpyDeviceToHost, st));
-      DSM_HIP(hipMemcpyAsync(J.pts_spherical, hj[j].sph, sizeof(double) * 3 * (size_t)n_out[j], hipMemcpyDeviceToHost, st));
+    const int *small = (const int *)(h_out + P.out_small[j]);
+    const int n_out = small[0], n_sig = small[1];
+    *J.n_out = n_out;
+    if (J.sel_idx && n_out > 0) {
+      memcpy(J.sel_idx, h_out + P.out_sel[j], sizeof(int) * (size_t)n_out);
+      memcpy(J.pts_spherical, h_out + P.out_sph[j], sizeof(double) * 3 * (size_t)n_out);
     }
-  }
-  if (!any_sc) {
-    DSM_HIP(hipStreamSynchronize(st));
-    return DSM_OK;
-  }
-  for (int j = 0; j < n_jobs; j++) {
-    const dsm_loop_job &J = jobs[j];
     if (!J.ringkey) continue;
-    if (n_out[j] < 1) {
-      DSM_HIP(hipStreamSynchronize(st));
-      return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set");
+    if (n_out < 1) return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set");
+    memcpy(J.tfm_pca_rig, h_out + P.out_small[j] + 16, sizeof(double) * 16);
+    *J.n_sig = n_sig;
+    memcpy(J.ringkey, (const float *)(h_out + P.out_keys) + (size_t)j * P.num_r, sizeof(float) * (size_t)P.num_r);
+    if (n_sig > 0) {
+      memcpy(J.sig_idx, h_out + P.out_sig_idx[j], sizeof(int) * (size_t)n_sig);
+      memcpy(J.sig_val, h_out + P.out_sig_val[j], sizeof(double) * (size_t)n_sig);
     }
-    memcpy(J.tfm_pca_rig, back[j].tfm, sizeof(double) * 16);
   }
-  std::vector<int> n_sig(n_jobs);
-  for (int j = 0; j < n_jobs; j++) DSM_HIP(hipMemcpyAsync(&n_sig[j], hj[j].n_sig, sizeof(int), hipMemcpyDeviceToHost, st));
-  DSM_HIP(hipStreamSynchronize(st));
+  return DSM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r) {
+  LoopPlan P;
+  int rc = loop_enqueue(ctx, n_jobs, jobs, lidar_range, num_s, num_r, 0, P, nullptr, nullptr);
+  if (rc) return rc;
+  return loop_finish(ctx, jobs, P, nullptr);
+}
+
+// The per-keyframe loop chain of LoopHandler (LoopHandler.cpp:186 generate_spherical_points, :236 ScanContext::generate, :247
+// search_ringkey) as ONE enqueue and ONE read-back, batched over the keyframes that were marginalised in the same advance (one per
+// concurrent sequence): descriptors on the device, their ring keys handed to the ring-key index's k-NN on the device, then a single copy
+// back of descriptors and candidates.  Semantics = the jobs' search_ringkey calls one after the other (search_place.h:25-57): query j
+// searches the index as it stands after the keys of queries 0 .. j-1 were enqueued.  An enqueue moves the key that has waited for
+// `margin` insertions from the delay queue into the index; those keys are OLDER than this batch (n_jobs <= margin), known to the host,
+// few, and visible to the later queries of the batch only: the device searches the index as it stood before the batch, the host adds
+// every query's distances to the keys that matured before it (FLANN's L2 expression, the kernels' own) and merges -- same candidates
+// as the sequential calls, bit for bit.  cand_out: n_jobs x k indices (search_ringkey's `idx - 1`), ncand_out: n_jobs counts.
+int dsm_loop_detect_batch(dsm_context *ctx, dsm_ringdb *db, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r,
+                          int *cand_out, int *ncand_out) {
+  if (!db || !cand_out || !ncand_out) return invalid("dsm_loop_detect_batch: bad argument");
+  if (db->ctx != ctx) return invalid("dsm_loop_detect_batch: the index belongs to another context");
+  if (db->shard_count != 1) return invalid("dsm_loop_detect_batch: unsharded index only (a sharded one searches through dsm_ringdb_query_then_enqueue)");
+  if (num_r != db->dim) return invalid("dsm_loop_detect_batch: num_r must equal the index's key dimension");
+  if (n_jobs > db->margin) return invalid("dsm_loop_detect_batch: at most `margin` keyframes per call");
+  for (int j = 0; jobs && j < n_jobs; j++)
+    if (!jobs[j].ringkey) return invalid("dsm_loop_detect_batch: every job needs its descriptor outputs");
+  LoopPlan P;
+  float *d_keys = nullptr;
+  void *d_cand = nullptr;
+  const int k = db->k;
+  int rc = loop_enqueue(ctx, n_jobs, jobs, lidar_range, num_s, num_r, sizeof(unsigned long long) * (size_t)n_jobs * k, P, &d_keys, &d_cand);
+  if (rc) return rc;
+  const bool search = db->size_global > k; // `ringkeys->size() > FLANN_NN`, search_place.h:29 (the index as it stands before the batch)
+  if (search && (rc = dsm::ringdb_knn_device(db, d_keys, n_jobs, (unsigned long long *)d_cand))) return rc;
+  const void *h_cand_v = nullptr;
+  rc = loop_finish(ctx, jobs, P, &h_cand_v);
+  if (rc) return rc;
+  const unsigned long long *h_cand = (const unsigned long long *)h_cand_v;
+  // the sequential semantics on the host: matured keys and the queries that see them
+  std::vector<float> matured; // keys that entered the index during this batch, in order
+  const long long base = db->size_global;
   for (int j = 0; j < n_jobs; j++) {
-    const dsm_loop_job &J = jobs[j];
-    if (!J.ringkey) continue;
-    *J.n_sig = n_sig[j];
-    DSM_HIP(hipMemcpyAsync(J.ringkey, hj[j].ringkey, sizeof(float) * num_r, hipMemcpyDeviceToHost, st));
-    if (n_sig[j] > 0) {
-      DSM_HIP(hipMemcpyAsync(J.sig_idx, hj[j].sig_idx, sizeof(int) * n_sig[j], hipMemcpyDeviceToHost, st));
-      DSM_HIP(hipMemcpyAsync(J.sig_val, hj[j].sig_val, sizeof(double) * n_sig[j], hipMemcpyDeviceToHost, st));
+    const float *key = jobs[j].ringkey;
+    unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    const long long size_now = base + (long long)(matured.size() / db->dim);
+    int nb = 0;
+    if (size_now > k) {
+      if (search)
+        for (int i = 0; i < k; i++)
+          if (h_cand[(size_t)j * k + i] != (unsigned long long)DSM_RINGDB_NO_CANDIDATE) best[nb++] = h_cand[(size_t)j * k + i];
+      for (size_t m = 0; m < matured.size() / db->dim; m++) { // flann::L2, as the kernels: groups of four, then the tail
+        const float *kp = matured.data() + m * db->dim;
+        float result = 0.f;
+        int d = 0;
+        for (; d + 3 < db->dim; d += 4) {
+          const float d0 = key[d] - kp[d], d1 = key[d + 1] - kp[d + 1], d2 = key[d + 2] - kp[d + 2], d3 = key[d + 3] - kp[d + 3];
+          result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        for (; d < db->dim; d++) {
+          const float d0 = key[d] - kp[d];
+          result += d0 * d0;
+        }
+        if (!(result < db->thres)) continue;
+        unsigned bits;
+        memcpy(&bits, &result, 4);
+        const unsigned long long c = ((unsigned long long)bits << 32) | (unsigned long long)(base + (long long)m);
+        // insert into the ascending list of at most k
+        int pos = nb < k ? nb : k;
+        for (int i = 0; i < nb && i < k; i++)
+          if (c < best[i]) {
+            pos = i;
+            break;
+          }
+        if (pos < k) {
+          for (int i = (nb < k ? nb : k - 1); i > pos; i--) best[i] = best[i - 1];
+          best[pos] = c;
+          if (nb < k) nb++;
+        }
+      }
+      // (the index was too small for the device to search but has grown past k inside the batch: cannot happen with margin >= k)
     }
+    int nc = 0;
+    for (int i = 0; i < nb && i < k; i++) {
+      const int idx = (int)(best[i] & 0xFFFFFFFFull);
+      if (idx > 0) cand_out[(size_t)j * k + nc++] = idx - 1; // :34-38
+    }
+    ncand_out[j] = nc;
+    // the enqueue of search_ringkey (:41-56): the slot's old key matures into the index
+    float *slot = db->queue.data() + (size_t)(db->queue_idx % db->margin) * db->dim;
+    if (db->queue_idx >= db->margin) matured.insert(matured.end(), slot, slot + db->dim);
+    memcpy(slot, key, sizeof(float) * db->dim);
+    db->queue_idx++;
   }
-  DSM_HIP(hipStreamSynchronize(st));
+  if (!matured.empty()) return dsm_ringdb_add_points(db, matured.data(), (int64_t)(matured.size() / db->dim));
   return DSM_OK;
 }
 

@@ -96,6 +96,9 @@ static int rdb_knn_dev(dsm_ringdb *db, const float *d_queries, int nq, unsigned 
   return DSM_OK;
 }
 
+namespace dsm {
+int ringdb_knn_device(dsm_ringdb *db, const float *d_queries, int nq, unsigned long long *d_out) { return rdb_knn_dev(db, d_queries, nq, d_out); }
+} // namespace dsm
 extern "C" {
 int dsm_ringdb_destroy(dsm_ringdb *db);
 

@@ -41,6 +41,8 @@ int ringdb_merge_attached(dsm_ringdb *db, void *d_packed, int nq);
 // every rank only if every rank was ready and all hold the same index size; otherwise every rank gets the same error and
 // none enters the merge rounds (a rank that bailed out alone would leave the others waiting in a collective).
 int ringdb_agree(dsm_ringdb *db, bool ready, const char *why_not);
+// the local k-NN scan over device-resident queries (nq x dim floats) into d_out (nq x k packed candidates), enqueued on the context's stream
+int ringdb_knn_device(dsm_ringdb *db, const float *d_queries, int nq, unsigned long long *d_out);
 // the communicator is going away: detach it from the databases that borrow it
 void ringdb_forget_comm(dsm_ringdb *db);
 } // namespace dsm

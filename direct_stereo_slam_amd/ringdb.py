@@ -215,42 +215,74 @@ def generate_spherical_points(kf_ids, kf_pose_wc, cur_cw, lidar_range, pt_kf_id,
     return keep.astype(bool), sel[: n.value].copy(), out[: n.value].copy()
 
 
-def loop_descriptors_batch(ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True):
+class LoopBatch:
+    """The ctypes job table of dsm_loop_descriptors_batch / dsm_loop_detect_batch and its output arrays, built once: `run()` is the C call
+    alone (a node keeps its clouds and job tables; bench.py times this), `results()` unpacks."""
+
+    def __init__(self, ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True):
+        self.ctx, self.L, self.db = ctx, ctx.L, db
+        self.lidar_range, self.num_s, self.num_r, self.scancontext, self.selected_points = lidar_range, num_s, num_r, scancontext, selected_points
+        self.arr = (_lib.LoopJob * len(jobs))()
+        self.keepalive, self.outs = [], []
+        dp, ip = _lib.c_double_p, c_int_p
+        for j, (kf_ids, kf_pose_wc, cur_cw, pt_kf_id, pt_xyz) in enumerate(jobs):
+            kf_ids = np.ascontiguousarray(kf_ids, np.int32)
+            poses = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 6)
+            cw = np.ascontiguousarray(cur_cw, np.float64).reshape(3, 4)
+            pid = np.ascontiguousarray(pt_kf_id, np.int32)
+            xyz = np.ascontiguousarray(pt_xyz, np.float64).reshape(-1, 3)
+            o = dict(kf_keep=np.zeros(max(1, len(kf_ids)), np.int32), n_out=np.zeros(1, np.int32), ringkey=np.zeros(num_r, np.float32),
+                     sig_idx=np.zeros(num_s * num_r, np.int32), sig_val=np.zeros(num_s * num_r), n_sig=np.zeros(1, np.int32), tfm=np.zeros(16))
+            if selected_points:
+                o.update(sel_idx=np.zeros(max(1, len(pid)), np.int32), pts_spherical=np.zeros((max(1, len(pid)), 3)))
+            self.keepalive.append((kf_ids, poses, cw, pid, xyz))
+            self.outs.append((o, len(kf_ids)))
+            J = self.arr[j]
+            J.n_kf, J.kf_ids, J.kf_pose_wc, J.cur_cw = len(kf_ids), kf_ids.ctypes.data_as(ip), poses.ctypes.data_as(dp), cw.ctypes.data_as(dp)
+            J.n_pts, J.pt_kf_id, J.pt_xyz = len(pid), pid.ctypes.data_as(ip), xyz.ctypes.data_as(dp)
+            J.kf_keep, J.n_out = o["kf_keep"].ctypes.data_as(ip), o["n_out"].ctypes.data_as(ip)
+            if selected_points:
+                J.sel_idx, J.pts_spherical = o["sel_idx"].ctypes.data_as(ip), o["pts_spherical"].ctypes.data_as(dp)
+            if scancontext:
+                J.ringkey, J.sig_idx, J.sig_val = _fp(o["ringkey"]), o["sig_idx"].ctypes.data_as(ip), o["sig_val"].ctypes.data_as(dp)
+                J.n_sig, J.tfm_pca_rig = o["n_sig"].ctypes.data_as(ip), o["tfm"].ctypes.data_as(dp)
+        self.cand = self.ncand = None
+        if db is not None:
+            self.cand, self.ncand = np.full((len(jobs), db.k), -1, np.int32), np.zeros(len(jobs), np.int32)
+
+    def run(self):
+        ip = c_int_p
+        if self.db is None:
+            check(self.L.dsm_loop_descriptors_batch(self.ctx.h, len(self.arr), self.arr, self.lidar_range, self.num_s, self.num_r))
+        else:
+            check(self.L.dsm_loop_detect_batch(self.ctx.h, self.db.h, len(self.arr), self.arr, self.lidar_range, self.num_s, self.num_r,
+                                               self.cand.ctypes.data_as(ip), self.ncand.ctypes.data_as(ip)))
+
+    def results(self):
+        res = []
+        for j, (o, n_kf) in enumerate(self.outs):
+            n, ns = int(o["n_out"][0]), int(o["n_sig"][0])
+            r = dict(kf_keep=o["kf_keep"][:n_kf].astype(bool), n_out=n)
+            if self.selected_points:
+                r.update(sel_idx=o["sel_idx"][:n].copy(), pts_spherical=o["pts_spherical"][:n].copy())
+            if self.cand is not None:
+                r["candidates"] = [int(c) for c in self.cand[j, : self.ncand[j]]]
+            if self.scancontext:
+                r.update(ringkey=o["ringkey"].copy(), sig_idx=o["sig_idx"][:ns].copy(), sig_val=o["sig_val"][:ns].copy(), tfm_pca_rig=o["tfm"].reshape(4, 4).copy())
+            res.append(r)
+        return res
+
+
+def loop_descriptors_batch(ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True):
     """DEVICE form of generate_spherical_points + ScanContext::generate for a batch of keyframes (dsm_loop_descriptors_batch).
     jobs: list of (kf_ids, kf_pose_wc, cur_cw, pt_kf_id, pt_xyz).  Returns, per job, a dict with kf_keep, sel_idx,
-    pts_spherical and -- with scancontext -- ringkey, sig_idx, sig_val, tfm_pca_rig."""
-    L = ctx.L
-    arr = (_lib.LoopJob * len(jobs))()
-    keepalive, outs = [], []
-    dp, ip = _lib.c_double_p, c_int_p
-    for j, (kf_ids, kf_pose_wc, cur_cw, pt_kf_id, pt_xyz) in enumerate(jobs):
-        kf_ids = np.ascontiguousarray(kf_ids, np.int32)
-        poses = np.ascontiguousarray(kf_pose_wc, np.float64).reshape(-1, 6)
-        cw = np.ascontiguousarray(cur_cw, np.float64).reshape(3, 4)
-        pid = np.ascontiguousarray(pt_kf_id, np.int32)
-        xyz = np.ascontiguousarray(pt_xyz, np.float64).reshape(-1, 3)
-        o = dict(kf_keep=np.zeros(max(1, len(kf_ids)), np.int32), n_out=np.zeros(1, np.int32), sel_idx=np.zeros(max(1, len(pid)), np.int32),
-                 pts_spherical=np.zeros((max(1, len(pid)), 3)), ringkey=np.zeros(num_r, np.float32), sig_idx=np.zeros(num_s * num_r, np.int32),
-                 sig_val=np.zeros(num_s * num_r), n_sig=np.zeros(1, np.int32), tfm=np.zeros(16))
-        keepalive.append((kf_ids, poses, cw, pid, xyz))
-        outs.append((o, len(kf_ids)))
-        J = arr[j]
-        J.n_kf, J.kf_ids, J.kf_pose_wc, J.cur_cw = len(kf_ids), kf_ids.ctypes.data_as(ip), poses.ctypes.data_as(dp), cw.ctypes.data_as(dp)
-        J.n_pts, J.pt_kf_id, J.pt_xyz = len(pid), pid.ctypes.data_as(ip), xyz.ctypes.data_as(dp)
-        J.kf_keep, J.n_out, J.sel_idx = o["kf_keep"].ctypes.data_as(ip), o["n_out"].ctypes.data_as(ip), o["sel_idx"].ctypes.data_as(ip)
-        J.pts_spherical = o["pts_spherical"].ctypes.data_as(dp)
-        if scancontext:
-            J.ringkey, J.sig_idx, J.sig_val = _fp(o["ringkey"]), o["sig_idx"].ctypes.data_as(ip), o["sig_val"].ctypes.data_as(dp)
-            J.n_sig, J.tfm_pca_rig = o["n_sig"].ctypes.data_as(ip), o["tfm"].ctypes.data_as(dp)
-    check(L.dsm_loop_descriptors_batch(ctx.h, len(jobs), arr, lidar_range, num_s, num_r))
-    res = []
-    for o, n_kf in outs:
-        n, ns = int(o["n_out"][0]), int(o["n_sig"][0])
-        r = dict(kf_keep=o["kf_keep"][:n_kf].astype(bool), sel_idx=o["sel_idx"][:n].copy(), pts_spherical=o["pts_spherical"][:n].copy())
-        if scancontext:
-            r.update(ringkey=o["ringkey"], sig_idx=o["sig_idx"][:ns].copy(), sig_val=o["sig_val"][:ns].copy(), tfm_pca_rig=o["tfm"].reshape(4, 4))
-        res.append(r)
-    return res
+    pts_spherical and -- with scancontext -- ringkey, sig_idx, sig_val, tfm_pca_rig.
+    db (a RingKeyDB): dsm_loop_detect_batch instead -- the jobs' ring keys are searched in (and enqueued into) the index on the device,
+    one enqueue and one read-back for the whole chain; every result also carries `candidates` (search_ringkey's list).
+    selected_points = False: sel_idx / pts_spherical stay on the device (NULL outputs)."""
+    b = LoopBatch(ctx, jobs, lidar_range, num_s, num_r, scancontext, db, selected_points)
+    b.run()
+    return b.results()
 
 
 def write_trajectory(path, incoming_ids, t_wc):

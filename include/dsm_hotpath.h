@@ -535,7 +535,7 @@ typedef struct dsm_loop_job {
   const double *pt_xyz;       /* n_pts x 3 */
   int *kf_keep;               /* out: n_kf */
   int *n_out;                 /* out */
-  int *sel_idx;               /* out: capacity n_pts */
+  int *sel_idx;               /* out: capacity n_pts; NULL (together with pts_spherical): the selected points stay on the device */
   double *pts_spherical;      /* out: capacity n_pts x 3 */
   float *ringkey;             /* out: num_r floats, or NULL to stop after the point filter */
   int *sig_idx;               /* out: capacity num_s*num_r */
@@ -544,6 +544,15 @@ typedef struct dsm_loop_job {
   double *tfm_pca_rig;        /* out: row-major 4x4 */
 } dsm_loop_job;
 int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r);
+/* The per-keyframe loop chain -- generate_spherical_points (LoopHandler.cpp:186), ScanContext::generate (:236), search_ringkey (:247,
+ * search_place.h:25-57) -- as ONE enqueue and ONE read-back for the keyframes marginalised in the same advance (one per concurrent
+ * sequence; n_jobs <= the index's margin): the ring keys go from the descriptor kernels to the index's k-NN on the device.  Every job
+ * needs its descriptor outputs (ringkey ... tfm_pca_rig); sel_idx / pts_spherical may both be NULL (the selected points -- 0.45 MB per
+ * keyframe -- then stay on the device).  Results equal the jobs' dsm_loop_descriptors_batch + dsm_ringdb_query_then_enqueue calls one
+ * after the other, bit for bit: cand_out[j * k ...] / ncand_out[j] = search_ringkey's candidate list of job j, and every key is enqueued.
+ * Unsharded index; num_r = its key dimension. */
+int dsm_loop_detect_batch(dsm_context *ctx, dsm_ringdb *db, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r,
+                          int *cand_out, int *ncand_out);
 
 /* replaces TrackerAndScaler::makeCoarseDepthL0 (TrackerAndScaler.cpp:143-315) for callers that hold
  * the active points as flat arrays: (pu,pv) = centerProjectedTo[0..1], pidepth = centerProjectedTo[2],

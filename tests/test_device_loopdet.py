@@ -97,3 +97,45 @@ def test_batch_of_eleven_sequences_feeds_the_ring_key_search(ctx):
     db.add_points(keys)
     packed = db.knn_packed_host(keys)
     assert np.array_equal(packed[:, 0] & 0xFFFFFFFF, np.arange(1, 12))  # every key finds itself (index 0 is the dummy slot)
+
+
+def test_fused_loop_chain_equals_the_sequential_calls(ctx):
+    """dsm_loop_detect_batch: descriptors -> ring key -> k-NN -> candidates as ONE enqueue and ONE read-back for a batch of keyframes.
+    Semantics = LoopHandler's per-keyframe chain run job after job (LoopHandler.cpp:186,236,247; search_place.h:25-57): query j
+    searches the index as it stands after the keys of queries 0 .. j-1 were enqueued -- including the keys those enqueues moved out of
+    the delay queue.  Same descriptors, same candidates, same index afterwards, bit for bit, in batches small and large, with a
+    short delay margin so that keys mature inside the batches."""
+    from direct_stereo_slam_amd.ringdb import RingKeyDB
+
+    rng = np.random.default_rng(7)
+    # revisits: every place is described twice (second time from a slightly different cloud), in a shuffled order
+    places = [make_job(300 + s, n_pts=3000 + 200 * (s % 5)) for s in range(14)]
+    jobs = []
+    for rep in range(2):
+        for s in rng.permutation(len(places)):
+            kf_ids, poses, cur_cw, pt_kf, xyz = places[s]
+            jobs.append((kf_ids, poses, cur_cw, pt_kf, xyz + rng.normal(0, 0.003 * rep, xyz.shape)))
+    for margin, batches in ((5, (1, 3, 5, 5, 4, 5, 5)), (9, (7, 9, 9, 3))):
+        assert sum(batches) == len(jobs)
+        seq_db, fus_db = (RingKeyDB(ctx, capacity=64, margin=margin) for _ in range(2))
+        seq = []
+        for job in jobs:  # the sequential chain: one descriptor call, one search_ringkey call per keyframe
+            r = loop_descriptors_batch(ctx, [job], 40.0)[0]
+            r["candidates"] = seq_db.search_ringkey(r["ringkey"])
+            seq.append(r)
+        fus, i = [], 0
+        for b in batches:
+            fus += loop_descriptors_batch(ctx, jobs[i:i + b], 40.0, db=fus_db, selected_points=(i % 2 == 0))
+            i += b
+        assert any(r["candidates"] for r in seq), "the scenario must produce loop candidates"
+        for a, f in zip(seq, fus):
+            assert np.array_equal(a["ringkey"], f["ringkey"]) and a["candidates"] == f["candidates"]
+            assert np.array_equal(a["sig_idx"], f["sig_idx"]) and np.array_equal(a["sig_val"], f["sig_val"])
+            assert np.array_equal(a["tfm_pca_rig"], f["tfm_pca_rig"]) and a["n_out"] == f["n_out"]
+            if "sel_idx" in f:
+                assert np.array_equal(a["sel_idx"], f["sel_idx"]) and np.array_equal(a["pts_spherical"], f["pts_spherical"])
+        assert seq_db.size() == fus_db.size()
+        q = np.stack([r["ringkey"] for r in seq[:8]])
+        assert np.array_equal(seq_db.knn_packed_host(q), fus_db.knn_packed_host(q))  # the same index afterwards
+    with pytest.raises(Exception):
+        loop_descriptors_batch(ctx, jobs[:6], 40.0, db=RingKeyDB(ctx, capacity=64, margin=5))  # more keyframes than the delay margin

@@ -286,10 +286,35 @@ struct GpuBackend {
   void search_sc(const SigType &sig, const std::vector<SigType> &all, const std::vector<int> &cand, int &idx, float &diff) {
     dsm_host::search_sc(sig, [&](int i) -> const SigType & { return all[i]; }, cand, 60, idx, diff);
   }
+  // the keyframe's whole chain -- generate_spherical_points, ScanContext::generate, search_ringkey -- as ONE enqueue and ONE read-back
+  // (dsm_loop_detect_batch, one job; the selected points stay on the device: nothing downstream of the hot path reads them here)
+  static constexpr bool kFusedLoopChain = true;
+  void descriptors_and_search(std::vector<int> &kf_ids, std::vector<double> &kf_pose_wc, const double cur_cw[12], std::vector<int> &pt_kf,
+                              std::vector<double> &pt_xyz, std::vector<float> &ringkey, SigType &sig, std::vector<int> &cand, Timers &tm) {
+    const int n_kf = (int)kf_ids.size(), n_pts = (int)pt_kf.size();
+    std::vector<int> keep(n_kf), sidx(60 * 20);
+    std::vector<double> sval(60 * 20);
+    int n_out = 0, n_sig = 0, ncand = 0, cands[4] = {0, 0, 0, 0};
+    double tfm[16];
+    ringkey.assign(20, 0.f);
+    dsm_loop_job job;
+    memset(&job, 0, sizeof job);
+    job.n_kf = n_kf, job.kf_ids = kf_ids.data(), job.kf_pose_wc = kf_pose_wc.data(), job.cur_cw = cur_cw;
+    job.n_pts = n_pts, job.pt_kf_id = pt_kf.data(), job.pt_xyz = pt_xyz.data();
+    job.kf_keep = keep.data(), job.n_out = &n_out;
+    job.ringkey = ringkey.data(), job.sig_idx = sidx.data(), job.sig_val = sval.data(), job.n_sig = &n_sig, job.tfm_pca_rig = tfm;
+    const auto t0 = Clock::now();
+    dsm_host::loop_check(dsm_loop_detect_batch(ctx, ring->handle(), 1, &job, P.lidar_range, 60, 20, cands, &ncand), "dsm_loop_detect_batch");
+    tm.add("pts_generation+sc_generation+search_ringkey (one call)", ms_since(t0));
+    sig.clear();
+    for (int i = 0; i < n_sig; i++) sig.push_back({sidx[i], sval[i]});
+    cand.assign(cands, cands + ncand);
+  }
 };
 
 // ---- backend 2: the CPU path (oracle restatement of the reference; host functions of the product for the loop descriptors) ----
 struct CpuBackend {
+  static constexpr bool kFusedLoopChain = false;
   const Pack &P;
   orc_tracker *a, *b, *cur, *nxt;
   orc_ringdb *ring;
@@ -649,17 +674,21 @@ static RunResult run(B &be, const Pack &P) {
         }
         std::vector<float> key;
         SigType sig;
-        be.descriptors(ids, poses, cw, pk, xyz, key, sig, R.tm);
+        std::vector<int> cand;
+        if constexpr (B::kFusedLoopChain) {
+          be.descriptors_and_search(ids, poses, cw, pk, xyz, key, sig, cand, R.tm);
+        } else {
+          be.descriptors(ids, poses, cw, pk, xyz, key, sig, R.tm);
+          t0 = Clock::now();
+          be.search_ringkey(key, cand);
+          R.tm.add("search_ringkey", ms_since(t0));
+        }
         {
           LoopQuery lq;
           lq.ids = ids, lq.pk = pk, lq.poses = poses, lq.xyz = xyz, lq.key = key;
           memcpy(lq.cw, cw, sizeof lq.cw);
           R.queries.push_back(std::move(lq));
         }
-        std::vector<int> cand;
-        t0 = Clock::now();
-        be.search_ringkey(key, cand);
-        R.tm.add("search_ringkey", ms_since(t0));
         int matched = -1;
         float diff = -1;
         if (!cand.empty()) {
