@@ -152,8 +152,9 @@ struct ScaleDepthArgs { // every level of one template in one launch (blockIdx.y
   float4 *pts[DSM_MAX_LEVELS];
 };
 void launch_scale_depth_levels(hipStream_t s, const ScaleDepthArgs &a, int max_n, float scale);
-// Template lists are allocated with this many entries of slack (zeroed): the evaluation loop prefetches template entries up to
-// three trips (3 x 256 points) past the end of a chunk without clamping the index; what it reads there is never used (masked)
+// Template lists are allocated with this many entries of slack (zeroed).  The evaluation loop prefetches template entries up to three
+// trips (3 x 256 points) past the end of a chunk; its buffer loads are range-checked against the list (an entry beyond it reads as
+// zeros, never used: masked), so the slack is only a second line of defence for the paths that read the list with plain loads
 constexpr int kTemplatePad = 1024;
 // chunks of an evaluation of level L of a tracker
 inline int level_chunks(const TrackerDev &d, int L) { return num_chunks(d.lv[L].n); }

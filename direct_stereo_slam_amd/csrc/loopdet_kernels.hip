@@ -374,7 +374,7 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
   P.hj.assign(n_jobs, JobDev());
   P.in_xyz.resize(n_jobs), P.in_keep.resize(n_jobs), P.out_small.resize(n_jobs), P.out_sig_idx.resize(n_jobs), P.out_sig_val.resize(n_jobs);
   P.out_sel.resize(n_jobs), P.out_sph.resize(n_jobs);
-  Arena in, work, out, side;
+  Arena in, work, out;
   std::vector<size_t> w_gy(n_jobs), w_gi(n_jobs), w_bc(n_jobs), w_mom(n_jobs), w_bins(n_jobs), w_sel(n_jobs), w_sph(n_jobs);
   int max_pts = 1;
   for (int j = 0; j < n_jobs; j++) {

@@ -441,8 +441,8 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     {
       // Template stream: entry (start + tid) of the list = one coalesced 16-byte load per lane from a wave-uniform base (SGPR pair)
       // plus this thread's constant byte offset -- no per-point index arithmetic.  Entries past the chunk (the loop prefetches up to
-      // three trips ahead) or past the list are never used: their lanes are masked; the list's allocation has kTemplatePad entries
-      // of slack (dsm_kernels.hpp), the LDS copy (coarse_kernel) is read with a clamped index instead.
+      // three trips ahead) or past the list are never used: their lanes are masked, and an entry past the list reads as zeros (the
+      // buffer descriptor checks the range); the LDS copy (coarse_kernel) is read with a clamped index instead.
       const unsigned voff = 16u * (unsigned)tid;
       const unsigned lds_pts = c.lds_pts;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.pts, 0, 16 * n, 0x00020000);
@@ -2279,7 +2279,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
     else
       eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out); // (this kernel is allocated 128 registers by its level-0 loop)
-    __syncthreads(); // red[] is reused by the next item
+    __syncthreads(); // red[] is reused by the next item (the arrival-ticket form of eval_kernel measured the same here: profiles/r05_ab_tick_arrival_ticket.log)
   }
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses the raw rocprofv3 / bench outputs of tools/profile_round_r04.sh into the small tracked files under profiles/:
+"""Condenses the raw rocprofv3 / bench outputs of tools/profile_round_r04.sh / _r05.sh into the small tracked files under profiles/:
    python tools/summarize_profiles_r04.py gpurun_out/<tag> <tag> <dst> [pmc|all]
 The dominant kernel of the round-4 default line is tick_eval_kernel<0> (the tick engine's evaluation launch: the staged
 evaluations of EVERY pyramid level of a stream group's resident problems)."""
@@ -18,6 +18,8 @@ KERNEL = "tick_eval_kernel<0>"
 
 
 def last_json(path):
+    if os.path.exists(path + ".detail.json"):  # round 5: the stdout line is the compact form; the full object is the side file
+        return json.load(open(path + ".detail.json"))
     for line in reversed(open(path).read().splitlines()):
         if line.startswith("{"):
             return json.loads(line)
