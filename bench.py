@@ -119,6 +119,8 @@ def _parse():
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--compact", type=int, default=None, help="dsm_params.compact_tail (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
+    ap.add_argument("--geometry", type=int, default=None, choices=(0, 1),
+                    help="dsm_params.chunk_geometry: 0 throughput table (library default), 1 latency table (what one frame in flight -- --batch 1, the replay adaptors -- uses)")
     ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="upper bound of the frames timed on the CPU baseline (rank 0, N=1); the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the single-core CPU baseline leg once --cpu-min-frames are done")
@@ -344,6 +346,8 @@ def build_workload(args, ctx, config):
         params.speculate = args.speculate
     if args.compact is not None:
         params.compact_tail = args.compact
+    if args.geometry is not None:
+        params.chunk_geometry = args.geometry
     if args.evals_only:
         for l in range(6):
             params.max_iterations[l] = 0
@@ -611,6 +615,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     frames = B * steps
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": 0, "adaptive_schedule": True, "persistent_coarse": int(wl["params"].persistent_coarse),
+              "chunk_geometry": ("throughput table (library default)", "latency table")[int(wl["params"].chunk_geometry)],
               "streams": args.streams,
               "form": ("stream, tick engine (dsm_stream_*: every resident problem advances one LM round per tick, admission and retirement on the device; "
                        "a step submits its frames and runs one advance, the pool is drained after the last step)") if ticks else
@@ -622,6 +627,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
                          "frames_submitted": frames, "ms_per_pass": 1e3 * dt / max(1, timed_passes),
                          "device_ms_per_advance": float(timed["ms"]) / max(1, timed_passes),
                          "host_share_of_timed_region": 1.0 - float(timed["ms"]) * 1e-3 / dt,
+                         "group_streams": dict(zip(("in_use", "sharing_a_hardware_queue"), ctx.stream_queues())),
                          "steady_state": {"frames_per_s": steady["retired"] / steady["wall"], "passes": int(steady["passes"]), "frames_retired": int(steady["retired"]),
                                           "ms_per_pass": 1e3 * steady["wall"] / max(1, steady["passes"]),
                                           "what": "8 advances after the timed region with waiting frames at hand all the time: frames retired / wall time (no ramp-up, no drain)"}},
@@ -762,6 +768,7 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": int(stt.queue_blocks), "adaptive_schedule": not args.no_adaptive,
               "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams,
+              "chunk_geometry": ("throughput table (library default)", "latency table")[int(wl["params"].chunk_geometry)],
               "launch_pairs_per_step": int(sum(stt.launches) + sum(sts.launches)), "readbacks_per_step": int(stt.polls + sts.polls),
               "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
               "algorithmic_MB_per_frame": all_bytes / B / 1e6,

@@ -41,7 +41,7 @@ class Params(C.Structure):
         ("speculate", C.c_int),
         ("compact_tail", C.c_int),
         ("fixed_schedule", C.c_int),
-        ("tile_l0", C.c_int),
+        ("chunk_geometry", C.c_int),
         ("frame_check", C.c_int),
         ("frame_grad_tol", C.c_float),
     ]
@@ -136,6 +136,7 @@ SYMBOLS = {
     "dsm_context_set_streams": (C.c_int, [_vp, C.c_int]),
     "dsm_context_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "dsm_context_stream": (_vp, [_vp]),
+    "dsm_context_stream_queues": (C.c_int, [_vp, c_int_p, c_int_p]),
     "dsm_diag_read_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, c_double_p]),
     "dsm_diag_read_bandwidth_chunked": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_int, c_double_p]),
     "dsm_diag_xwg_litmus": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -225,7 +226,12 @@ def load():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        try:
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        except AttributeError:
+            if os.environ.get("DSM_HOTPATH_LIB") and os.environ.get("DSM_HOTPATH_LIB_OLDER_BUILD"):
+                continue  # developer A/B against a build of an earlier commit (same ABI version, fewer entry points)
+            raise
         fn.restype = res
         fn.argtypes = args
     # the struct layouts above are those of ABI version ABI_VERSION (include/dsm_hotpath.h: DSM_ABI_VERSION)

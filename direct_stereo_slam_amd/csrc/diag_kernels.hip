@@ -35,6 +35,24 @@ __global__ __launch_bounds__(256) void read_bw_chunked_kernel(const fvec4d *__re
   if (s == 123456.789f) out[0] = s;
 }
 
+// Queue probe (ensure_streams, dsm_capi.hip): a kernel that stays resident for `ticks` of the constant-rate wall clock (bounded: it
+// leaves after 2^22 polls whatever the clock says) and an empty one.  A HIP stream is mapped onto one of a few hardware queues by the
+// runtime (four by default, shared round robin with every other stream of the process); two streams on ONE queue run their kernels
+// one after the other however independent they are -- the probe makes that visible: the empty kernel on stream B finishes while the
+// waiting kernel on stream A is still resident only if A and B sit on different queues.
+__global__ __launch_bounds__(64) void queue_probe_wait_kernel(long long ticks, int *sink) {
+  const long long t0 = wall_clock64();
+  int polls = 0;
+  while (wall_clock64() - t0 < ticks && polls < (1 << 22)) {
+    __builtin_amdgcn_s_sleep(16);
+    polls++;
+  }
+  if (ticks < 0) *sink = polls;
+}
+__global__ void queue_probe_empty_kernel() {}
+void launch_queue_probe_wait(hipStream_t s, long long ticks) { hipLaunchKernelGGL(queue_probe_wait_kernel, dim3(1), dim3(64), 0, s, ticks, nullptr); }
+void launch_queue_probe_empty(hipStream_t s) { hipLaunchKernelGGL(queue_probe_empty_kernel, dim3(1), dim3(1), 0, s); }
+
 // Message-passing litmus of the hand-off protocol the eval / LM / queue kernels use between workgroups (xwg_sync.hpp):
 // workgroup 2p produces, workgroup 2p + 1 consumes (consecutive workgroups run on different XCDs: b % 8).  Per hand-off k
 // the producer stores a 64-float "partial" whose every word is k with device-scope stores, xwg_release(), then adds 1 to

@@ -240,7 +240,7 @@ void dsm_params_default(dsm_params *p) {
   p->speculate = 1;
   p->compact_tail = 1;
   p->fixed_schedule = 0;
-  p->tile_l0 = 0;
+  p->chunk_geometry = 0;
   p->frame_check = 1;
   p->frame_grad_tol = 0.0f;
 }
@@ -345,6 +345,12 @@ int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out) {
   return DSM_OK;
 }
 void *dsm_context_stream(dsm_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int dsm_context_stream_queues(dsm_context *ctx, int *streams_out, int *sharing_out) {
+  if (!ctx) return invalid("dsm_context_stream_queues: null context");
+  if (streams_out) *streams_out = 1 + (int)ctx->extra_streams.size() + (ctx->companion_stream ? 1 : 0);
+  if (sharing_out) *sharing_out = ctx->streams_sharing_a_queue;
+  return DSM_OK;
+}
 
 // ---- tracker ------------------------------------------------------------------------------
 static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, int nlevels, const double T_f1_f0[16],
@@ -380,8 +386,8 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
     if (params->struct_size != sizeof(dsm_params))
       return invalid("dsm_params.struct_size does not match this library's dsm_params: the caller was built against another "
                      "version of dsm_hotpath.h (use dsm_params_default, compare dsm_abi_version() with DSM_ABI_VERSION)");
-    if (params->tile_l0 != 0)
-      return invalid("dsm_params.tile_l0 is reserved and must be 0 (round 4's tile form of the level-0 evaluation was removed: include/dsm_hotpath.h)");
+    if (params->chunk_geometry != 0 && params->chunk_geometry != 1)
+      return invalid("dsm_params.chunk_geometry: 0 (throughput table) or 1 (latency table)");
     t->params = *params;
   } else {
     dsm_params_default(&t->params);
@@ -400,13 +406,14 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
   D.p.lambda_extrapolation_limit = t->params.lambda_extrapolation_limit;
   for (int l = 0; l < DSM_MAX_LEVELS; l++) D.p.max_iterations[l] = t->params.max_iterations[l];
   D.p.fixed_schedule = t->params.fixed_schedule;
+  D.p.geometry = t->params.chunk_geometry;
   se3_from_matrix(T_f1_f0, D.T10);
   for (int l = 0; l < nlevels; l++) { // TrackerAndScaler.cpp:52-64
     const int wl = w >> l, hl = h >> l;
     D.lv[l].w = wl;
     D.lv[l].h = hl;
     DSM_HIP(hipMalloc(&t->d_pts[l], sizeof(float4) * ((size_t)wl * hl + kTemplatePad)));
-    DSM_HIP(hipMemset(t->d_pts[l], 0, sizeof(float4) * ((size_t)wl * hl + kTemplatePad)));
+    DSM_HIP(hipMemsetAsync(t->d_pts[l], 0, sizeof(float4) * ((size_t)wl * hl + kTemplatePad), ctx->stream)); // (not the null stream: streams_overlap)
     t->pts_cap[l] = wl * hl;
     for (int s = 0; s < 2; s++) {
       DSM_HIP(hipMalloc(&t->d_img[s][l], plane_bytes(wl, hl)));
@@ -429,6 +436,7 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
   }
   DSM_HIP(hipMalloc(&t->d_desc, sizeof(TrackerDev)));
   t->desc_dirty = true;
+  DSM_HIP(hipStreamSynchronize(ctx->stream)); // the zero fills are through before any other stream may write these buffers
   return DSM_OK;
 }
 
@@ -1008,8 +1016,8 @@ int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pt
   (void)t;
   (void)lvl;
   if (threads) *threads = kThreads;
-  if (pts_per_thread_out) *pts_per_thread_out = pts_per_thread(n);
-  if (chunks) *chunks = num_chunks(n);
+  if (pts_per_thread_out) *pts_per_thread_out = pts_per_thread(n, t->desc.p.geometry);
+  if (chunks) *chunks = num_chunks(n, t->desc.p.geometry);
   return DSM_OK;
 }
 
@@ -1064,18 +1072,87 @@ hipEvent_t get_event(dsm_context *ctx, size_t idx) {
 
 // streams of the segments of a launch schedule: `ng` stream groups (the context's stream + ng - 1 extra ones) and, on
 // request, the companion stream
-int ensure_streams(dsm_context *ctx, int ng, bool companion) {
-  if (companion && !ctx->companion_stream) {
-    DSM_HIP(hipStreamCreateWithFlags(&ctx->companion_stream, hipStreamNonBlocking));
-    DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
+// Do kernels of streams a and b run at the same time?  (The runtime maps streams onto a few hardware queues -- four by default --
+// round robin, together with every other stream of the process; two streams that share a queue serialise.  Measured in round 5: a
+// hipMemset on the null stream in dsm_tracker_create shifted the assignment, two of the three stream groups of dsm_stream_* landed on
+// one queue, and the bench lost 6 % on 512 frames, 15 % on 256 and 30 % on the sparse template -- profiles/r05_ab_bisect.log.)
+// A kernel that stays resident for 400 us on a, an empty one on b behind it in host order: b's finishes early only on another queue.
+static int streams_overlap(dsm_context *ctx, hipStream_t a, hipStream_t b, bool *overlap) {
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+  const double wait_ms = 0.4;
+  hipEvent_t e0, e1;
+  DSM_HIP(hipEventCreate(&e0));
+  DSM_HIP(hipEventCreate(&e1));
+  int rc = DSM_OK;
+  float ms = 0.f;
+  hipError_t e = hipSuccess;
+  for (int pass = 0; pass < 2 && e == hipSuccess; pass++) { // (pass 0 loads the two kernels)
+    e = hipEventRecord(e0, a);
+    launch_queue_probe_wait(a, pass == 0 ? 1 : (long long)(wait_ms * khz));
+    launch_queue_probe_empty(b);
+    if (e == hipSuccess) e = hipEventRecord(e1, b);
+    if (e == hipSuccess) e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
   }
-  while ((int)ctx->extra_streams.size() < ng - 1) {
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (e != hipSuccess) rc = hip_fail(e, "queue probe", __FILE__, __LINE__);
+  *overlap = ms < 0.5 * wait_ms;
+  return rc;
+}
+// a new stream whose kernels run concurrently with those of every stream in `with` (up to 12 candidates: the runtime hands out its
+// queues round robin, so a few rejected candidates later one on a free queue comes up); none found -- fewer hardware queues than
+// streams wanted (GPU_MAX_HW_QUEUES) --: the last candidate, counted in ctx->streams_sharing_a_queue
+static int create_concurrent_stream(dsm_context *ctx, const std::vector<hipStream_t> &with, hipStream_t *out) {
+  std::vector<hipStream_t> rejected;
+  hipStream_t found = nullptr;
+  int rc = DSM_OK;
+  for (int attempt = 0; attempt < 12 && !found && rc == DSM_OK; attempt++) {
     hipStream_t st;
-    DSM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+      break;
+    }
+    bool ok = true;
+    for (size_t i = 0; i < with.size() && ok && rc == DSM_OK; i++) rc = streams_overlap(ctx, with[i], st, &ok);
+    if (ok && rc == DSM_OK)
+      found = st;
+    else
+      rejected.push_back(st);
+  }
+  if (!found && rc == DSM_OK && !rejected.empty()) {
+    found = rejected.back();
+    rejected.pop_back();
+    ctx->streams_sharing_a_queue++;
+  }
+  for (hipStream_t st : rejected) hipStreamDestroy(st);
+  *out = found;
+  return rc;
+}
+
+int ensure_streams(dsm_context *ctx, int ng, bool companion) {
+  auto in_use = [&]() {
+    std::vector<hipStream_t> v{ctx->stream};
+    v.insert(v.end(), ctx->extra_streams.begin(), ctx->extra_streams.end());
+    if (ctx->companion_stream) v.push_back(ctx->companion_stream);
+    return v;
+  };
+  while ((int)ctx->extra_streams.size() < ng - 1) { // (the groups first: they carry the large kernels)
+    hipStream_t st;
+    const int rc = create_concurrent_stream(ctx, in_use(), &st);
+    if (rc) return rc;
     ctx->extra_streams.push_back(st);
     hipEvent_t ev;
     DSM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     ctx->join_events.push_back(ev);
+  }
+  if (companion && !ctx->companion_stream) {
+    const int rc = create_concurrent_stream(ctx, in_use(), &ctx->companion_stream);
+    if (rc) return rc;
+    DSM_HIP(hipEventCreateWithFlags(&ctx->companion_event, hipEventDisableTiming));
   }
   return DSM_OK;
 }
@@ -1247,7 +1324,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     // plane does not fit the kernel's LDS arena.
     const int max_px = P.persistent_coarse;
     bool any = false;
-    for (int i = 0; i < N && !any; i++) any = coarse_level_fits(ts[i]->w >> coarsest, ts[i]->h >> coarsest, ts[i]->desc.lv[coarsest].n, max_px);
+    for (int i = 0; i < N && !any; i++) any = coarse_level_fits(ts[i]->w >> coarsest, ts[i]->h >> coarsest, ts[i]->desc.lv[coarsest].n, ts[i]->desc.p.geometry, max_px);
     if (any) {
       if (ng > 1 || top2 >= 0) {
         DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
@@ -1270,7 +1347,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
         int t = -1;
         for (int i = i0; i < i1; i++)
           for (int L = coarsest; L > t; L--)
-            if (!coarse_level_fits(ts[i]->w >> L, ts[i]->h >> L, ts[i]->desc.lv[L].n, max_px)) {
+            if (!coarse_level_fits(ts[i]->w >> L, ts[i]->h >> L, ts[i]->desc.lv[L].n, ts[i]->desc.p.geometry, max_px)) {
               t = L;
               break;
             }
@@ -1693,7 +1770,7 @@ int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const
     hipFree(t->d_pts[l]);
     t->d_pts[l] = nullptr;
     hipError_t e = hipMalloc(&t->d_pts[l], sizeof(float4) * ((size_t)w * h + kTemplatePad));
-    if (e == hipSuccess) e = hipMemset(t->d_pts[l], 0, sizeof(float4) * ((size_t)w * h + kTemplatePad));
+    if (e == hipSuccess) e = hipMemsetAsync(t->d_pts[l], 0, sizeof(float4) * ((size_t)w * h + kTemplatePad), ctx->stream);
     if (e != hipSuccess) {
       dsm_tracker_destroy(t);
       DSM_HIP(e);
@@ -1702,6 +1779,13 @@ int dsm_pose_estimator_create(dsm_context *ctx, int w, int h, int nlevels, const
     t->desc.lv[l].pts = t->d_pts[l];
   }
   t->desc_dirty = true;
+  {
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      dsm_tracker_destroy(t);
+      DSM_HIP(e);
+    }
+  }
   dsm_pose_estimator *pe = new dsm_pose_estimator();
   pe->t = t;
   *out = pe;

@@ -42,6 +42,7 @@ struct ParamsDev {
   float lambda_extrapolation_limit;
   int max_iterations[DSM_MAX_LEVELS];
   int fixed_schedule; // dsm_params.fixed_schedule: K > 0 = benchmark schedule (1 + K evaluations per level, every step taken)
+  int geometry;       // dsm_params.chunk_geometry: which table picks the points per thread of a chunk (dsm_kernels.hpp)
 };
 
 // Read-only (during track / optimize_scale) description of one TrackerAndScaler.
@@ -63,6 +64,7 @@ struct EvalIn {
   const float4 *pts;
   const float *img;
   int n, w, h;
+  int ppt, pad0, pad1, pad2; // points per thread of a chunk of this evaluation (pts_per_thread of n under the tracker's table); the struct stays a multiple of 16 bytes
   int residual_only; // the LM loop ends after this evaluation whatever it yields (:588, the iteration bound): only the
                      // residual side (calcResPose / calcResScale) is needed -- the normal equations calcGSSSE* would build
                      // from it are never read by the reference either

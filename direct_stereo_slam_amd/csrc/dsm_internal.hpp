@@ -28,6 +28,7 @@ struct dsm_context {
   std::vector<hipStream_t> extra_streams;
   std::vector<hipEvent_t> join_events;
   hipEvent_t fork_event = nullptr;
+  int streams_sharing_a_queue = 0;        // streams of ensure_streams that could not be given a hardware queue of their own
   hipStream_t companion_stream = nullptr; // the companion segment of dsm_track_and_scale_batch
   hipEvent_t companion_event = nullptr;
   hipEvent_t copy_event = nullptr; // end of a host->device hand-over (dsm_tracker_upload_image)

@@ -6,23 +6,35 @@
 
 namespace dsm {
 
-// Reduction geometry (part of the documented numerics): a workgroup of
-// 256 threads owns a chunk of 256*P consecutive template points, thread t handles points
-// chunk*256*P + k*256 + t for k = 0..P-1.
-__host__ __device__ inline int pts_per_thread(int n) {
-  return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
+// Reduction geometry (part of the documented numerics): a workgroup of 256 threads owns a chunk of 256*P
+// consecutive template points, thread t handles points chunk*256*P + k*256 + t for k = 0..P-1.  P is chosen per level from its point
+// count by one of two tables (dsm_params.chunk_geometry):
+//   throughput (0, the default): long chunks -- the per-chunk prologue (three dependent memory round trips before the first point's
+//     arithmetic) and epilogue (52 row sums, a barrier, the partial) are paid once per 16 points per thread down to levels of 16 k points.
+//     Many problems in flight: the stream, the batched calls.  Measured against the other table on the streamed bench: + 7 %
+//     (profiles/r05_ab_geometry.log; the levels below 0 run 10-45 % faster, the LM step reads half the partials)
+//   latency (1): short chunks -- more workgroups per evaluation, each through sooner: ONE problem in flight (the replay adaptors):
+//     0.53 instead of 0.61 ms per frame there
+// Results differ between the tables in the last bits of the float sums only (another summation tree); integer outputs are identical.
+enum { kGeomThroughput = 0, kGeomLatency = 1 };
+__host__ __device__ inline int pts_per_thread(int n, int geom) {
+  if (geom == kGeomLatency) return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
+  return n >= 16 * 1024 ? 16 : n >= 4 * 1024 ? 8 : n >= 1024 ? 4 : n >= 512 ? 2 : 1;
 }
-__host__ __device__ inline int num_chunks(int n) {
-  const int per = kThreads * pts_per_thread(n);
+// chunks of a list of n points at P points per thread
+__host__ __device__ inline int chunks_of(int n, int ppt) {
+  const int per = kThreads * ppt;
   return (n + per - 1) / per;
 }
+__host__ __device__ inline int num_chunks(int n, int geom) { return chunks_of(n, pts_per_thread(n, geom)); }
 
-// largest chunk count any n <= cap can produce (P grows with n, so num_chunks is not monotone)
+// largest chunk count any n <= cap can produce under either table (P grows with n, so num_chunks is not monotone)
 inline int max_chunks_upto(int cap) {
-  int best = num_chunks(cap);
-  const int edges[4] = {256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1};
-  for (int e : edges)
-    if (e <= cap && num_chunks(e) > best) best = num_chunks(e);
+  int best = 0;
+  const int edges[8] = {cap, 256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1, 1023, 511, 255};
+  for (int g = 0; g < 2; g++)
+    for (int e : edges)
+      if (e <= cap && num_chunks(e, g) > best) best = num_chunks(e, g);
   return best;
 }
 
@@ -100,11 +112,6 @@ struct TickResult { // a retired problem (device -> host)
   float scale_cur, pad1;
   long long evals[DSM_MAX_LEVELS], evals_ro[DSM_MAX_LEVELS], rounds[DSM_MAX_LEVELS];
 };
-// positions a problem's evaluation occupies in an item list: its chunks, rounded so that every XCD owns a contiguous band
-__host__ __device__ inline int tick_positions(int n) {
-  const int nch = num_chunks(n);
-  return nch < 8 ? nch : 8 * ((nch + 7) >> 3);
-}
 // start of an advance, before the stream groups fork: which free slot takes which entry of the waiting ring (tick_reserve_kernel)
 constexpr int kTickMaxSegs = 20;
 struct TickSegDesc {
@@ -127,7 +134,7 @@ void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trac
 // by the kernel's LDS arena): coarse_level_fits tells whether a level of w x h pixels and n template points qualifies
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_px, bool spec);
-bool coarse_level_fits(int w, int h, int n, int max_px);
+bool coarse_level_fits(int w, int h, int n, int geom, int max_px);
 
 // row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip), batched over the keyframes of a call
 struct TplJob {
@@ -157,7 +164,7 @@ void launch_scale_depth_levels(hipStream_t s, const ScaleDepthArgs &a, int max_n
 // zeros, never used: masked), so the slack is only a second line of defence for the paths that read the list with plain loads
 constexpr int kTemplatePad = 1024;
 // chunks of an evaluation of level L of a tracker
-inline int level_chunks(const TrackerDev &d, int L) { return num_chunks(d.lv[L].n); }
+inline int level_chunks(const TrackerDev &d, int L) { return num_chunks(d.lv[L].n, d.p.geometry); }
 // makeImages (upstream DSO): the intensity plane of level 0 from the float image, of level l from level l-1
 void launch_pyramid(hipStream_t s, int w, int h, int nlevels, const float *raw, float *const *img);
 // the reference's (I, dx, dy) texels out of / into an intensity plane; with d_bad != nullptr import counts the texels whose
@@ -175,6 +182,10 @@ void launch_desc_scatter(hipStream_t s, int n, const TrackerDev *d_src, TrackerD
 // raw <- src for every job, rows of row_bytes at pitch `pitch` in src (tight in raw); unit: 16, 4 or 1 bytes per access
 void launch_host_rows_copy(hipStream_t s, const PyrJob *d_jobs, int njobs, int row_bytes, int rows, size_t pitch, int unit, int max_blocks);
 void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJob *d_jobs, int njobs, bool u8);
+
+// queue probe of ensure_streams (diag_kernels.hip): a kernel resident for `ticks` of the wall clock, and an empty one
+void launch_queue_probe_wait(hipStream_t s, long long ticks);
+void launch_queue_probe_empty(hipStream_t s);
 
 // ring-key kernels
 void launch_ringkey_knn(hipStream_t s, const float *keysT, int64_t cap, int64_t n_local, int dim,

@@ -539,6 +539,15 @@ int dsm_loop_detect_batch(dsm_context *ctx, dsm_ringdb *db, int n_jobs, const ds
   rc = loop_finish(ctx, jobs, P, &h_cand_v);
   if (rc) return rc;
   const unsigned long long *h_cand = (const unsigned long long *)h_cand_v;
+  if (!search) {
+    // The index is still too small to be searched (search_place.h:29) and may grow past that inside this batch: the first keyframes of a
+    // run take the calls one by one (their descriptors are already here; exact by definition, and a handful of calls in a run's life)
+    for (int j = 0; j < n_jobs; j++) {
+      rc = dsm_ringdb_query_then_enqueue(db, jobs[j].ringkey, cand_out + (size_t)j * k, ncand_out + j);
+      if (rc) return rc;
+    }
+    return DSM_OK;
+  }
   // the sequential semantics on the host: matured keys and the queries that see them
   std::vector<float> matured; // keys that entered the index during this batch, in order
   const long long base = db->size_global;
@@ -580,7 +589,6 @@ int dsm_loop_detect_batch(dsm_context *ctx, dsm_ringdb *db, int n_jobs, const ds
           if (nb < k) nb++;
         }
       }
-      // (the index was too small for the device to search but has grown past k inside the batch: cannot happen with margin >= k)
     }
     int nc = 0;
     for (int i = 0; i < nb && i < k; i++) {

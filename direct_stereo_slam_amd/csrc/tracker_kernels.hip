@@ -228,6 +228,7 @@ struct EvalConsts {
   const float4 *pts;
   const float *img;
   int n, w, h;
+  int ppt; // EvalIn::ppt
   float fx, fy, cx, cy;
   float Ki[9];
   float huber;
@@ -259,11 +260,26 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img 
 // (the 96-register kernels of five waves per SIMD), 1 the warp's twelve (the two-point loop at four waves per SIMD: 128 registers hold
 // these and no more), 2 the camera, gradient-scale and brightness constants as well (the one-point loop inside a kernel that is
 // allocated 128 registers anyway: tick_eval_kernel)
+#ifdef DSM_EXP_STAMPS // EXPERIMENT: where a tick workgroup's life goes (shader-clock stamps of wave 0, summed per level)
+__device__ unsigned long long g_st_sum[DSM_MAX_LEVELS][8], g_st_cnt[DSM_MAX_LEVELS];
+__device__ __forceinline__ unsigned long long exp_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define DSM_STAMP(k) do { if (st) st[k] = exp_stamp(); } while (0)
+#else
+#define DSM_STAMP(k) do { } while (0)
+#endif
 template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                                float *out, int *arrive = nullptr) {
+                                                float *out, int *arrive = nullptr
+#ifdef DSM_EXP_STAMPS
+                                                , unsigned long long *st = nullptr
+#endif
+                                                ) {
   const int n = c.n;
-  const int P = pts_per_thread(n);
+  const int P = c.ppt;
   constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
   float acc[NACC];
 #pragma unroll
@@ -438,87 +454,14 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       }
     };
 
-    {
-      // Template stream: entry (start + tid) of the list = one coalesced 16-byte load per lane from a wave-uniform base (SGPR pair)
-      // plus this thread's constant byte offset -- no per-point index arithmetic.  Entries past the chunk (the loop prefetches up to
-      // three trips ahead) or past the list are never used: their lanes are masked, and an entry past the list reads as zeros (the
-      // buffer descriptor checks the range); the LDS copy (coarse_kernel) is read with a clamped index instead.
-      const unsigned voff = 16u * (unsigned)tid;
-      const unsigned lds_pts = c.lds_pts;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.pts, 0, 16 * n, 0x00020000);
-      auto load_pt = [=](int start) {
-        if constexpr (LDSPTS) {
-          const int idx = start + tid;
-          return *(const DSM_LDS fvec4 *)(size_t)(lds_pts + 16u * (unsigned)(idx < n ? idx : n - 1));
-        } else {
-          // streamed once: non-temporal (aux = 2), so the template does not evict target rows from the 32 KiB L1 (+2.5 %).
-          // buffer_load ... offen: descriptor and the trip's byte offset in SGPRs, this thread's constant offset in a VGPR -- no vector
-          // address arithmetic at all; an entry beyond the list reads as zeros (range-checked by the descriptor).
-          const uvec4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * start, 2);
-          return fvec4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-        }
-      };
-      // lanes whose entry `start + tid` exists and whose trip belongs to the chunk: every lane except in the list's last chunk
-      const bool tail = chunk_start + kThreads * P > n;
-      auto listed = [=](int start, bool trip) -> lmask {
-        if (!trip) return 0ull;
-        return mask_sgpr(tail ? (lmask)__builtin_amdgcn_sicmp(tid, n - start, kSLT) : full);
-      };
-      const int i = chunk_start;
-      const fvec4 p0 = load_pt(i);
-      if (DEEP) {
-        // Level 0 (long loops, HBM-resident targets): two points per trip with FIXED register roles (sets a / b).
-        // The taps of point k+1 are issued before the arithmetic of point k and awaited only after the taps of
-        // point k+2 have been issued, so two points' gathers are in flight per wave; template entries are fetched
-        // two points ahead.  (The rotating single-body loop below makes the compiler copy the freshly loaded tap
-        // registers at the back-edge, which waits for them -- vmcnt(0) -- and leaves only the arithmetic of one
-        // point to cover the memory latency; it needs 7 VGPRs less, which is one more resident wave per SIMD and
-        // worth more than the deeper pipeline on the small, cache-resident levels: level 0 +5 %, levels 1-3 -7..-10 %
-        // with this form.)  Points beyond the chunk / the list are masked (they add exact zeros), so odd P needs
-        // no special case.
-        fvec4 ea = load_pt(i + kThreads), eb = load_pt(i + 2 * kThreads);
-        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-        Warped Wa, Wb;
-        Taps Ta, Tb;
-        stage_a(p0, listed(i, true), Wa, Ta);
-        int ia = i + kThreads; // start of the entries held in ea (eb: ia + kThreads)
-        for (int k = 0; k < P; k += 2) {
-          stage_a(ea, listed(ia, k + 1 < P), Wb, Tb); // point k+1
-          ea = load_pt(ia + 2 * kThreads);
-          stage_b(Wa, Ta); // point k
-          stage_a(eb, listed(ia + kThreads, k + 2 < P), Wa, Ta); // point k+2
-          eb = load_pt(ia + 3 * kThreads);
-          stage_b(Wb, Tb); // point k+1 (masked when k+1 == P)
-          ia += 2 * kThreads;
-        }
-      } else {
-        // Template stream prefetched one point ahead.
-        int i2 = i + kThreads;
-        fvec4 p_next = load_pt(i2);
-        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-        Warped Wc;
-        Taps Tc;
-        stage_a(p0, listed(i, true), Wc, Tc);
-        for (int k = 0; k < P; k++) {
-          // stage A for point k+1 (its template entry was prefetched one iteration ago)
-          const fvec4 p = p_next;
-          const lmask in_next = listed(i2, k + 1 < P);
-          const int i3 = i2 + kThreads;
-          p_next = load_pt(i3);
-          Warped Wn;
-          Taps Tn;
-          stage_a(p, in_next, Wn, Tn);
-          // stage B for point k
-          stage_b(Wc, Tc);
-          Wc = Wn;
-          Tc = Tn;
-          i2 = i3;
-        }
-      }
-    }
-
+#ifdef DSM_EXP_FLOWFIRST
+    constexpr bool FLOW_FIRST = LVL0 && DEEP; // EXPERIMENT: the flow-indicator pass while the first template entries are on their way
+#else
+    constexpr bool FLOW_FIRST = false;
+#endif
     // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
     // handles the 8*P such points of this chunk in a single pass.
+    auto flow_pass = [&]() {
     if (LVL0 && tid < 8 * P) {
       const int i = chunk_start + 32 * tid;
       if (i < n) {
@@ -576,8 +519,102 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         fNum += 2;
       }
     }
+    };
+    {
+      // Template stream: entry (start + tid) of the list = one coalesced 16-byte load per lane from a wave-uniform base (SGPR pair)
+      // plus this thread's constant byte offset -- no per-point index arithmetic.  Entries past the chunk (the loop prefetches up to
+      // three trips ahead) or past the list are never used: their lanes are masked, and an entry past the list reads as zeros (the
+      // buffer descriptor checks the range); the LDS copy (coarse_kernel) is read with a clamped index instead.
+      const unsigned voff = 16u * (unsigned)tid;
+      const unsigned lds_pts = c.lds_pts;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)c.pts, 0, 16 * n, 0x00020000);
+      auto load_pt = [=](int start) {
+        if constexpr (LDSPTS) {
+          const int idx = start + tid;
+          return *(const DSM_LDS fvec4 *)(size_t)(lds_pts + 16u * (unsigned)(idx < n ? idx : n - 1));
+        } else {
+          // streamed once: non-temporal (aux = 2), so the template does not evict target rows from the 32 KiB L1 (+2.5 %).
+          // buffer_load ... offen: descriptor and the trip's byte offset in SGPRs, this thread's constant offset in a VGPR -- no vector
+          // address arithmetic at all; an entry beyond the list reads as zeros (range-checked by the descriptor).
+          const uvec4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * start, 2);
+          return fvec4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+      };
+      // lanes whose entry `start + tid` exists and whose trip belongs to the chunk: every lane except in the list's last chunk
+      const bool tail = chunk_start + kThreads * P > n;
+      auto listed = [=](int start, bool trip) -> lmask {
+        if (!trip) return 0ull;
+        return mask_sgpr(tail ? (lmask)__builtin_amdgcn_sicmp(tid, n - start, kSLT) : full);
+      };
+      const int i = chunk_start;
+      const fvec4 p0 = load_pt(i);
+      if (DEEP) {
+        // Level 0 (long loops, HBM-resident targets): two points per trip with FIXED register roles (sets a / b).
+        // The taps of point k+1 are issued before the arithmetic of point k and awaited only after the taps of
+        // point k+2 have been issued, so two points' gathers are in flight per wave; template entries are fetched
+        // two points ahead.  (The rotating single-body loop below makes the compiler copy the freshly loaded tap
+        // registers at the back-edge, which waits for them -- vmcnt(0) -- and leaves only the arithmetic of one
+        // point to cover the memory latency; it needs 7 VGPRs less, which is one more resident wave per SIMD and
+        // worth more than the deeper pipeline on the small, cache-resident levels: level 0 +5 %, levels 1-3 -7..-10 %
+        // with this form.)  Points beyond the chunk / the list are masked (they add exact zeros), so odd P needs
+        // no special case.
+        fvec4 ea = load_pt(i + kThreads), eb = load_pt(i + 2 * kThreads);
+        if (FLOW_FIRST) { // its point load travels with the three above; the sums wait in the reduction scratch, not in registers
+          flow_pass();
+          const float sT = row16_sum(fT), sRT = row16_sum(fRT), sN = row16_sum(fNum);
+          if ((tid & 15) == 0) {
+            const int row_ = (tid >> 6) * 4 + ((tid & 63) >> 4);
+            red[row_][kSlotFlowT] = sT, red[row_][kSlotFlowRT] = sRT, red[row_][kSlotFlowNum] = sN;
+          }
+          fT = fRT = fNum = 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+        DSM_STAMP(2);
+        Warped Wa, Wb;
+        Taps Ta, Tb;
+        stage_a(p0, listed(i, true), Wa, Ta);
+        int ia = i + kThreads; // start of the entries held in ea (eb: ia + kThreads)
+        for (int k = 0; k < P; k += 2) {
+          stage_a(ea, listed(ia, k + 1 < P), Wb, Tb); // point k+1
+          ea = load_pt(ia + 2 * kThreads);
+          stage_b(Wa, Ta); // point k
+          stage_a(eb, listed(ia + kThreads, k + 2 < P), Wa, Ta); // point k+2
+          eb = load_pt(ia + 3 * kThreads);
+          stage_b(Wb, Tb); // point k+1 (masked when k+1 == P)
+          ia += 2 * kThreads;
+        }
+      } else {
+        // Template stream prefetched one point ahead.
+        int i2 = i + kThreads;
+        fvec4 p_next = load_pt(i2);
+        __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
+        DSM_STAMP(2);
+        Warped Wc;
+        Taps Tc;
+        stage_a(p0, listed(i, true), Wc, Tc);
+        for (int k = 0; k < P; k++) {
+          // stage A for point k+1 (its template entry was prefetched one iteration ago)
+          const fvec4 p = p_next;
+          const lmask in_next = listed(i2, k + 1 < P);
+          const int i3 = i2 + kThreads;
+          p_next = load_pt(i3);
+          Warped Wn;
+          Taps Tn;
+          stage_a(p, in_next, Wn, Tn);
+          // stage B for point k
+          stage_b(Wc, Tc);
+          Wc = Wn;
+          Tc = Tn;
+          i2 = i3;
+        }
+      }
+    }
 
-
+#ifdef DSM_EXP_STAMPS
+    asm volatile("" : "+v"(E));
+    DSM_STAMP(3);
+#endif
+    if (!FLOW_FIRST) flow_pass();
   } // active
   // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
   const int lane = tid & 63, wave = tid >> 6;
@@ -593,16 +630,24 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     // n_terms / n_sat / n_warped are wave totals (identical in every lane): count them once per wave
     const bool first = lane == 0;
     const int iT = first ? n_terms : 0, iS = first ? n_sat : 0, iW = first ? n_warped : 0; // (a row's writer is its lane 0: the wave's first row carries the totals)
-    if (writer) {
-      red[row][kSlotE] = sE;
+#ifdef DSM_EXP_FLOWFIRST
+    const bool parked = LVL0 && DEEP && active;
+#else
+    const bool parked = false;
+#endif
+    if (writer && !parked) {
       red[row][kSlotFlowT] = sT;
       red[row][kSlotFlowRT] = sRT;
       red[row][kSlotFlowNum] = sN;
+    }
+    if (writer) {
+      red[row][kSlotE] = sE;
       red[row][kSlotNTerms] = __int_as_float(iT);
       red[row][kSlotNSat] = __int_as_float(iS);
       red[row][kSlotNWarped] = __int_as_float(iW);
     }
   }
+  DSM_STAMP(4);
   int slot = tid;
   if (arrive) {
     // a wave's LDS operations are performed in order: its rows are in place before its ticket is counted
@@ -615,6 +660,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   } else {
     __syncthreads();
   }
+  DSM_STAMP(5);
   const bool is_float_slot = slot < NACC || (slot >= kSlotE && slot < kSlotNTerms);
   if (!active) {
   } else if (is_float_slot) {
@@ -632,11 +678,22 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 template <int MODE, bool LVL0, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                           float *out, int *arrive = nullptr) {
+                                           float *out, int *arrive = nullptr
+#ifdef DSM_EXP_STAMPS
+                                           , unsigned long long *st = nullptr
+#endif
+                                           ) {
+#ifdef DSM_EXP_STAMPS
+  if (c.residual_only) // wave-uniform
+    eval_chunk_impl<MODE, LVL0, true, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive, st);
+  else
+    eval_chunk_impl<MODE, LVL0, false, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive, st);
+#else
   if (c.residual_only) // wave-uniform
     eval_chunk_impl<MODE, LVL0, true, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
   else
     eval_chunk_impl<MODE, LVL0, false, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -668,6 +725,7 @@ __device__ __forceinline__ void make_eval_pose(const TrackerDev &T, EvalIn &e, i
     e.pts = L.pts;
     e.img = L.img[0]; // new left frame (:709)
     e.n = L.n;
+    e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
     e.w = L.w;
     e.h = L.h;
     e.fx = L.fx;
@@ -710,6 +768,7 @@ __device__ __forceinline__ void make_eval_scale(const TrackerDev &T, EvalIn &e, 
     e.pts = L.pts;
     e.img = L.img[1]; // right frame fh1_ (:1016)
     e.n = L.n;
+    e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
     e.w = L.w;
     e.h = L.h;
     e.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
@@ -756,6 +815,7 @@ __device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &
   e.pts = L.pts;
   e.img = L.img[0];
   e.n = L.n;
+  e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
   e.w = L.w;
   e.h = L.h;
   e.fx = L.fx;
@@ -1459,9 +1519,10 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
   // the pending evaluation was built for this level
   const int n_lvl = COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
-  reduce_partials_groups(partials_prob, num_chunks(n_lvl), tid, sh.red);
+  const int ppt_lvl = COH ? __hip_atomic_load(&S.in.ppt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.ppt;
+  reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red);
   if (sp) { // (garbage where no speculative candidate was evaluated: never looked at then)
-    reduce_partials_groups(partials_prob + spec_off, num_chunks(n_lvl), tid, sp->red);
+    reduce_partials_groups(partials_prob + spec_off, chunks_of(n_lvl, ppt_lvl), tid, sp->red);
     if (tid == 0) sp->cmd = 0, sp->done = 0;
   }
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
@@ -1523,7 +1584,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
   const int s_status = S.status, s_lvl = S.lvl, s_kind = S.is_scale, s_spec_valid = S.spec_valid;
   EvalConsts c;
-  c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h;
+  c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h, c.ppt = in.ppt;
   c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
 #pragma unroll
   for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
@@ -1548,7 +1609,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   if (ROSEL == 1 && c.residual_only) return;
   if (ROSEL == 2 && !c.residual_only) return;
   const int n = c.n;
-  const int P = pts_per_thread(n);
+  const int P = c.ppt;
   const int nchunks = (n + kThreads * P - 1) / (kThreads * P);
   // XCD-aware chunk mapping: workgroup b is dispatched to XCD b % 8, so give each XCD a
   // contiguous band of the template (and therefore of the target rows it gathers from).  Levels of fewer than 8 chunks get
@@ -1707,7 +1768,7 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   }
 
   // LM_OP_SINGLE_FINISH: reduced sums -> rs, H, b of one evaluation (dsm_tracker_calc_res_*)
-  reduce_partials_groups(partials + (size_t)prob * partial_stride, num_chunks(S.in.n), tid, sh.red);
+  reduce_partials_groups(partials + (size_t)prob * partial_stride, chunks_of(S.in.n, S.in.ppt), tid, sh.red);
   __syncthreads();
   if (tid >= 64) return;
   reduce_partials_final(lane, sh.red);
@@ -1762,8 +1823,8 @@ constexpr int kCoarseMaxChunks = 20;      // chunks of one evaluation whose part
 constexpr int kCoarseArenaFloats = 9216;  // 36 KB: planes up to 120 x 67 (level 4 of 1920 x 1080), 156 x 48 (level 3 of 1248 x 384)
 
 // a level runs in coarse_kernel iff its target plane fits the arena and its chunk partials fit the LDS block (host and device)
-__host__ __device__ inline bool coarse_level_ok(int w, int h, int n, int arena_floats) {
-  return ((w * h + 3) & ~3) <= arena_floats && num_chunks(n) <= kCoarseMaxChunks;
+__host__ __device__ inline bool coarse_level_ok(int w, int h, int nchunks, int arena_floats) {
+  return ((w * h + 3) & ~3) <= arena_floats && nchunks <= kCoarseMaxChunks;
 }
 
 template <int MODE, bool LVL0>
@@ -1796,6 +1857,7 @@ __device__ __forceinline__ void eval_consts_from_lds(const EvalIn &in, EvalConst
   c.img = (const float *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) |
                           (unsigned)__builtin_amdgcn_readfirstlane((int)ip));
   c.n = __builtin_amdgcn_readfirstlane(in.n);
+  c.ppt = __builtin_amdgcn_readfirstlane(in.ppt);
   c.w = __builtin_amdgcn_readfirstlane(in.w);
   c.h = __builtin_amdgcn_readfirstlane(in.h);
   c.fx = rf(in.fx), c.fy = rf(in.fy), c.cx = rf(in.cx), c.cy = rf(in.cy), c.huber = rf(in.huber);
@@ -1833,7 +1895,7 @@ __global__ __launch_bounds__(kCoarseThreads) __attribute__((amdgpu_waves_per_eu(
     const int status = sh.st.status, lvl = __builtin_amdgcn_readfirstlane(sh.st.lvl);
     EvalConsts c;
     eval_consts_from_lds(in, c);
-    if (status != ST_RUNNING || !coarse_level_ok(c.w, c.h, c.n, arena_floats)) break; // workgroup-uniform
+    if (status != ST_RUNNING || !coarse_level_ok(c.w, c.h, chunks_of(c.n, c.ppt), arena_floats)) break; // workgroup-uniform
     stepped = true;
     if (lvl != staged_lvl) { // entering a level: its plane (and the template, when both fit) -> LDS
       const int px4 = (c.w * c.h + 3) >> 2; // (planes carry four rows of slack: reading up to three floats past w*h is safe)
@@ -1852,7 +1914,7 @@ __global__ __launch_bounds__(kCoarseThreads) __attribute__((amdgpu_waves_per_eu(
     }
     c.lds_img = arena_lds;
     c.lds_pts = lds_pts;
-    const int nch = num_chunks(c.n);
+    const int nch = chunks_of(c.n, c.ppt);
     const bool have_spec = spec && sh.st.spec_valid != 0; // workgroup-uniform
     for (int cand = 0; cand < (have_spec ? 2 : 1); cand++) {
       if (cand == 1) {
@@ -1917,9 +1979,9 @@ void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *
   else
     hipLaunchKernelGGL((coarse_kernel<2>), grid, block, dyn, s, trackers, states, status_out, arena_floats, spec ? 1 : 0);
 }
-bool coarse_level_fits(int w, int h, int n, int max_px) {
+bool coarse_level_fits(int w, int h, int n, int geom, int max_px) {
   if (max_px > kCoarseArenaFloats) max_px = kCoarseArenaFloats;
-  return coarse_level_ok(w, h, n, (max_px + 3) & ~3);
+  return coarse_level_ok(w, h, num_chunks(n, geom), (max_px + 3) & ~3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1968,7 +2030,7 @@ __global__ __launch_bounds__(256) void queue_seed_kernel(int mode, const LMState
   if (p >= nprob) return;
   const LMState &S0 = states[p];
   if (S0.status == ST_RUNNING && S0.is_scale == mode) {
-    const int nch = num_chunks(S0.in.n);
+    const int nch = chunks_of(S0.in.n, S0.in.ppt);
     queue_push(q, items, qmask, p, nch > 0 ? nch : 1, lane);
   } else if (lane == 0) {
     atomicAdd(&q->done, 1u);
@@ -2028,7 +2090,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
     const int lvl = __builtin_amdgcn_readfirstlane(s_ctl[2]);
     EvalConsts c;
     eval_consts_from_lds(s_in, c);
-    const int nch = num_chunks(c.n);
+    const int nch = chunks_of(c.n, c.ppt);
     const int nitems = nch > 0 ? nch : 1; // an empty level still needs its LM step
     float *partials_prob = partials + (size_t)prob * partial_stride;
     if (chunk < nch) {
@@ -2054,7 +2116,7 @@ __global__ __launch_bounds__(kThreads, 4) void queue_kernel(const TrackerDev *co
       if (tid < 64) {
         xwg_release(); // new state (and the ticket reset) performed at device scope before the items appear
         if (sh.st.status == ST_RUNNING) {
-          const int nn = num_chunks(sh.st.in.n);
+          const int nn = chunks_of(sh.st.in.n, sh.st.in.ppt);
           queue_push(q, items, qmask, prob, nn > 0 ? nn : 1, tid);
         } else if (tid == 0) {
           atomicAdd(&q->done, 1u);
@@ -2102,7 +2164,7 @@ void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const Tracker
 // ------------------------------------------------------------------------------------------
 // wave 0: the items of the evaluation(s) staged in `St` (the main candidate and, where staged, the speculative one)
 __device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, int lane) {
-  const int nch = num_chunks(St.in.n), per_xcd = (nch + 7) >> 3;
+  const int nch = chunks_of(St.in.n, St.in.ppt), per_xcd = (nch + 7) >> 3;
   const int npos = nch < 8 ? nch : 8 * per_xcd;
   const int total = St.spec_valid ? 2 * npos : npos;
   if (total == 0) return; // an empty level: nothing to evaluate, the LM step runs anyway
@@ -2254,10 +2316,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                                                                                                   const unsigned *__restrict__ items,
                                                                                                   TickSegCtl *__restrict__ seg, int buf) {
   __shared__ float red[16][kNumSlots];
+#ifdef DSM_EXP_LDSPAD
+  __shared__ float ldspad[MODE == 0 ? DSM_EXP_LDSPAD : 4];
+  if (partial_stride == -1) ldspad[threadIdx.x] = 1.f, __syncthreads(), partials[threadIdx.x] = ldspad[threadIdx.x ^ 1];
+#endif
   const int n_items = ((const DSM_GLOBAL TickSegCtl *)seg)->count[buf];
   // the other list was consumed by the previous tick's evaluation; this tick's LM launch appends to it
   if (blockIdx.x == 0 && threadIdx.x == 0) seg->count[buf ^ 1] = 0;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+#ifdef DSM_EXP_STAMPS
+    unsigned long long stv[8];
+    unsigned long long *st = stv;
+    DSM_STAMP(0);
+#endif
     const unsigned item = ((const DSM_GLOBAL unsigned *)items)[it];
     if (item & kTickNoop) continue; // (workgroup-uniform)
     const bool cand = (item & kTickCand) != 0;
@@ -2266,7 +2337,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
     const int lvl = S.lvl;
     EvalConsts c;
-    c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h;
+    c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h, c.ppt = in.ppt;
     c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
 #pragma unroll
     for (int i = 0; i < 9; i++) c.Ki[i] = in.Ki[i], c.M[i] = in.M[i];
@@ -2275,10 +2346,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     c.residual_only = in.residual_only;
       eval_consts_defaults(c);
     float *const out = partials + (size_t)prob * partial_stride + (cand ? (partial_stride >> 1) : 0) + (size_t)chunk * kPartialStride;
+#ifdef DSM_EXP_STAMPS
+    asm volatile("" ::"s"(c.n), "s"(c.M[8]), "s"(c.max_energy), "s"(lvl));
+    DSM_STAMP(1);
+    if (lvl == 0)
+      eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out, nullptr, st);
+    else
+      eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out, nullptr, st);
+    DSM_STAMP(6);
+    if (MODE == 0 && threadIdx.x == 0 && !c.residual_only) {
+      for (int k = 1; k <= 6; k++) atomicAdd(&g_st_sum[lvl][k], st[k] - st[0]);
+      atomicAdd(&g_st_cnt[lvl], 1ull);
+    }
+#else
     if (lvl == 0)
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
+#ifdef DSM_EXP_DEEP16
+    else if (c.ppt >= 16)
+      eval_chunk<MODE, false, true>(c, chunk, threadIdx.x, true, red, out);
+#endif
     else
       eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out); // (this kernel is allocated 128 registers by its level-0 loop)
+#endif
     __syncthreads(); // red[] is reused by the next item (the arrival-ticket form of eval_kernel measured the same here: profiles/r05_ab_tick_arrival_ticket.log)
   }
 }
@@ -2565,3 +2654,16 @@ void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJ
 }
 
 } // namespace dsm
+
+#ifdef DSM_EXP_STAMPS
+extern "C" int dsm_exp_read_stamps(double *out /* [levels][8]: slot 0 = count, 1..6 = mean cycles since the workgroup's entry */) {
+  unsigned long long sum[DSM_MAX_LEVELS][8], cnt[DSM_MAX_LEVELS];
+  if (hipMemcpyFromSymbol(sum, HIP_SYMBOL(dsm::g_st_sum), sizeof sum) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(dsm::g_st_cnt), sizeof cnt) != hipSuccess) return -1;
+  for (int l = 0; l < DSM_MAX_LEVELS; l++) {
+    out[l * 8] = (double)cnt[l];
+    for (int k = 1; k < 8; k++) out[l * 8 + k] = cnt[l] ? (double)sum[l][k] / (double)cnt[l] : 0.0;
+  }
+  return 0;
+}
+#endif

@@ -19,7 +19,7 @@ static void rd(FILE *f, T *p, size_t n) {
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s fixture.bin\n", argv[0]);
+    fprintf(stderr, "usage: %s fixture.bin [chunk_geometry]\n", argv[0]);
     return 2;
   }
   FILE *f = fopen(argv[1], "rb");
@@ -61,7 +61,10 @@ int main(int argc, char **argv) {
     return 3;
   }
   {
-    dsm_host::TrackerAndScaler tracker(ctx, w, h, nl, T, K);
+    dsm_params prm; // library defaults unless the caller names the reduction geometry (the reference binding uses the latency table)
+    dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
+    if (argc > 2) prm.chunk_geometry = atoi(argv[2]);
+    dsm_host::TrackerAndScaler tracker(ctx, w, h, nl, T, K, &prm);
     tracker.makeK(K[0], K[1], K[2], K[3]);
     dsm_host::FrameView ref, nf, rf;
     ref.shell_id = 7;

@@ -94,6 +94,12 @@ class Context:
     def set_streams(self, n):
         check(self.L.dsm_context_set_streams(self.h, int(n)))
 
+    def stream_queues(self):
+        """(group streams in use, how many of them share a hardware queue with another group): dsm_context_stream_queues"""
+        a, b = C.c_int(), C.c_int()
+        check(self.L.dsm_context_stream_queues(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stats(self):
         s = Stats()
         check(self.L.dsm_context_get_stats(self.h, C.byref(s)))

@@ -115,10 +115,18 @@ typedef struct dsm_params {
                                          cut-off repeat, no small-step break, no abort), so that the evaluations and bytes
                                          per frame do not depend on the input.  Not the reference's algorithm: 0 (default)
                                          runs trackNewestCoarse / optimizeScale as written. */
-  int tile_l0;                        /* RESERVED, must be 0.  Round 4's opt-in tile form of the level-0 evaluation (tile-ordered
-                                         template copy, warped window staged in LDS) measured slower than the gathers (4996 ->
-                                         4104 GB/s) and was removed in round 5 (tools/experiments/removed_r05/tile_form_and_ab_switches.patch);
-                                         the field keeps the structure's layout.  A non-zero value is DSM_ERR_INVALID. */
+  int chunk_geometry;                 /* Reduction geometry: which table gives a chunk's points per thread from the level's point count
+                                         (a chunk = one workgroup's share of an evaluation = one partial).
+                                         0 (default) THROUGHPUT: 16 points per thread from 16 k points up, 8 / 4 / 2 from 4 k / 1 k / 512 --
+                                           long chunks, their fixed cost (three dependent memory round trips before the first
+                                           point, the 52-sum reduction after the last) amortised: many problems in flight.
+                                         1 LATENCY: 16 / 8 / 4 / 2 from 256 k / 64 k / 16 k / 4 k points, else 1 -- short chunks, more
+                                           workgroups per evaluation, a single evaluation through sooner: ONE problem in flight
+                                           (the replay adaptors set it).  Rounds 1-4 used this table for everything.
+                                         Every form (single, batch, stream) follows the tracker's table: results of one tracker are
+                                         bit-identical across forms; between the tables only the summation tree of the float sums
+                                         differs (last bits), integer outputs are equal.  dsm_reduction_geometry reports the choice.
+                                         (This slot was round 4's tile_l0, RESERVED = 0 since: a caller that leaves it 0 gets the default.) */
   int frame_check;                    /* dsm_tracker_upload_frame: 1 (default) verify that the caller's gradient channels
                                          are makeImages' central differences of channel 0 (the device stores channel 0 only);
                                          0 trust the caller (channels 1, 2 are ignored) */
@@ -172,6 +180,12 @@ int dsm_context_get_stats(dsm_context *ctx, dsm_stats *out);
 int dsm_context_set_streams(dsm_context *ctx, int n_streams);
 /* raw hipStream_t of the context (for callers that order their own device work) */
 void *dsm_context_stream(dsm_context *ctx);
+/* The stream groups (dsm_context_set_streams, dsm_stream_*) only overlap if their HIP streams sit on different HARDWARE queues; the
+ * runtime hands its few queues (GPU_MAX_HW_QUEUES, 4 by default) out round robin to every stream of the process.  The library therefore
+ * probes each stream it creates for a group (a resident kernel on one, an empty kernel on the other: docs in dsm_capi.hip) and keeps
+ * only streams that run concurrently with the groups it already has.  streams_out: group streams in use (the context's own included),
+ * sharing_out: how many of them had to share a queue with another group after 12 candidates (0 on a default runtime). */
+int dsm_context_stream_queues(dsm_context *ctx, int *streams_out, int *sharing_out);
 
 /* measurement aid (no reference counterpart): read-only streaming bandwidth of the device in GB/s,
  * `bytes` per pass (choose > 256 MiB to defeat the Infinity Cache), `iters` timed passes */

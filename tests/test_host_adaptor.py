@@ -30,9 +30,9 @@ def write_fixture(sc, path):
                 f.write(np.ascontiguousarray(pyr[l], np.float32).tobytes())
 
 
-def run_host(exe_name, path):
+def run_host(exe_name, path, *args):
     exe = os.path.join(ROOT, "direct_stereo_slam_amd", "host", "_build", exe_name)
-    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(path), *args], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     return out.stdout.strip().splitlines()[-1]
 
@@ -46,7 +46,7 @@ def test_reference_binding_through_standin_types_equals_the_plain_adaptor(ctx, t
     sc = make_scene("small", seed=23)
     path = tmp_path / "fixture.bin"
     write_fixture(sc, path)
-    plain, bound = run_host("host_adaptor_demo", path), run_host("reference_binding_check", path)
+    plain, bound = run_host("host_adaptor_demo", path, "1"), run_host("reference_binding_check", path)  # (the binding tracks one frame at a time: latency table)
     a, b = json.loads(plain), json.loads(bound)
     assert a["good"] == 1
     a.pop("stream_results_equal")  # (the plain demo also exercises dsm_host::Stream)

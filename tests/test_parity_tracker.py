@@ -420,23 +420,59 @@ def test_call_order_errors(ctx):
         trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl)  # coarsestLvl >= pyrLevelsUsed (:457)
 
 
-def test_sparse_template_just_below_a_chunking_threshold(ctx):
-    """points-per-thread grows with n, so the chunk count is not monotone in n: n = 65535 uses 4 points
-    per thread and 64 chunks although the level holds up to 113k points (8 per thread, 56 chunks).
-    The partial-sum workspace must be sized for the worst n, not for the largest."""
+@pytest.mark.parametrize("geometry,n_cut,expect", [(1, 65535, (256, 4, 64)), (0, 16383, (256, 8, 8))])
+def test_sparse_template_just_below_a_chunking_threshold(ctx, geometry, n_cut, expect):
+    """points-per-thread grows with n, so the chunk count is not monotone in n: under the latency table n = 65535 uses 4 points
+    per thread and 64 chunks although the level holds up to 113k points (8 per thread, 56 chunks); under the throughput table
+    n = 16383 uses 8 per thread and 8 chunks, n = 16384 16 per thread and 4.  The partial-sum workspace must be sized for the
+    worst n of either table, not for the largest."""
+    from direct_stereo_slam_amd.tracker import default_params
+
     sc = make_scene("medium", seed=50)
-    assert len(sc.tpl[0][0]) > 65535
+    assert len(sc.tpl[0][0]) > n_cut
     for a in sc.tpl:
-        a[0] = a[0][:65535].copy()
-    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
-    t, p, c = trk.reduction_geometry(0, 65535)
-    assert (t, p, c) == (256, 4, 64)
-    assert trk.reduction_geometry(0, sc.w * sc.h)[2] < c
+        a[0] = a[0][:n_cut].copy()
+    prm = default_params()
+    assert prm.chunk_geometry == 0  # the library default: the throughput table
+    prm.chunk_geometry = geometry
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc, prm)
+    assert trk.reduction_geometry(0, n_cut) == expect
+    assert trk.reduction_geometry(0, n_cut + 1)[2] < expect[2]
     assert_eval_pose_equal(orc, trk, 0, sc.gt_pose, sc.gt_aff, 20.0)
     good_o, pose_o, _, _, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     good_g, pose_g, _, _ = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     assert good_g == good_o
     np.testing.assert_allclose(pose_g, pose_o, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_chunk_geometries_agree(ctx):
+    """dsm_params.chunk_geometry picks the summation tree only: both tables give the oracle's result within the float-sum tolerance,
+    equal integer outputs, and a batch of the two kinds of tracker mixed gives each tracker what it gets alone."""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    scs = [make_scene("medium", seed=60 + i) for i in range(4)]
+    prm = [default_params() for _ in range(2)]
+    prm[1].chunk_geometry = 1
+    trks = [hip_tracker(ctx, sc, prm[i & 1]) for i, sc in enumerate(scs)]
+    alone = [t.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], scs[0].nl - 1) for t in trks]
+    good, poses = ctx.track_batch(trks, np.tile(S.IDENTITY_POSE, (4, 1)), np.zeros((4, 2)), scs[0].nl - 1)[:2]
+    for i, (sc, t) in enumerate(zip(scs, trks)):
+        assert bool(good[i]) == bool(alone[i][0])
+        np.testing.assert_array_equal(poses[i], alone[i][1])
+        good_o, pose_o, _, _, _ = oracle_tracker(sc).track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        assert bool(good[i]) == good_o
+        np.testing.assert_allclose(poses[i], pose_o, atol=1e-4)
+    # one scene under both tables: single evaluations agree in the integer outputs exactly
+    a, b = hip_tracker(ctx, scs[0], prm[0]), hip_tracker(ctx, scs[0], prm[1])
+    differ = 0
+    for lvl in range(scs[0].nl):
+        (rsa, Ha, ba, na), (rsb, Hb, bb, nb) = (t.calcResPose(lvl, scs[0].gt_pose, scs[0].gt_aff, 20.0) for t in (a, b))
+        assert rsa[1] == rsb[1] and rsa[5] == rsb[5] and na == nb  # numTermsInE, saturated share, warped count
+        np.testing.assert_allclose(rsa[0], rsb[0], rtol=1e-5)
+        np.testing.assert_allclose(Ha, Hb, rtol=0, atol=1e-5 * np.abs(Ha).max())
+        differ += a.reduction_geometry(lvl, len(scs[0].tpl[lvl][0]))[2] != b.reduction_geometry(lvl, len(scs[0].tpl[lvl][0]))[2]
+    assert differ > 0  # (the tables do cut this scene's levels differently)
 
 
 def test_stream_groups_do_not_change_results(ctx):

@@ -203,6 +203,13 @@ struct TrackOut {
 };
 
 // ---- backend 1: the product through the C++ adaptors ----
+// dsm_params.chunk_geometry of every tracker of the replay: 1 (latency table: one frame of a sequence is in flight at a time) unless
+// DSM_REPLAY_GEOMETRY says otherwise; the one-sequence run and the concurrent run share it, so their results stay comparable bit for bit
+static int replay_geometry() {
+  const char *e = getenv("DSM_REPLAY_GEOMETRY");
+  return e ? atoi(e) : 1;
+}
+
 struct GpuBackend {
   const Pack &P;
   dsm_context *ctx = nullptr;
@@ -216,6 +223,7 @@ struct GpuBackend {
     dsm_host::check(dsm_context_create(0, &ctx), "dsm_context_create");
     dsm_params prm;
     dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
+    prm.chunk_geometry = replay_geometry();
     std::vector<double> tv(P.T, P.T + 16);
     a.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
     b.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
@@ -765,6 +773,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
   {
     dsm_params prm;
     dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
+    prm.chunk_geometry = replay_geometry();
     std::vector<double> tv(P.T, P.T + 16);
     std::vector<Seq> seqs((size_t)S);
     for (int s = 0; s < S; s++) {
