@@ -939,10 +939,6 @@ static int tick_advance(dsm_stream *s) {
       long long grid = (long long)s->last_count[si] * 5 / 4 + 256;
       if (s->last_count[si] == 0) grid = (long long)ns * 16;
       if (grid > s->items_cap[si]) grid = s->items_cap[si];
-      {
-        static const int exp_grid = getenv("DSM_EXP_TICK_GRID") ? atoi(getenv("DSM_EXP_TICK_GRID")) : 0; // EXPERIMENT
-        if (exp_grid > 0 && grid > exp_grid) grid = exp_grid;
-      }
       float *part = s->d_partials + (size_t)i0 * s->partial_stride;
       hipEvent_t ea = nullptr, eb = nullptr;
       if (ctx->timing && !sg.companion) {

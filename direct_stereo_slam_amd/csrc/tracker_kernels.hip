@@ -260,24 +260,9 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img 
 // (the 96-register kernels of five waves per SIMD), 1 the warp's twelve (the two-point loop at four waves per SIMD: 128 registers hold
 // these and no more), 2 the camera, gradient-scale and brightness constants as well (the one-point loop inside a kernel that is
 // allocated 128 registers anyway: tick_eval_kernel)
-#ifdef DSM_EXP_STAMPS // EXPERIMENT: where a tick workgroup's life goes (shader-clock stamps of wave 0, summed per level)
-__device__ unsigned long long g_st_sum[DSM_MAX_LEVELS][8], g_st_cnt[DSM_MAX_LEVELS];
-__device__ __forceinline__ unsigned long long exp_stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define DSM_STAMP(k) do { if (st) st[k] = exp_stamp(); } while (0)
-#else
-#define DSM_STAMP(k) do { } while (0)
-#endif
 template <int MODE, bool LVL0, bool RO, bool LDSIMG = false, bool LDSPTS = false, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                                float *out, int *arrive = nullptr
-#ifdef DSM_EXP_STAMPS
-                                                , unsigned long long *st = nullptr
-#endif
-                                                ) {
+                                                float *out, int *arrive = nullptr) {
   const int n = c.n;
   const int P = c.ppt;
   constexpr int NACC = MODE == 1 ? 3 : kNumAcc;
@@ -454,13 +439,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       }
     };
 
-#ifdef DSM_EXP_FLOWFIRST
-    constexpr bool FLOW_FIRST = LVL0 && DEEP; // EXPERIMENT: the flow-indicator pass while the first template entries are on their way
-#else
-    constexpr bool FLOW_FIRST = false;
-#endif
-    // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  One wave
-    // handles the 8*P such points of this chunk in a single pass.
+    // flow indicators (:754-784 / :1070-1100): level 0, every 32nd template index.  Two waves handle the 8*P such points of this chunk
+    // in a single pass.  In the two-point loop's kernels (FLOW_FIRST) the pass runs BEFORE the loop, its point load travelling with the
+    // first template entries the workgroup has to wait for anyway, and its three row sums wait in the reduction scratch instead of
+    // in registers: after the loop the pass was a dependent HBM round trip plus four divisions in front of the reduction -- 5 k of a
+    // level-0 workgroup's 65 k cycles (shader-clock stamps, profiles/r05_queue_probe_and_geometry.log); same operations on the same
+    // values, same row sums: the same bits.  Measured: tick_eval_kernel + 2.4 %, stream + 1.4 % (profiles/r05_ab_flow_first.log).
+    constexpr bool FLOW_FIRST = LVL0 && DEEP;
     auto flow_pass = [&]() {
     if (LVL0 && tid < 8 * P) {
       const int i = chunk_start + 32 * tid;
@@ -559,7 +544,7 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         // with this form.)  Points beyond the chunk / the list are masked (they add exact zeros), so odd P needs
         // no special case.
         fvec4 ea = load_pt(i + kThreads), eb = load_pt(i + 2 * kThreads);
-        if (FLOW_FIRST) { // its point load travels with the three above; the sums wait in the reduction scratch, not in registers
+        if (FLOW_FIRST) {
           flow_pass();
           const float sT = row16_sum(fT), sRT = row16_sum(fRT), sN = row16_sum(fNum);
           if ((tid & 15) == 0) {
@@ -569,7 +554,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
           fT = fRT = fNum = 0.f;
         }
         __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-        DSM_STAMP(2);
         Warped Wa, Wb;
         Taps Ta, Tb;
         stage_a(p0, listed(i, true), Wa, Ta);
@@ -588,7 +572,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
         int i2 = i + kThreads;
         fvec4 p_next = load_pt(i2);
         __builtin_amdgcn_s_waitcnt(0); // drain the prologue loads so the loop's waits only cover its own loads
-        DSM_STAMP(2);
         Warped Wc;
         Taps Tc;
         stage_a(p0, listed(i, true), Wc, Tc);
@@ -610,10 +593,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       }
     }
 
-#ifdef DSM_EXP_STAMPS
-    asm volatile("" : "+v"(E));
-    DSM_STAMP(3);
-#endif
     if (!FLOW_FIRST) flow_pass();
   } // active
   // ---- workgroup reduction: DPP row sums -> LDS [16 rows][slots] -> fixed-order sum ----
@@ -626,15 +605,13 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
     if (writer) red[row][i] = s;
   }
   {
-    const float sE = row16_sum(E), sT = LVL0 ? row16_sum(fT) : 0.f, sRT = LVL0 ? row16_sum(fRT) : 0.f, sN = LVL0 ? row16_sum(fNum) : 0.f; // (flow indicators: level 0 only)
+    // flow indicators: level 0 only; `parked`: this thread group's sums already sit in red[][] (FLOW_FIRST above)
+    const bool parked = LVL0 && DEEP && active;
+    const bool flow_here = LVL0 && !parked;
+    const float sE = row16_sum(E), sT = flow_here ? row16_sum(fT) : 0.f, sRT = flow_here ? row16_sum(fRT) : 0.f, sN = flow_here ? row16_sum(fNum) : 0.f;
     // n_terms / n_sat / n_warped are wave totals (identical in every lane): count them once per wave
     const bool first = lane == 0;
     const int iT = first ? n_terms : 0, iS = first ? n_sat : 0, iW = first ? n_warped : 0; // (a row's writer is its lane 0: the wave's first row carries the totals)
-#ifdef DSM_EXP_FLOWFIRST
-    const bool parked = LVL0 && DEEP && active;
-#else
-    const bool parked = false;
-#endif
     if (writer && !parked) {
       red[row][kSlotFlowT] = sT;
       red[row][kSlotFlowRT] = sRT;
@@ -647,7 +624,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
       red[row][kSlotNWarped] = __int_as_float(iW);
     }
   }
-  DSM_STAMP(4);
   int slot = tid;
   if (arrive) {
     // a wave's LDS operations are performed in order: its rows are in place before its ticket is counted
@@ -660,7 +636,6 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
   } else {
     __syncthreads();
   }
-  DSM_STAMP(5);
   const bool is_float_slot = slot < NACC || (slot >= kSlotE && slot < kSlotNTerms);
   if (!active) {
   } else if (is_float_slot) {
@@ -678,22 +653,11 @@ __device__ __forceinline__ void eval_chunk_impl(const EvalConsts &c, int chunk, 
 
 template <int MODE, bool LVL0, bool DEEP = LVL0, int VC = DEEP ? 1 : 0>
 __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int tid, bool active, float (*red)[kNumSlots],
-                                           float *out, int *arrive = nullptr
-#ifdef DSM_EXP_STAMPS
-                                           , unsigned long long *st = nullptr
-#endif
-                                           ) {
-#ifdef DSM_EXP_STAMPS
-  if (c.residual_only) // wave-uniform
-    eval_chunk_impl<MODE, LVL0, true, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive, st);
-  else
-    eval_chunk_impl<MODE, LVL0, false, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive, st);
-#else
+                                           float *out, int *arrive = nullptr) {
   if (c.residual_only) // wave-uniform
     eval_chunk_impl<MODE, LVL0, true, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
   else
     eval_chunk_impl<MODE, LVL0, false, false, false, DEEP, VC>(c, chunk, tid, active, red, out, arrive);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2316,19 +2280,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                                                                                                   const unsigned *__restrict__ items,
                                                                                                   TickSegCtl *__restrict__ seg, int buf) {
   __shared__ float red[16][kNumSlots];
-#ifdef DSM_EXP_LDSPAD
-  __shared__ float ldspad[MODE == 0 ? DSM_EXP_LDSPAD : 4];
-  if (partial_stride == -1) ldspad[threadIdx.x] = 1.f, __syncthreads(), partials[threadIdx.x] = ldspad[threadIdx.x ^ 1];
-#endif
   const int n_items = ((const DSM_GLOBAL TickSegCtl *)seg)->count[buf];
   // the other list was consumed by the previous tick's evaluation; this tick's LM launch appends to it
   if (blockIdx.x == 0 && threadIdx.x == 0) seg->count[buf ^ 1] = 0;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-#ifdef DSM_EXP_STAMPS
-    unsigned long long stv[8];
-    unsigned long long *st = stv;
-    DSM_STAMP(0);
-#endif
     const unsigned item = ((const DSM_GLOBAL unsigned *)items)[it];
     if (item & kTickNoop) continue; // (workgroup-uniform)
     const bool cand = (item & kTickCand) != 0;
@@ -2346,28 +2301,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     c.residual_only = in.residual_only;
       eval_consts_defaults(c);
     float *const out = partials + (size_t)prob * partial_stride + (cand ? (partial_stride >> 1) : 0) + (size_t)chunk * kPartialStride;
-#ifdef DSM_EXP_STAMPS
-    asm volatile("" ::"s"(c.n), "s"(c.M[8]), "s"(c.max_energy), "s"(lvl));
-    DSM_STAMP(1);
-    if (lvl == 0)
-      eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out, nullptr, st);
-    else
-      eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out, nullptr, st);
-    DSM_STAMP(6);
-    if (MODE == 0 && threadIdx.x == 0 && !c.residual_only) {
-      for (int k = 1; k <= 6; k++) atomicAdd(&g_st_sum[lvl][k], st[k] - st[0]);
-      atomicAdd(&g_st_cnt[lvl], 1ull);
-    }
-#else
     if (lvl == 0)
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
-#ifdef DSM_EXP_DEEP16
-    else if (c.ppt >= 16)
-      eval_chunk<MODE, false, true>(c, chunk, threadIdx.x, true, red, out);
-#endif
     else
       eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out); // (this kernel is allocated 128 registers by its level-0 loop)
-#endif
     __syncthreads(); // red[] is reused by the next item (the arrival-ticket form of eval_kernel measured the same here: profiles/r05_ab_tick_arrival_ticket.log)
   }
 }
@@ -2655,15 +2592,3 @@ void launch_pyramid_batched(hipStream_t s, int w, int h, int nlevels, const PyrJ
 
 } // namespace dsm
 
-#ifdef DSM_EXP_STAMPS
-extern "C" int dsm_exp_read_stamps(double *out /* [levels][8]: slot 0 = count, 1..6 = mean cycles since the workgroup's entry */) {
-  unsigned long long sum[DSM_MAX_LEVELS][8], cnt[DSM_MAX_LEVELS];
-  if (hipMemcpyFromSymbol(sum, HIP_SYMBOL(dsm::g_st_sum), sizeof sum) != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(dsm::g_st_cnt), sizeof cnt) != hipSuccess) return -1;
-  for (int l = 0; l < DSM_MAX_LEVELS; l++) {
-    out[l * 8] = (double)cnt[l];
-    for (int k = 1; k < 8; k++) out[l * 8 + k] = cnt[l] ? (double)sum[l][k] / (double)cnt[l] : 0.0;
-  }
-  return 0;
-}
-#endif

@@ -187,10 +187,13 @@ def test_textbook_fences_give_the_same_results(ctx, tmp_path):
     assert res.returncode == 0 and "TEXTBOOK-OK" in res.stdout, res.stderr[-3000:]
 
 
-def test_compact_straggler_launches_are_bit_identical(ctx):
+@pytest.mark.parametrize("geometry", [0, 1])
+def test_compact_straggler_launches_are_bit_identical(ctx, geometry):
     """dsm_params.compact_tail: after the rounds most problems of a level need, the level's status is read back once and the
     remaining rounds run as compact launches over the stragglers; later passes cover the running problems only.  Same
-    evaluations, same steps: bit-identical results, in every combination with the other scheduling switches."""
+    evaluations, same steps: bit-identical results, in every combination with the other scheduling switches -- under either
+    chunk table (the compact form only sets in for launches of >= 1024 workgroups: 48 of these small scenes reach that under
+    the latency table's short chunks, which is where the read-backs are counted)."""
     from direct_stereo_slam_amd.tracker import default_params
 
     scs = [make_scene("small", seed=400 + i, template="dense" if i % 4 else "sparse", n0=5000, motion_scale=3.0 if i % 5 == 0 else 1.0)
@@ -200,7 +203,7 @@ def test_compact_straggler_launches_are_bit_identical(ctx):
     try:
         for compact, ns, fuse, spec in ((0, 1, 0, 0), (1, 1, 0, 0), (1, 2, 1, 1), (0, 2, 1, 1), (1, 3, 2, 2)):
             p = default_params()
-            p.compact_tail, p.fuse_lm, p.speculate, p.work_queue = compact, fuse, spec, 0
+            p.compact_tail, p.fuse_lm, p.speculate, p.work_queue, p.chunk_geometry = compact, fuse, spec, 0, geometry
             ctx.set_streams(ns)
             trks = [hip_tracker(ctx, sc, p) for sc in scs]
             out = None
@@ -220,4 +223,5 @@ def test_compact_straggler_launches_are_bit_identical(ctx):
     for key, got in results.items():
         for a, b in zip(got, ref):
             assert np.array_equal(a, b, equal_nan=True), key
-    assert polls[(1, 1, 0, 0)] > polls[(0, 1, 0, 0)]  # the per-level read-backs really happened
+    if geometry == 1:
+        assert polls[(1, 1, 0, 0)] > polls[(0, 1, 0, 0)]  # the per-level read-backs really happened

@@ -33,9 +33,11 @@ b bench_b256 $Q --batch 256
 b bench_b1024 $Q --batch 1024
 b bench_cfg_S3 $Q --config S3 --batch 256
 b bench_cfg_sparse $Q --template sparse
+b bench_cfg_sparse_latency_table $Q --template sparse --geometry 1
+b bench_latency_table $Q --geometry 1
 b bench_fixed3 $Q --fixed-schedule 3
-b bench_b1 $Q --batch 1 --scenes 1 --steps 50 --stream 0
-b bench_b1_S1 $Q --batch 1 --scenes 1 --steps 50 --stream 0 --config S1
+b bench_b1 $Q --batch 1 --scenes 1 --steps 50 --stream 0 --geometry 1
+b bench_b1_S1 $Q --batch 1 --scenes 1 --steps 50 --stream 0 --config S1 --geometry 1
 b bench_evals_only_batch_form $Q --evals-only --kf-every 100000 --streams 1 --stream 0
 b bench_with_upload_u8_pinned_overlap $Q --with-upload --u8 --pinned --overlap
 timeout 300 python $R/bench.py --membw > $OUT/membw.log 2>&1
