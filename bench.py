@@ -1183,6 +1183,9 @@ def loop_chain_leg(ctx, seqs=64, n_pts=16000, reps=20):
     one, many = LoopBatch(ctx, jobs[:1], 40.0, db=db, selected_points=False), LoopBatch(ctx, jobs, 40.0, db=db, selected_points=False)
     out["one_keyframe_per_call_ms"] = timed(one.run, reps * 4)
     out[f"{seqs}_keyframes_per_call_ms_per_keyframe"] = timed(many.run, reps) / seqs
+    # the same with the clouds kept in page-locked memory (dsm_host_alloc): the device reads them where they are, no host copy
+    many_p = LoopBatch(ctx, jobs, 40.0, db=RingKeyDB(ctx, capacity=1 << 16), selected_points=False, pinned_clouds=True)
+    out[f"{seqs}_keyframes_per_call_ms_per_keyframe_pinned_clouds"] = timed(many_p.run, reps) / seqs
     db2 = RingKeyDB(ctx, capacity=1 << 16)
     desc = LoopBatch(ctx, jobs[:1], 40.0)
 
@@ -1333,7 +1336,8 @@ def compact_line(res, detail_path):
     lc = c.get("loop_chain")
     if isinstance(lc, dict):
         legs["loop_chain_ms_per_keyframe"] = {"error": lc["error"][:120]} if "error" in lc else {
-            ("S1" if k.startswith("one_keyframe_per") else "S64" if "keyframes_per_call" in k else "S1_unfused"): _r(v, 2) for k, v in lc.items() if k != "workload"}
+            ("S1" if k.startswith("one_keyframe_per") else "S64_pinned" if k.endswith("pinned_clouds") else "S64" if "keyframes_per_call" in k else "S1_unfused"): _r(v, 3)
+            for k, v in lc.items() if k != "workload"}
     sh = c.get("ringkey_sharded")
     if isinstance(sh, dict):
         legs["ringkey_sharded"] = {"error": sh["error"][:160]} if "error" in sh else {

@@ -55,8 +55,13 @@ __device__ __forceinline__ double key_to_double(unsigned long long k) {
 
 struct JobDev {             // one keyframe
   const double *xyz;        // n_pts x 3 world coordinates
-  const unsigned char *keep; // n_pts: the owning keyframe survived the orientation trim (may be null: all kept)
-  int n_pts;
+  const int *pt_kf;         // n_pts: id of the keyframe that owns the point
+  const int *ids;           // n_ids pairs (keyframe id, survived the orientation trim :33-41), sorted
+  int n_ids, n_pts;
+  // the caller's cloud in page-locked memory (device-visible addresses): loop_gather_kernel copies it into xyz / pt_kf -- no staging copy
+  // on the host; null: the cloud travelled through the pinned mirror
+  const double *xyz_src;
+  const int *pt_kf_src;
   double cw[12];            // camera <- world, row-major 3x4
   // outputs / workspace of the voxel filter
   unsigned long long *grid_y; // cells
@@ -84,12 +89,35 @@ __device__ __forceinline__ void to_camera(const double *cw, const double *g, dou
 
 // in range and kept?  returns the voxel cell or -1  (:53-70)
 __device__ __forceinline__ long long voxel_of(const JobDev &J, int i, double lidar_range, long long vs0, long long vs1, double p[3]) {
-  if (J.keep && !J.keep[i]) return -1;
+  { // :55: a point whose keyframe is unknown or was trimmed is dropped (an id listed twice is kept if either entry survived). A few
+    // keyframes per window: the search over the sorted pairs costs less here than the per-point host loop it replaces (0.24 ms per
+    // 16 000-point keyframe: most of the fused chain's time at 64 keyframes per call)
+    const int id = J.pt_kf[i];
+    int lo = 0, hi = J.n_ids;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (J.ids[2 * mid] < id) lo = mid + 1; else hi = mid;
+    }
+    bool kept = false;
+    for (; lo < J.n_ids && J.ids[2 * lo] == id; lo++) kept = kept || J.ids[2 * lo + 1] != 0;
+    if (!kept) return -1;
+  }
   to_camera(J.cw, J.xyz + 3 * (size_t)i, p);
   if (sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) >= lidar_range) return -1;
   const long long xi = (long long)floor((p[0] + lidar_range) * 1.0), yi = (long long)floor((p[1] + lidar_range) * 2.0),
                   zi = (long long)floor((p[2] + lidar_range) * 1.0); // steps 1/RES_X, 1/RES_Y, 1/RES_Z (:23-25,:44)
   return xi + yi * vs0 + zi * vs0 * vs1;
+}
+
+// the clouds of jobs whose caller keeps them in page-locked memory: read over the bus by the kernel, 8 bytes per access
+__global__ void loop_gather_kernel(const JobDev *jobs) {
+  const JobDev &J = jobs[blockIdx.y];
+  if (!J.xyz_src) return;
+  const size_t nd = 3 * (size_t)J.n_pts, stride = (size_t)gridDim.x * blockDim.x;
+  double *xyz = const_cast<double *>(J.xyz);
+  int *pk = const_cast<int *>(J.pt_kf);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += stride) xyz[i] = __builtin_nontemporal_load(J.xyz_src + i);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)J.n_pts; i += stride) pk[i] = __builtin_nontemporal_load(J.pt_kf_src + i);
 }
 
 __global__ void voxel_clear_kernel(const JobDev *jobs, long long cells) {
@@ -320,7 +348,7 @@ struct LoopPlan {
   long long cells = 0;
   std::vector<JobDev> hj;
   // offsets (bytes) into the input region (pinned + device), the work region (device only), the output region (device + pinned)
-  std::vector<size_t> in_xyz, in_keep, out_small, out_sig_idx, out_sig_val, out_sel, out_sph;
+  std::vector<size_t> in_xyz, in_ptkf, in_ids, out_small, out_sig_idx, out_sig_val, out_sel, out_sph;
   size_t in_tab = 0, in_bytes = 0, work_bytes = 0, out_bytes = 0, out_keys = 0, out_cand = 0;
   bool any_sc = false;
 };
@@ -372,7 +400,7 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
   hipStream_t st = ctx->stream;
   P.n_jobs = n_jobs, P.nbins = num_s * num_r, P.num_r = num_r, P.cells = cells, P.nblocks = (int)((cells + kLdThreads - 1) / kLdThreads);
   P.hj.assign(n_jobs, JobDev());
-  P.in_xyz.resize(n_jobs), P.in_keep.resize(n_jobs), P.out_small.resize(n_jobs), P.out_sig_idx.resize(n_jobs), P.out_sig_val.resize(n_jobs);
+  P.in_xyz.resize(n_jobs), P.in_ptkf.resize(n_jobs), P.in_ids.resize(n_jobs), P.out_small.resize(n_jobs), P.out_sig_idx.resize(n_jobs), P.out_sig_val.resize(n_jobs);
   P.out_sel.resize(n_jobs), P.out_sph.resize(n_jobs);
   Arena in, work, out;
   std::vector<size_t> w_gy(n_jobs), w_gi(n_jobs), w_bc(n_jobs), w_mom(n_jobs), w_bins(n_jobs), w_sel(n_jobs), w_sph(n_jobs);
@@ -381,8 +409,7 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
     const dsm_loop_job &J = jobs[j];
     if (J.n_pts > max_pts) max_pts = J.n_pts;
     P.any_sc = P.any_sc || J.ringkey;
-    P.in_xyz[j] = in.take(sizeof(double) * 3 * (size_t)J.n_pts);
-    P.in_keep[j] = in.take((size_t)J.n_pts);
+    P.in_ids[j] = in.take(sizeof(int) * 2 * (size_t)(J.n_kf > 0 ? J.n_kf : 1));
     w_gy[j] = work.take(sizeof(unsigned long long) * (size_t)cells);
     w_gi[j] = work.take(sizeof(int) * (size_t)cells);
     w_bc[j] = work.take(sizeof(int) * (size_t)P.nblocks);
@@ -401,6 +428,12 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
     }
   }
   P.in_tab = in.take(sizeof(JobDev) * (size_t)n_jobs);
+  const size_t in_small_bytes = in.used; // [keyframe tables | job table], then the clouds: clouds read directly from page-locked caller
+                                         // memory (loop_gather_kernel) do not travel through the mirror at all
+  for (int j = 0; j < n_jobs; j++) {
+    P.in_xyz[j] = in.take(sizeof(double) * 3 * (size_t)jobs[j].n_pts);
+    P.in_ptkf[j] = in.take(sizeof(int) * (size_t)jobs[j].n_pts);
+  }
   P.out_keys = out.take(sizeof(float) * (size_t)num_r * n_jobs);
   P.out_cand = out.take(extra_out_bytes);
   P.in_bytes = in.used, P.work_bytes = work.used, P.out_bytes = out.used;
@@ -409,6 +442,7 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
   if (rc) return rc;
   unsigned char *d_in = (unsigned char *)ctx->loop_dev, *d_work = d_in + P.in_bytes, *d_out = d_work + P.work_bytes;
   unsigned char *h_in = (unsigned char *)ctx->loop_pin;
+  bool any_direct = false, any_staged = false;
   for (int j = 0; j < n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
     JobDev &D = P.hj[j];
@@ -418,18 +452,31 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
     // :33-41 on the host (a handful of keyframes): which keyframes survive, hence which points
     trim_keyframes(J.n_kf, J.kf_pose_wc, J.cur_cw, J.kf_keep);
     std::vector<std::pair<int, int>> ids;
-    for (int k = 0; k < J.n_kf; k++) ids.push_back(std::make_pair(J.kf_ids[k], J.kf_keep[k]));
+    for (int k = 0; k < J.n_kf; k++) ids.push_back(std::make_pair(J.kf_ids[k], J.kf_keep[k] ? 1 : 0));
     std::sort(ids.begin(), ids.end());
-    unsigned char *keep = h_in + P.in_keep[j];
-    for (int i = 0; i < J.n_pts; i++) {
-      auto it = std::lower_bound(ids.begin(), ids.end(), std::make_pair(J.pt_kf_id[i], 0));
-      unsigned char k = 0;
-      for (; it != ids.end() && it->first == J.pt_kf_id[i]; ++it)
-        if (it->second) k = 1;
-      keep[i] = k; // unknown keyframe: `find == end` (:55)
+    int *h_ids = (int *)(h_in + P.in_ids[j]);
+    for (int k = 0; k < J.n_kf; k++) h_ids[2 * k] = ids[k].first, h_ids[2 * k + 1] = ids[k].second;
+    // the cloud: straight from the caller's buffers where both are page-locked (dsm_host_alloc / hipHostMalloc / hipHostRegister: a node
+    // that keeps its window's clouds there), else through the pinned mirror (a host copy of 28 bytes per point)
+    const void *dev_xyz = nullptr, *dev_kf = nullptr;
+    if (J.n_pts) {
+      hipPointerAttribute_t ax, ak;
+      if (hipPointerGetAttributes(&ax, J.pt_xyz) == hipSuccess && ax.type == hipMemoryTypeHost && ax.devicePointer &&
+          hipPointerGetAttributes(&ak, J.pt_kf_id) == hipSuccess && ak.type == hipMemoryTypeHost && ak.devicePointer)
+        dev_xyz = ax.devicePointer, dev_kf = ak.devicePointer;
+      else
+        (void)hipGetLastError(); // (pageable memory is reported as an error by some runtimes)
     }
-    if (J.n_pts) memcpy(h_in + P.in_xyz[j], J.pt_xyz, sizeof(double) * 3 * (size_t)J.n_pts);
-    D.xyz = (const double *)(d_in + P.in_xyz[j]), D.keep = d_in + P.in_keep[j];
+    if (dev_xyz) {
+      D.xyz_src = (const double *)dev_xyz, D.pt_kf_src = (const int *)dev_kf;
+      any_direct = true;
+    } else if (J.n_pts) {
+      memcpy(h_in + P.in_ptkf[j], J.pt_kf_id, sizeof(int) * (size_t)J.n_pts);
+      memcpy(h_in + P.in_xyz[j], J.pt_xyz, sizeof(double) * 3 * (size_t)J.n_pts);
+      any_staged = true;
+    }
+    D.xyz = (const double *)(d_in + P.in_xyz[j]), D.pt_kf = (const int *)(d_in + P.in_ptkf[j]);
+    D.ids = (const int *)(d_in + P.in_ids[j]), D.n_ids = J.n_kf;
     D.grid_y = (unsigned long long *)(d_work + w_gy[j]), D.grid_idx = (int *)(d_work + w_gi[j]), D.block_count = (int *)(d_work + w_bc[j]);
     D.moments = (double *)(d_work + w_mom[j]), D.bins = (unsigned long long *)(d_work + w_bins[j]);
     D.sel_idx = (int *)(J.sel_idx ? d_out + P.out_sel[j] : d_work + w_sel[j]);
@@ -441,8 +488,9 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
     D.sig_idx = (int *)(d_out + P.out_sig_idx[j]), D.sig_val = (double *)(d_out + P.out_sig_val[j]);
   }
   memcpy(h_in + P.in_tab, P.hj.data(), sizeof(JobDev) * (size_t)n_jobs);
-  DSM_HIP(hipMemcpyAsync(d_in, h_in, P.in_bytes, hipMemcpyHostToDevice, st));
+  DSM_HIP(hipMemcpyAsync(d_in, h_in, any_staged ? P.in_bytes : in_small_bytes, hipMemcpyHostToDevice, st));
   JobDev *dj = (JobDev *)(d_in + P.in_tab);
+  if (any_direct) hipLaunchKernelGGL(loop_gather_kernel, dim3(64, n_jobs), dim3(kLdThreads), 0, st, dj);
   // a job without a descriptor leaves its key slot untouched: zero the key array so that the search sees defined values
   DSM_HIP(hipMemsetAsync(d_out + P.out_keys, 0, sizeof(float) * (size_t)num_r * n_jobs, st));
   // ---- generate_spherical_points: all jobs side by side (blockIdx.y = job)

@@ -219,7 +219,9 @@ class LoopBatch:
     """The ctypes job table of dsm_loop_descriptors_batch / dsm_loop_detect_batch and its output arrays, built once: `run()` is the C call
     alone (a node keeps its clouds and job tables; bench.py times this), `results()` unpacks."""
 
-    def __init__(self, ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True):
+    def __init__(self, ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True, pinned_clouds=False):
+        """pinned_clouds: the clouds (pt_kf_id, pt_xyz) are kept in page-locked memory (dsm_host_alloc), which the device reads directly:
+        no staging copy on the host"""
         self.ctx, self.L, self.db = ctx, ctx.L, db
         self.lidar_range, self.num_s, self.num_r, self.scancontext, self.selected_points = lidar_range, num_s, num_r, scancontext, selected_points
         self.arr = (_lib.LoopJob * len(jobs))()
@@ -231,6 +233,12 @@ class LoopBatch:
             cw = np.ascontiguousarray(cur_cw, np.float64).reshape(3, 4)
             pid = np.ascontiguousarray(pt_kf_id, np.int32)
             xyz = np.ascontiguousarray(pt_xyz, np.float64).reshape(-1, 3)
+            if (pinned_clouds[j] if isinstance(pinned_clouds, (list, tuple)) else pinned_clouds) and len(pid):
+                from .tracker import pinned_array
+
+                ppid, pxyz = pinned_array(pid.shape, np.int32), pinned_array(xyz.shape, np.float64)
+                ppid[...], pxyz[...] = pid, xyz
+                pid, xyz = ppid, pxyz
             o = dict(kf_keep=np.zeros(max(1, len(kf_ids)), np.int32), n_out=np.zeros(1, np.int32), ringkey=np.zeros(num_r, np.float32),
                      sig_idx=np.zeros(num_s * num_r, np.int32), sig_val=np.zeros(num_s * num_r), n_sig=np.zeros(1, np.int32), tfm=np.zeros(16))
             if selected_points:
@@ -273,14 +281,14 @@ class LoopBatch:
         return res
 
 
-def loop_descriptors_batch(ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True):
+def loop_descriptors_batch(ctx, jobs, lidar_range, num_s=60, num_r=20, scancontext=True, db=None, selected_points=True, pinned_clouds=False):
     """DEVICE form of generate_spherical_points + ScanContext::generate for a batch of keyframes (dsm_loop_descriptors_batch).
     jobs: list of (kf_ids, kf_pose_wc, cur_cw, pt_kf_id, pt_xyz).  Returns, per job, a dict with kf_keep, sel_idx,
     pts_spherical and -- with scancontext -- ringkey, sig_idx, sig_val, tfm_pca_rig.
     db (a RingKeyDB): dsm_loop_detect_batch instead -- the jobs' ring keys are searched in (and enqueued into) the index on the device,
     one enqueue and one read-back for the whole chain; every result also carries `candidates` (search_ringkey's list).
     selected_points = False: sel_idx / pts_spherical stay on the device (NULL outputs)."""
-    b = LoopBatch(ctx, jobs, lidar_range, num_s, num_r, scancontext, db, selected_points)
+    b = LoopBatch(ctx, jobs, lidar_range, num_s, num_r, scancontext, db, selected_points, pinned_clouds)
     b.run()
     return b.results()
 

@@ -139,3 +139,25 @@ def test_fused_loop_chain_equals_the_sequential_calls(ctx):
         assert np.array_equal(seq_db.knn_packed_host(q), fus_db.knn_packed_host(q))  # the same index afterwards
     with pytest.raises(Exception):
         loop_descriptors_batch(ctx, jobs[:6], 40.0, db=RingKeyDB(ctx, capacity=64, margin=5))  # more keyframes than the delay margin
+
+
+@pytest.mark.gpu
+def test_clouds_in_page_locked_memory_are_read_in_place(ctx):
+    """A caller that keeps its clouds in page-locked memory (dsm_host_alloc) is served without the host staging copy: the device reads
+    the buffers where they are (loop_gather_kernel).  Same results as from pageable memory, all jobs page-locked, none, or mixed; the
+    keep decision per point (keyframe trimmed or unknown, generate_spherical_points.h:55) is taken on the device in every case."""
+    jobs = [make_job(500 + s, n_pts=2500 + 300 * (s % 4)) for s in range(6)]
+    kf_ids, poses, cur_cw, pt_kf, xyz = jobs[2]
+    pt_kf = pt_kf.copy()
+    pt_kf[::7] = 99999  # points of a keyframe that is not in the window: dropped
+    jobs[2] = (kf_ids, poses, cur_cw, pt_kf, xyz)
+    ref = loop_descriptors_batch(ctx, jobs, 40.0)
+    for pinned in (True, [True, False, True, False, False, True]):
+        got = loop_descriptors_batch(ctx, jobs, 40.0, pinned_clouds=pinned)
+        for a, b in zip(ref, got):
+            assert a["n_out"] == b["n_out"] and np.array_equal(a["kf_keep"], b["kf_keep"])
+            for k in ("sel_idx", "pts_spherical", "ringkey", "sig_idx", "sig_val", "tfm_pca_rig"):
+                assert np.array_equal(a[k], b[k]), k
+    # ... and the device's keep decision equals the oracle's (host restatement of the whole chain)
+    keep_o, sel_o, pts_o = SC.generate_spherical_points(*jobs[2][:3], 40.0, jobs[2][3], jobs[2][4])
+    assert np.array_equal(ref[2]["sel_idx"], sel_o) and np.array_equal(ref[2]["kf_keep"], keep_o)
