@@ -546,7 +546,9 @@ typedef struct dsm_loop_job {
   const double *cur_cw;       /* row-major 3x4 */
   int n_pts;
   const int *pt_kf_id;
-  const double *pt_xyz;       /* n_pts x 3 */
+  const double *pt_xyz;       /* n_pts x 3.  If pt_kf_id AND pt_xyz of a job lie in page-locked memory (dsm_host_alloc, hipHostMalloc,
+                                 hipHostRegister) the device reads them in place -- no host copy of the cloud; pageable clouds are staged
+                                 (28 bytes per point copied on the host).  Same results either way. */
   int *kf_keep;               /* out: n_kf */
   int *n_out;                 /* out */
   int *sel_idx;               /* out: capacity n_pts; NULL (together with pts_spherical): the selected points stay on the device */
