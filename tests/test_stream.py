@@ -272,10 +272,28 @@ def test_tick_engine_on_the_bench_workload_equals_the_oracle(ctx):
     flips, stats = _stream_vs_oracle(ctx, frames, track_slots=6, scale_slots=2, kf_every=5, waves=2, max_route_flips=1)
     hd = make_relief_frames("hd6", 2, 1, seed0=0x5EED0100)
     _stream_vs_oracle(ctx, hd, track_slots=1, scale_slots=1, kf_every=1, waves=1, max_route_flips=0)
-    # the three stream groups and the scale segment run on hardware queues of their own (probed when the streams were created: two
-    # groups on one queue serialise -- round 5 lost 6-30 % to that before the probe existed)
-    in_use, sharing = ctx.stream_queues()
-    assert in_use == 4 and sharing == 0
+
+
+def test_stream_groups_get_hardware_queues_of_their_own(built):
+    """The three stream groups and the scale segment of a stream must sit on different hardware queues, or their launches serialise
+    (round 5 lost 6-30 % to two groups on one queue before the probe existed: DESIGN.md 4.3a).  A fresh context -- the session's has
+    sixteen groups' streams from other tests, more than the runtime has queues --, three groups, a small tick-engine job; the probe's
+    outcome as dsm_context_stream_queues reports it, and the results still equal the batch calls."""
+    from direct_stereo_slam_amd.tracker import Context
+
+    c = Context(0)
+    try:
+        assert c.stream_queues() == (1, 0)
+        scs = [make_scene("small", seed=760 + i) for i in range(9)]
+        trks = [hip_tracker(c, sc) for sc in scs]
+        scales = np.linspace(0.9, 1.2, len(trks)).astype(np.float32)
+        ref = _batch_reference(c, trks, scs[0].nl, scales)
+        c.set_streams(3)
+        res, _, _ = _stream_run(c, trks, scs[0].nl, scales.copy(), 9, 4, None, None, 1, engine=1, ticks=0)
+        _check(res, ref, len(trks), scs[0].nl)
+        assert c.stream_queues() == (4, 0)
+    finally:
+        c.close()
 
 
 def test_tick_engine_relief_golden_fixture(ctx):
