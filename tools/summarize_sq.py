@@ -5,7 +5,10 @@ import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-L0 = "eval_kernel<0, true, false"  # every instantiation of the level-0 pose evaluation: ", 0>" mixed, ", 1>" full, ", 2>" residual-only launches
+# every instantiation of the level-0 pose evaluation: ", 0>" mixed, ", 1>" full, ", 2>" residual-only launches; DSM_SQ_KERNEL / DSM_SQ_NAME
+# (round 5): another kernel, e.g. "tick_eval_kernel<0>" (all levels in one launch) -> profiles/<tag>_sq_<name>.json
+L0 = os.environ.get("DSM_SQ_KERNEL", "eval_kernel<0, true, false")
+NAME = os.environ.get("DSM_SQ_NAME", "level0")
 sums, avg, ndisp = {}, {}, 0
 for p in ("p1", "p2", "p3", "p4", "p5"):
     files = sorted(glob.glob(os.path.join(src, p, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
@@ -25,7 +28,7 @@ for p in ("p1", "p2", "p3", "p4", "p5"):
         seen.add(r["Dispatch_Id"])
     ndisp = max(ndisp, len(seen))
 out = {"source": "five rocprofv3 --pmc passes (tools/profile_sq.sh) with --kernel-trace on `python bench.py --no-cpu --no-second-leg "
-                 "--steps 2 --warmup 1`; sums over the dispatches WITH WORK of dsm::" + L0 + " (level-0 pose evaluation)",
+                 "--steps 2 --warmup 1` (round 5: + --no-ringkey-leg --no-replay-leg); sums over the dispatches WITH WORK (>= 20 us) of dsm::" + L0,
        "dispatches": ndisp}
 out.update({k: int(v) for k, v in sorted(sums.items())})
 d = {}
@@ -51,5 +54,5 @@ if sums.get("TCC_HIT_sum") is not None and sums.get("TCC_MISS_sum"):
 out["derived"] = d
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-json.dump(out, open(os.path.join(dst, f"{tag}_sq_level0.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_sq_{NAME}.json"), "w"), indent=1)
 print(json.dumps(d, indent=1))
