@@ -254,8 +254,9 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img 
 // rows and store the partial -- the same additions in the same order by another wave; the other waves leave at once instead
 // of waiting for the slowest wave's gathers (measured: a mid-level workgroup spent a third of its life between the end of
 // its first wave's loop and the partial store).
-// DEEP: the two-points-per-trip loop with fixed register roles (level 0 always; the tick engine's kernel, which runs at four
-// waves per SIMD whatever the level, also uses it on the other large levels)
+// DEEP: the two-points-per-trip loop with fixed register roles (level 0 only: inside the tick engine's kernel, which runs at four
+// waves per SIMD whatever the level, it measured no faster than the one-point loop on the 16-point chunks of the other levels,
+// profiles/r05_ab_flow_first_deep16_b1.log)
 // VC: which wave-uniform constants the loop keeps in VGPRs (an SGPR source costs an instruction 4.65 instead of 2.5 cycles): 0 none
 // (the 96-register kernels of five waves per SIMD), 1 the warp's twelve (the two-point loop at four waves per SIMD: 128 registers hold
 // these and no more), 2 the camera, gradient-scale and brightness constants as well (the one-point loop inside a kernel that is
@@ -2299,7 +2300,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     c.t[0] = in.t[0], c.t[1] = in.t[1], c.t[2] = in.t[2];
     c.aff0 = in.aff0, c.aff1 = in.aff1, c.b0 = in.b0, c.scale = in.scale, c.cutoff = in.cutoff, c.max_energy = in.max_energy;
     c.residual_only = in.residual_only;
-      eval_consts_defaults(c);
+    eval_consts_defaults(c);
     float *const out = partials + (size_t)prob * partial_stride + (cand ? (partial_stride >> 1) : 0) + (size_t)chunk * kPartialStride;
     if (lvl == 0)
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
