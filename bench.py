@@ -128,6 +128,8 @@ def _parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the short reference-faithful five-level (S1) leg reported in config.reference_five_level")
     ap.add_argument("--second-leg-steps", type=int, default=10, help="timed steps of the fixed-schedule and five-level legs (streamed: ramp-up and drain are inside, so a handful of steps understates the rate)")
+    ap.add_argument("--quick", action="store_true", help="the headline leg alone: --no-cpu --no-fixed-leg --no-second-leg --no-plane-leg --no-replay-leg --no-ringkey-leg (A/B runs, profiles)")
+    ap.add_argument("--no-plane-leg", action="store_true", help="skip the short leg on SURVEY.md 8d's literal scene family (config.plane_family)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-core leg of the CPU baseline (one share of frames per physical core, forked workers)")
     ap.add_argument("--evals-only", action="store_true",
                     help="diagnostic: max_iterations=0, i.e. exactly one fused evaluation per level and problem (clean per-kernel roofline)")
@@ -149,7 +151,10 @@ def _parse():
     ap.add_argument("--detail-out", default="gpurun_out/bench_detail.json",
                     help="side file (relative to the repository root unless absolute) that receives the FULL result object -- every leg, table and note; the ONE "
                          "stdout line is its compact form (< 4 KB: contract keys, roofline and cpu_baseline as numbers, one summary per leg)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.quick:
+        a.no_cpu = a.no_fixed_leg = a.no_second_leg = a.no_plane_leg = a.no_replay_leg = a.no_ringkey_leg = True
+    return a
 
 
 _BACKEND = "nccl"
@@ -920,6 +925,26 @@ def cpu_baseline(args, wl, gpu_poses=None, gpu_good=None, gpu_evals=None):
         # both paths; the ATE half of the metric is taken over the frames the CPU path tracks (selected by the CPU result
         # alone, so a GPU-only failure would show) and, for completeness, over all frames.
         ok = np.abs(cp - gt).max(1) <= 0.01
+        # RPE (north_star: "within a stated ATE/RPE tolerance"): every bench frame IS one relative pose -- keyframe to
+        # new frame, one step of the sequence -- so the relative pose error over a step of one frame is E = T_gt^-1 T_est per frame:
+        # RMSE of |trans(E)| and of the rotation angle of E, both paths against the ground truth and the GPU path against the CPU path
+        def rpe(est, ref):
+            est, ref = np.asarray(est, np.float64), np.asarray(ref, np.float64)
+            if not len(est):
+                return float("nan"), float("nan")
+            tr, ro = [], []
+            for a, b in zip(est, ref):
+                Ra, Rb = S.quat_to_rot(a[:4]), S.quat_to_rot(b[:4])
+                Re, te = Rb.T @ Ra, Rb.T @ (a[4:] - b[4:])
+                tr.append(float(te @ te))
+                ro.append(float(np.arccos(np.clip((np.trace(Re) - 1.0) / 2.0, -1.0, 1.0))) ** 2)
+            return float(np.sqrt(np.mean(tr))), float(np.degrees(np.sqrt(np.mean(ro))))
+        gpa, cpa, gta = np.asarray(gpu_poses)[:n], np.array(cpu_poses), np.asarray(wl["gts"])[:n]
+        (rg_t, rg_r), (rc_t, rc_r), (rd_t, rd_r) = rpe(gpa[ok], gta[ok]), rpe(cpa[ok], gta[ok]), rpe(gpa[ok], cpa[ok])
+        out["rpe_vs_cpu_ref"] = {"delta_frames": 1, "frames": int(ok.sum()), "rpe_trans_gpu_m": rg_t, "rpe_trans_cpu_m": rc_t,
+                                 "rpe_trans_ratio_gpu_over_cpu": rg_t / max(rc_t, 1e-30), "rpe_rot_gpu_deg": rg_r, "rpe_rot_cpu_deg": rc_r,
+                                 "rpe_rot_ratio_gpu_over_cpu": rg_r / max(rc_r, 1e-30), "rpe_gpu_against_cpu_trans_m": rd_t, "rpe_gpu_against_cpu_rot_deg": rd_r,
+                                 "tolerance": "ratios within 1 % of 1 (the metric's ATE bar applied to the RPE as well)"}
         out["ate_vs_cpu_ref"] = {"frames": int(ok.sum()), "ate_gpu_m": ate(gp[ok], gt[ok]), "ate_cpu_m": ate(cp[ok], gt[ok]),
                                  "ate_ratio_gpu_over_cpu": ate(gp[ok], gt[ok]) / max(ate(cp[ok], gt[ok]), 1e-30),
                                  "max_abs_translation_diff_gpu_vs_cpu_m": float(np.abs(gp[ok] - cp[ok]).max()) if ok.any() else None,
@@ -1313,6 +1338,10 @@ def compact_line(res, detail_path):
     if isinstance(fv, dict):
         legs["reference_five_level_S1"] = {"error": fv["error"][:120]} if "error" in fv else {
             **_pick(fv, ("value", "ms_per_step", "algorithmic_MB_per_frame")), **_pick(fv.get("roofline") or {}, ("frac", "frac_whole_step"))}
+    pf = c.get("plane_family")
+    if isinstance(pf, dict):
+        legs["plane"] = {"error": pf["error"][:120]} if "error" in pf else {
+            **_pick(pf, ("value", "ms_per_step", "algorithmic_MB_per_frame")), **_pick(pf.get("roofline") or {}, ("frac", "frac_whole_step"))}
     rp = c.get("replay")
     if isinstance(rp, dict):
         lr = {}
@@ -1323,7 +1352,8 @@ def compact_line(res, detail_path):
             g, cp, vs = d["gpu"]["stages_mean_ms"], d["cpu"]["stages_mean_ms"], d.get("gpu_vs_cpu", {})
             lr[name] = {"ms_per_frame_gpu": _r(g["per_frame"]["mean_ms"]), "ms_per_frame_cpu": _r(cp["per_frame"]["mean_ms"]),
                         "trackNewCoarse_ms_gpu": _r(g["trackNewCoarse"]["mean_ms"]),
-                        **_pick(vs, ("ate_ratio_gpu_over_cpu", "loop_queries", "queries_with_identical_candidates"), 4)}
+                        **_pick(vs, ("ate_ratio_gpu_over_cpu", "rpe_trans_ratio_gpu_over_cpu", "rpe_rot_ratio_gpu_over_cpu", "loop_queries",
+                                     "queries_with_identical_candidates"), 4)}
             cc = d.get("concurrent")
             if isinstance(cc, dict):
                 lr[name]["concurrent"] = _pick(cc, ("sequences", "frames_per_s", "max_abs_trajectory_diff_vs_the_one_sequence_run_m"))
@@ -1336,8 +1366,9 @@ def compact_line(res, detail_path):
     lc = c.get("loop_chain")
     if isinstance(lc, dict):
         legs["loop_chain_ms_per_keyframe"] = {"error": lc["error"][:120]} if "error" in lc else {
-            ("S1" if k.startswith("one_keyframe_per") else "S64_pinned" if k.endswith("pinned_clouds") else "S64" if "keyframes_per_call" in k else "S1_unfused"): _r(v, 3)
-            for k, v in lc.items() if k != "workload"}
+            ("S1" if k.startswith("one_keyframe_per") else f"S{k.split('_', 1)[0]}_pinned" if k.endswith("pinned_clouds") else f"S{k.split('_', 1)[0]}" if "keyframes_per_call" in k
+             else "S1_unfused"): _r(v, 3)
+            for k, v in lc.items() if k != "workload"}  # (labels follow the leg's own sequence count: ADVICE r05)
     sh = c.get("ringkey_sharded")
     if isinstance(sh, dict):
         legs["ringkey_sharded"] = {"error": sh["error"][:160]} if "error" in sh else {
@@ -1362,6 +1393,9 @@ def compact_line(res, detail_path):
         if isinstance(ate, dict):
             o["ate_vs_cpu_ref"] = _pick(ate, ("frames", "ate_gpu_m", "ate_cpu_m", "ate_ratio_gpu_over_cpu",
                                               "max_abs_translation_diff_gpu_vs_cpu_m", "good_flags_equal"), 5)
+        rp = cb.get("rpe_vs_cpu_ref")
+        if isinstance(rp, dict):
+            o["rpe_vs_cpu_ref"] = _pick(rp, ("rpe_trans_ratio_gpu_over_cpu", "rpe_rot_ratio_gpu_over_cpu", "rpe_trans_gpu_m", "rpe_rot_gpu_deg"), 5)
         if isinstance(lm, dict):
             o["lm_routes_vs_cpu_ref"] = _pick(lm, ("frames", "same_evaluation_counts", "different_evaluation_counts"))
         if isinstance(ac, dict):
@@ -1373,7 +1407,15 @@ def compact_line(res, detail_path):
             break
         out["config"].pop(drop, None)
         text = json.dumps(out, separators=(",", ":"))
-    assert len(text.encode()) < LINE_LIMIT, len(text)
+    if len(text.encode()) >= LINE_LIMIT:
+        # last resort (a long error string, a new leg): the contract keys alone plus where the rest lies -- never an exception, the line
+        # is what the driver reads (the assert here lost the whole line, and vanished under python -O)
+        out["config"] = {"workload": str(cfg.get("workload", ""))[:300], "detail": detail_path, "truncated": True}
+        out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic"), 4)
+        out["cpu_baseline"] = None if cb is None else _pick(cb, ("value", "unit", "cores", "kind"))
+        if out["cpu_baseline"] is not None:
+            out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        text = json.dumps(out, separators=(",", ":"))
     return text
 
 
@@ -1512,6 +1554,19 @@ def bench_tracking(args):
             del wl2
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["reference_five_level"] = {"error": repr(e)}
+    if args.scene_family == "relief" and not args.no_plane_leg and not args.with_upload and not args.evals_only and args.fixed_schedule == 0:
+        # SURVEY.md 8d's literal scene family (PlaneScene: eight sinusoids of 8 ... 128 px on one plane -- rounds 1-3's workload; BASELINE.md
+        # section 2 says how the default relief family departs from it), same configuration, same rules: VERDICT r05 item 4
+        try:
+            a4 = argparse.Namespace(**vars(args))
+            a4.scene_family, a4.cpu_frames = "plane", 0
+            wl4 = build_workload(a4, ctx, args.config)
+            m4 = measure(a4, ctx, wl4, args.second_leg_steps, 1, world)
+            res["config"]["plane_family"] = {"workload": workload_label(a4, wl4, m4["n0"]), "value": m4["value"], "unit": "stereo frames/s",
+                                             "steps": args.second_leg_steps, "ms_per_step": m4["ms_per_step"], "roofline": m4["roofline"], **m4["detail"]}
+            del wl4
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            res["config"]["plane_family"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_replay_leg and not args.with_upload and not args.no_cpu:
         try:
             res["config"]["replay"] = replay_leg(args)

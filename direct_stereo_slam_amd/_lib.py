@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSM_HOTPATH_LIB: developer override used for A/B builds of the same sources (e.g. other compiler flags)
 LIB_PATH = os.environ.get("DSM_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libdsm_hotpath.so")
 MAX_LEVELS = 6
-ABI_VERSION = 3  # DSM_ABI_VERSION of the header the structures below mirror
+ABI_VERSION = 4  # DSM_ABI_VERSION of the header the structures below mirror
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

@@ -1013,8 +1013,8 @@ int dsm_tracker_get_frame(dsm_tracker *t, int slot, int lvl, float *dIp_out) {
 int dsm_tracker_ref_frame_id(dsm_tracker *t) { return t ? t->ref_frame_id : -1; }
 
 int dsm_reduction_geometry(dsm_tracker *t, int lvl, int n, int *threads, int *pts_per_thread_out, int *chunks) {
-  (void)t;
   (void)lvl;
+  if (!t) return invalid("dsm_reduction_geometry: null tracker");
   if (threads) *threads = kThreads;
   if (pts_per_thread_out) *pts_per_thread_out = pts_per_thread(n, t->desc.p.geometry);
   if (chunks) *chunks = num_chunks(n, t->desc.p.geometry);

@@ -524,6 +524,12 @@ int loop_finish(dsm_context *ctx, const dsm_loop_job *jobs, const LoopPlan &P, c
   DSM_HIP(hipMemcpyAsync(h_out, d_out, P.out_bytes, hipMemcpyDeviceToHost, st));
   DSM_HIP(hipStreamSynchronize(st));
   if (h_extra) *h_extra = h_out + P.out_cand;
+  // A job that asks for a descriptor and whose cloud came out empty fails the WHOLE call before anything is written to the caller's
+  // arrays (and, in dsm_loop_detect_batch, before any key is enqueued): a batch is all or nothing, unlike the sequential calls it
+  // otherwise equals, which would have failed at that keyframe with the earlier ones already through
+  for (int j = 0; j < P.n_jobs; j++)
+    if (jobs[j].ringkey && ((const int *)(h_out + P.out_small[j]))[0] < 1)
+      return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set (no output of the call was written)");
   for (int j = 0; j < P.n_jobs; j++) {
     const dsm_loop_job &J = jobs[j];
     const int *small = (const int *)(h_out + P.out_small[j]);
@@ -534,7 +540,6 @@ int loop_finish(dsm_context *ctx, const dsm_loop_job *jobs, const LoopPlan &P, c
       memcpy(J.pts_spherical, h_out + P.out_sph[j], sizeof(double) * 3 * (size_t)n_out);
     }
     if (!J.ringkey) continue;
-    if (n_out < 1) return invalid("dsm_loop_descriptors_batch: ScanContext of an empty point set");
     memcpy(J.tfm_pca_rig, h_out + P.out_small[j] + 16, sizeof(double) * 16);
     *J.n_sig = n_sig;
     memcpy(J.ringkey, (const float *)(h_out + P.out_keys) + (size_t)j * P.num_r, sizeof(float) * (size_t)P.num_r);

@@ -33,8 +33,12 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 3 /* 2: dsm_params.struct_size / fixed_schedule / frame_check / frame_grad_tol, dsm_stats.evals_residual_only;
-                             3: dsm_params_default_sized / DSM_PARAMS_INIT, dsm_stream_* (streaming form of the batched calls) */
+#define DSM_ABI_VERSION 4 /* 2: dsm_params.struct_size / fixed_schedule / frame_check / frame_grad_tol, dsm_stats.evals_residual_only;
+                             3: dsm_params_default_sized / DSM_PARAMS_INIT, dsm_stream_* (streaming form of the batched calls);
+                             4: dsm_params.chunk_geometry takes the slot of version 3's tile_l0 -- same layout, another meaning: 0 now
+                                selects the THROUGHPUT chunk table (float sums differ in their last bits from versions <= 3, whose only
+                                table is today's 1 = LATENCY), and a version-3 caller's tile_l0 = 1 would silently select the latency
+                                table -- hence the bump; dsm_set_refs_from_points requires one geometry per call */
 #define DSM_MAX_LEVELS 6 /* DSO PYR_LEVELS; the reference tracker uses <= 5 (TrackerAndScaler.cpp:457,463) */
 
 typedef enum dsm_status {
@@ -230,7 +234,10 @@ int dsm_tracker_set_ref_from_points(dsm_tracker *t, dsm_tracker *frame_owner, in
 /* The same for the new keyframes of several sequences in ONE call (a node serving many sequences, dsm_stream_*): every job's
  * splat / pyramid / dilate / emit launches are enqueued back to back and the host waits ONCE for all the per-level counts.
  * A tracker may appear as `t` in one job only; results per job as dsm_tracker_set_ref_from_points.  On an error no tracker of
- * the batch has a valid reference any more. */
+ * the batch has a valid reference any more.
+ * ONE GEOMETRY PER CALL: every job's tracker must share image width, height and level count (the launches are batched over the
+ * jobs: blockIdx.y = job); a call that mixes geometries returns DSM_ERR_INVALID before anything is enqueued -- callers with
+ * trackers of several sizes issue one call per size (the per-job loop of ABI versions <= 3 accepted mixed sizes). */
 typedef struct dsm_ref_job {
   dsm_tracker *t, *frame_owner;
   int slot, ref_frame_id;
@@ -566,7 +573,9 @@ int dsm_loop_descriptors_batch(dsm_context *ctx, int n_jobs, const dsm_loop_job 
  * needs its descriptor outputs (ringkey ... tfm_pca_rig); sel_idx / pts_spherical may both be NULL (the selected points -- 0.45 MB per
  * keyframe -- then stay on the device).  Results equal the jobs' dsm_loop_descriptors_batch + dsm_ringdb_query_then_enqueue calls one
  * after the other, bit for bit: cand_out[j * k ...] / ncand_out[j] = search_ringkey's candidate list of job j, and every key is enqueued.
- * Unsharded index; num_r = its key dimension. */
+ * Unsharded index; num_r = its key dimension.
+ * Errors are all-or-nothing: a job whose filtered cloud is empty while a descriptor is asked for fails the call with DSM_ERR_INVALID
+ * BEFORE any output array of any job is written and before any key is enqueued (dsm_loop_descriptors_batch likewise writes nothing). */
 int dsm_loop_detect_batch(dsm_context *ctx, dsm_ringdb *db, int n_jobs, const dsm_loop_job *jobs, double lidar_range, int num_s, int num_r,
                           int *cand_out, int *ncand_out);
 

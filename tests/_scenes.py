@@ -83,11 +83,17 @@ def regrad(level):
     return out
 
 
+def _photometry(sc):
+    """(reference affine g2l, reference exposure, new-frame exposure) of a scene: (0, 0), 1, 1 unless make_affine_scene set them"""
+    return tuple(getattr(sc, "ref_aff", (0.0, 0.0))), float(getattr(sc, "ref_exposure", 1.0)), float(getattr(sc, "new_exposure", 1.0))
+
+
 def oracle_tracker(sc, params=None):
+    ref_aff, ref_exp, new_exp = _photometry(sc)
     orc = O.OracleTracker(sc.w, sc.h, sc.nl, sc.T, sc.K, params)
     orc.make_k(*sc.K)
-    orc.set_ref(0, 0.0, 0.0, 1.0, *sc.tpl)
-    orc.set_frame(0, sc.new_p, 1.0)
+    orc.set_ref(0, ref_aff[0], ref_aff[1], ref_exp, *sc.tpl)
+    orc.set_frame(0, sc.new_p, new_exp)
     orc.set_frame(1, sc.right_p, 1.0)
     return orc
 
@@ -95,12 +101,42 @@ def oracle_tracker(sc, params=None):
 def hip_tracker(ctx, sc, params=None):
     from direct_stereo_slam_amd.tracker import TrackerAndScaler
 
+    ref_aff, ref_exp, new_exp = _photometry(sc)
     trk = TrackerAndScaler(ctx, sc.w, sc.h, sc.nl, sc.T, sc.K, params)
     trk.makeK(*sc.K)
-    trk.setCoarseTrackingRef(0, (0.0, 0.0), 1.0, *sc.tpl)
-    trk.upload_frame(0, sc.new_p, 1.0)
+    trk.setCoarseTrackingRef(0, ref_aff, ref_exp, *sc.tpl)
+    trk.upload_frame(0, sc.new_p, new_exp)
     trk.upload_frame(1, sc.right_p, 1.0)
     return trk
+
+
+def aff_from_to(exp_f, exp_t, g2f, g2t):
+    """AffLight::fromToVecExposure (upstream DSO; call sites TrackerAndScaler.cpp:647-649,717-720): the brightness map
+    I_to = a I_from + b between two frames with affine parameters g2f / g2t and exposures exp_f / exp_t; either exposure 0 => both 1"""
+    if exp_f == 0 or exp_t == 0:
+        exp_f = exp_t = 1.0
+    a = np.exp(g2t[0] - g2f[0]) * exp_t / exp_f
+    return a, g2t[1] - a * g2f[1]
+
+
+def make_affine_scene(size="small", seed=3, ref_aff=(-0.3, 12.0), ref_exposure=0.8, new_exposure=1.3, new_aff=(-0.25, 20.0), family="plane",
+                      noise=1.0):
+    """A scene whose keyframe has a NONZERO affine brightness (a, b) and whose two frames have different exposure times -- what every
+    keyframe of a real sequence has (the reference's photometric model: TrackerAndScaler.cpp:647-649, 673-676, 717-720, 615-626).  The new
+    image is rendered with exactly the brightness map the model predicts for the ground-truth new-frame affine `new_aff`, so that the
+    tracker converges to (gt_pose, new_aff) from the keyframe's own affine as the initial guess (what FrontEnd hands over)."""
+    import math
+
+    sc = make_scene(size, seed=seed, noise=noise) if family == "plane" else make_relief_frames(size, 1, 1, seed0=0x5EED0300 + seed, noise=noise)[0]
+    a, b = aff_from_to(ref_exposure, new_exposure, ref_aff, new_aff)
+    rng = np.random.default_rng(seed + 500)
+    R, t = S.quat_to_rot(sc.gt_pose[:4]), np.asarray(sc.gt_pose[4:], np.float64)
+    sc.new_img = sc.scene.render(sc.K, sc.w, sc.h, R, t, a=math.log(a), b=b, noise=noise, rng=rng)
+    sc.new_p = O.make_images(sc.new_img, sc.nl)
+    sc.ref_aff, sc.ref_exposure, sc.new_exposure = tuple(ref_aff), ref_exposure, new_exposure
+    sc.gt_aff = np.array(new_aff, np.float64)
+    sc.aff_ll = (a, b)
+    return sc
 
 
 def make_relief_frames(size, n_frames, n_tex, seed0=0x5EED0000, noise=2.0, u8=False):

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from direct_stereo_slam_amd import synth as S  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-from _scenes import make_relief_frames, make_scene, oracle_tracker  # noqa: E402
+from _scenes import make_affine_scene, make_relief_frames, make_scene, oracle_tracker  # noqa: E402
 from test_oracle_ringkey import ring_keys  # noqa: E402
 
 
@@ -173,12 +173,43 @@ def tracker_relief_fixture():
     np.savez_compressed(os.path.join(HERE, "tracker_relief_small.npz"), **out)
 
 
+def tracker_affine_fixture():
+    """the photometric branch every real keyframe takes: reference affine (-0.3, 12), exposures 0.8 -> 1.3 on a
+    308x92x3 relief frame; plus the same frame with a ZERO reference exposure (fromToVecExposure's "either 0 => both 1").  Expected: the
+    fused evaluation of every level at the ground truth (rs, H, b, warped count) and the track from the keyframe's own affine."""
+    out = {}
+    for tag, ref_exp in (("exp", 0.8), ("zero", 0.0)):
+        sc = make_affine_scene("small", seed=41, ref_aff=(-0.3, 12.0), ref_exposure=ref_exp, new_exposure=1.3, new_aff=(-0.25, 20.0), family="relief")
+        orc = oracle_tracker(sc)
+        if tag == "exp":
+            out.update({"w": sc.w, "h": sc.h, "nl": sc.nl, "K": np.asarray(sc.K, np.float64), "T": sc.T, "gt_pose": sc.gt_pose, "gt_aff": sc.gt_aff,
+                        "ref_aff": np.array(sc.ref_aff), "new_exposure": sc.new_exposure})
+            for l in range(sc.nl):
+                for name, arr in zip(("u", "v", "id", "c"), sc.tpl):
+                    out[f"tpl_{name}{l}"] = arr[l]
+        out[f"{tag}_ref_exposure"] = ref_exp
+        out[f"{tag}_new_img"] = sc.new_img
+        for lvl in range(sc.nl):
+            rs = orc.calc_res_pose(lvl, sc.gt_pose, sc.gt_aff, 20.0)
+            out[f"{tag}_rs{lvl}"], out[f"{tag}_E64_{lvl}"] = rs, orc.last_energy_f64()
+            H, b = orc.calc_gs_pose(lvl, sc.gt_pose, sc.gt_aff)
+            out[f"{tag}_H{lvl}"], out[f"{tag}_b{lvl}"], out[f"{tag}_n{lvl}"] = H, b, orc.pose_warped_n()
+        good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, list(sc.ref_aff), sc.nl - 1)
+        out[f"{tag}_track_good"], out[f"{tag}_track_pose"], out[f"{tag}_track_aff"], out[f"{tag}_track_last"], out[f"{tag}_track_flow"] = good, pose, aff, last, flow
+        out[f"{tag}_track_evals"] = np.array(orc.eval_counts()[0])
+    np.savez_compressed(os.path.join(HERE, "tracker_affine_small.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "relief":  # (adds the round-5 fixture without rewriting the others)
         tracker_relief_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "affine":  # (round 6)
+        tracker_affine_fixture()
+        sys.exit(0)
     tracker_fixture()
     tracker_relief_fixture()
+    tracker_affine_fixture()
     ringkey_fixture()
     tracker_small_fixture()
     pose_estimator_fixture()

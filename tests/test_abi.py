@@ -45,7 +45,7 @@ def test_no_cpu_fallback(built):
     from direct_stereo_slam_amd import _lib
 
     L = _lib.load()
-    assert L.dsm_abi_version() == _lib.ABI_VERSION == 3
+    assert L.dsm_abi_version() == _lib.ABI_VERSION == 4
     # the header's DSM_ABI_VERSION is what the library reports
     import re
     hdr = open(os.path.join(ROOT, 'include', 'dsm_hotpath.h')).read()

@@ -270,3 +270,71 @@ def test_oracle_reproduces_golden_relief_frames():
         if i == 0:
             err, s = orc.optimize_scale(1.0, nl - 1)
             assert np.float32(s) == d["scale_out"] and np.float32(err) == d["scale_err"] and orc.eval_counts()[0] == list(d["scale_evals"])
+
+
+# ---- round 6: the photometric branch of a real keyframe (nonzero reference affine, unequal exposures, a zero exposure) ----
+def load_affine_fixture():
+    d = np.load(os.path.join(G, "tracker_affine_small.npz"))
+    nl = int(d["nl"])
+    tpl = [[d[f"tpl_{n}{l}"] for l in range(nl)] for n in ("u", "v", "id", "c")]
+    return d, nl, tpl
+
+
+def test_oracle_reproduces_golden_affine_frames():
+    d, nl, tpl = load_affine_fixture()
+    w, h, K, T = int(d["w"]), int(d["h"]), tuple(d["K"]), d["T"]
+    for tag in ("exp", "zero"):
+        orc = O.OracleTracker(w, h, nl, T, K)
+        orc.make_k(*K)
+        orc.set_ref(0, float(d["ref_aff"][0]), float(d["ref_aff"][1]), float(d[f"{tag}_ref_exposure"]), *tpl)
+        orc.set_frame(0, O.make_images(d[f"{tag}_new_img"], nl), float(d["new_exposure"]))
+        for lvl in range(nl):
+            rs = orc.calc_res_pose(lvl, d["gt_pose"], d["gt_aff"], 20.0)
+            H, b = orc.calc_gs_pose(lvl, d["gt_pose"], d["gt_aff"])
+            np.testing.assert_array_equal(rs, d[f"{tag}_rs{lvl}"])
+            np.testing.assert_array_equal(H, d[f"{tag}_H{lvl}"])
+            np.testing.assert_array_equal(b, d[f"{tag}_b{lvl}"])
+            assert orc.pose_warped_n() == int(d[f"{tag}_n{lvl}"])
+        good, pose, aff, last, flow = orc.track(S.IDENTITY_POSE, list(d["ref_aff"]), nl - 1)
+        assert good == bool(d[f"{tag}_track_good"]) and good
+        np.testing.assert_allclose(pose, d[f"{tag}_track_pose"], atol=1e-12)
+        np.testing.assert_allclose(aff, d[f"{tag}_track_aff"], rtol=1e-10, atol=1e-12)
+        assert orc.eval_counts()[0] == list(d[f"{tag}_track_evals"])
+        np.testing.assert_allclose(pose[4:], d["gt_pose"][4:], atol=5e-3)
+    # the two cases really are different photometries: exposure ratio 1.3 / 0.8 against 1 (the zero rule)
+    assert not np.allclose(d["exp_H0"][6], d["zero_H0"][6], rtol=1e-2)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_affine_frames(ctx):
+    from direct_stereo_slam_amd.tracker import Stream, TrackerAndScaler
+
+    d, nl, tpl = load_affine_fixture()
+    w, h, K, T = int(d["w"]), int(d["h"]), tuple(d["K"]), d["T"]
+    for tag in ("exp", "zero"):
+        trk = TrackerAndScaler(ctx, w, h, nl, T, K)
+        trk.makeK(*K)
+        trk.setCoarseTrackingRef(0, tuple(d["ref_aff"]), float(d[f"{tag}_ref_exposure"]), *tpl)
+        trk.upload_image(0, d[f"{tag}_new_img"], float(d["new_exposure"]))  # (device pyramid: makeImages on the GPU)
+        for lvl in range(nl):
+            rs, H, b, n = trk.calcResPose(lvl, d["gt_pose"], d["gt_aff"], 20.0)
+            g_rs, g_H, g_b = d[f"{tag}_rs{lvl}"], d[f"{tag}_H{lvl}"], d[f"{tag}_b{lvl}"]
+            assert rs[1] == g_rs[1] and n == int(d[f"{tag}_n{lvl}"]) and np.float32(rs[5]) == np.float32(g_rs[5])
+            np.testing.assert_allclose(rs[0], float(d[f"{tag}_E64_{lvl}"]), rtol=2e-6)
+            np.testing.assert_allclose(H, g_H, rtol=0, atol=2e-5 * np.abs(g_H).max())
+            for c in range(8):  # the affine row against its own scale
+                assert abs(H[6, c] - g_H[6, c]) <= 2e-5 * np.sqrt(g_H[6, 6] * g_H[c, c])
+            np.testing.assert_allclose(b, g_b, rtol=0, atol=2e-5 * max(np.abs(g_b).max(), 1e-3 * np.sqrt(np.abs(g_H).max())))
+            assert abs(b[6] - g_b[6]) <= 2e-5 * max(abs(g_b[6]), np.sqrt(g_H[6, 6] * g_rs[0] / g_rs[1]))
+        good, pose, aff, last = trk.trackNewestCoarse(S.IDENTITY_POSE, list(d["ref_aff"]), nl - 1)
+        assert good == bool(d[f"{tag}_track_good"])
+        np.testing.assert_allclose(pose, d[f"{tag}_track_pose"], atol=1e-4)
+        np.testing.assert_allclose(aff, d[f"{tag}_track_aff"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(last[:nl], d[f"{tag}_track_last"][:nl], rtol=1e-4)
+        assert list(ctx.stats().evals)[:nl] == list(d[f"{tag}_track_evals"])[:nl]
+        st = Stream(ctx, 1, 0)  # and through the tick engine: the direct call's bits
+        tk = st.submit_track([trk], [S.IDENTITY_POSE], np.array([d["ref_aff"]]), nl - 1)[0]
+        st.drain()
+        got = {r.ticket: r for r in st.results()}
+        st.close()
+        assert np.array_equal(np.array(got[tk].pose), pose) and np.array_equal(np.array(got[tk].aff), aff)

@@ -14,7 +14,7 @@ import pytest
 from direct_stereo_slam_amd import synth as S
 from oracle import oracle as O
 
-from _scenes import hip_tracker, make_scene, oracle_tracker, regrad
+from _scenes import hip_tracker, make_affine_scene, make_scene, oracle_tracker, regrad
 
 pytestmark = pytest.mark.gpu
 
@@ -274,6 +274,91 @@ def test_track_abort_and_affine_checks(ctx):
     good_g, pose_g, aff_g, _ = trk2.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc2.nl - 1)
     assert good_g == good_o
     np.testing.assert_allclose(pose_g, pose_o, atol=2e-4)
+
+
+# The photometric model of a REAL sequence: every keyframe carries a nonzero affine brightness (a, b) and the two
+# frames have different exposure times.  AffLight::fromToVecExposure(lastRef->ab_exposure, new_frame_->ab_exposure, lastRef_aff_g2l,
+# aff_g2l) (TrackerAndScaler.cpp:717-720, :647-649), J6 = a (b0 - refColor) (:673-676) with b0 = lastRef_aff_g2l.b (:646), the
+# "either exposure 0 => both 1" rule of fromToVecExposure, and the plausibility checks on the RELATIVE affine at the end (:615-626).
+AFFINE_CASES = {
+    "dark_keyframe_longer_exposure": dict(ref_aff=(-0.3, 12.0), ref_exposure=0.8, new_exposure=1.3, new_aff=(-0.25, 20.0)),
+    "bright_keyframe_shorter_exposure": dict(ref_aff=(0.15, -6.0), ref_exposure=1.3, new_exposure=0.8, new_aff=(0.2, -2.0)),
+    "zero_reference_exposure": dict(ref_aff=(-0.3, 12.0), ref_exposure=0.0, new_exposure=1.3, new_aff=(-0.25, 20.0)),
+    "zero_new_exposure": dict(ref_aff=(-0.3, 12.0), ref_exposure=0.8, new_exposure=0.0, new_aff=(-0.25, 20.0)),
+    "relief_family": dict(ref_aff=(-0.3, 12.0), ref_exposure=0.8, new_exposure=1.3, new_aff=(-0.25, 20.0), family="relief"),
+}
+
+
+def assert_affine_row(orc, trk, lvl, pose, aff, cutoff):
+    """row / column 6 of H and b[6] -- the only entries J6 = a (b0 - refColor) reaches -- each against ITS OWN scale (the whole-matrix bar
+    of assert_eval_pose_equal is relative to max |H|, which the SCALE_B = 1000 entry H[7][7] dominates)"""
+    rs_o = orc.calc_res_pose(lvl, pose, aff, cutoff)
+    H_o, b_o = orc.calc_gs_pose(lvl, pose, aff)
+    rs_g, H_g, b_g, n_g = trk.calcResPose(lvl, pose, aff, cutoff)
+    if n_g == 0:
+        return
+    assert H_o[6, 6] > 0
+    for c in range(8):  # |H[6][c]| <= sqrt(H[6][6] H[c][c]) (Cauchy-Schwarz on the weighted sums): the natural scale of the entry
+        tol = FLOAT_RTOL * np.sqrt(H_o[6, 6] * H_o[c, c])
+        assert abs(H_g[6, c] - H_o[6, c]) <= tol and abs(H_g[c, 6] - H_o[c, 6]) <= tol, (lvl, c, H_g[6, c], H_o[6, c])
+    assert abs(b_g[6] - b_o[6]) <= FLOAT_RTOL * max(abs(b_o[6]), np.sqrt(H_o[6, 6] * rs_o[0] / max(rs_o[1], 1.0))), (lvl, b_g[6], b_o[6])
+
+
+@pytest.mark.parametrize("case", sorted(AFFINE_CASES))
+def test_affine_and_exposure_branch_all_levels_track_and_stream(ctx, case):
+    from direct_stereo_slam_amd.tracker import Stream
+
+    sc = make_affine_scene("small", seed=31, **AFFINE_CASES[case])
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    # ---- fused evaluations, every level: the keyframe's own affine (what FrontEnd hands over as the guess), the truth, and (0, 0) ----
+    for lvl in range(sc.nl):
+        for pose in (S.IDENTITY_POSE, sc.gt_pose):
+            for aff in (list(sc.ref_aff), list(sc.gt_aff), [0.0, 0.0]):
+                for cutoff in (20.0, 5.0):
+                    assert_eval_pose_equal(orc, trk, lvl, pose, aff, cutoff)
+                assert_affine_row(orc, trk, lvl, pose, aff, 20.0)
+    # the branch really is exercised: the same images and template under the photometry every other test uses -- reference affine (0, 0),
+    # exposures 1 -- give another residual and another affine row
+    import copy
+
+    plain = copy.copy(sc)
+    plain.ref_aff, plain.ref_exposure, plain.new_exposure = (0.0, 0.0), 1.0, 1.0
+    orc_plain = oracle_tracker(plain)
+    rs_p, rs_a = orc_plain.calc_res_pose(0, sc.gt_pose, list(sc.gt_aff), 20.0), orc.calc_res_pose(0, sc.gt_pose, list(sc.gt_aff), 20.0)
+    H_p, H_a = orc_plain.calc_gs_pose(0, sc.gt_pose, list(sc.gt_aff))[0], orc.calc_gs_pose(0, sc.gt_pose, list(sc.gt_aff))[0]
+    assert abs(rs_p[0] - rs_a[0]) > 0.05 * rs_a[0] and not np.allclose(H_p[6], H_a[6], rtol=1e-2)
+    # ---- the LM loop ----
+    good_o, pose_o, aff_o, last_o, flow_o = orc.track(S.IDENTITY_POSE, list(sc.ref_aff), sc.nl - 1)
+    good_g, pose_g, aff_g, last_g = trk.trackNewestCoarse(S.IDENTITY_POSE, list(sc.ref_aff), sc.nl - 1)
+    assert good_g == good_o and good_o
+    np.testing.assert_allclose(pose_g, pose_o, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(aff_g, aff_o, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(last_g[:sc.nl], last_o[:sc.nl], rtol=1e-4)
+    np.testing.assert_allclose(trk.lastFlowIndicators, flow_o, rtol=1e-3)
+    np.testing.assert_allclose(pose_g[4:], sc.gt_pose[4:], atol=5e-3)  # and it is the scene's motion
+    assert list(ctx.stats().evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
+    # ---- the tick engine (what bench.py's step runs): the same bits as the direct call ----
+    st = Stream(ctx, 2, 1)
+    tk = st.submit_track([trk], [S.IDENTITY_POSE], np.array([sc.ref_aff]), sc.nl - 1)[0]
+    st.drain()
+    got = {r.ticket: r for r in st.results()}
+    st.close()
+    assert np.array_equal(np.array(got[tk].pose), pose_g) and np.array_equal(np.array(got[tk].aff), aff_g) and bool(got[tk].good) == bool(good_g)
+    assert list(got[tk].evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
+
+
+def test_implausible_relative_affine_fails_the_track_like_the_reference(ctx):
+    """:615-626: |log(relative a)| > 1.5 -- here an exposure ratio of 6.5 -- returns false AFTER lastToNew_out / aff_g2l_out were written
+    (:612-613); the pose is the tracked one"""
+    sc = make_affine_scene("small", seed=31, ref_aff=(-0.3, 12.0), ref_exposure=0.2, new_exposure=1.3, new_aff=(-0.25, 20.0))
+    orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc)
+    good_o, pose_o, aff_o, last_o, _ = orc.track(S.IDENTITY_POSE, list(sc.ref_aff), sc.nl - 1)
+    good_g, pose_g, aff_g, last_g = trk.trackNewestCoarse(S.IDENTITY_POSE, list(sc.ref_aff), sc.nl - 1)
+    assert not good_o and not good_g
+    np.testing.assert_allclose(pose_g, pose_o, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(aff_g, aff_o, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pose_g[4:], sc.gt_pose[4:], atol=5e-3)
+    assert list(ctx.stats().evals)[:sc.nl] == orc.eval_counts()[0][:sc.nl]
 
 
 @pytest.mark.parametrize("modes", [(-1.0, -1.0), (0.0, -1.0), (-1.0, 0.0)])

@@ -1107,6 +1107,28 @@ static double ate(const std::vector<SE3> &a, const std::vector<SE3> &b) {
   return std::sqrt(s / (double)a.size());
 }
 
+// Relative pose error over a step of one frame (the RPE of the TUM / KITTI trajectory tools, delta = 1): with camera-to-world poses
+// P_i = est_i^-1 and Q_i = gt_i^-1, E_i = (Q_i^-1 Q_{i+1})^-1 (P_i^-1 P_{i+1}); RMSE of |trans(E_i)| and of the rotation angle of E_i.
+// What dslam.txt is compared by next to the ATE (README.md:73-75; the trajectory itself: LoopHandler.cpp:60-80).
+struct Rpe {
+  double trans_m, rot_deg;
+};
+static Rpe rpe(const std::vector<SE3> &est, const std::vector<SE3> &gt) {
+  double st = 0, sr = 0;
+  size_t n = 0;
+  for (size_t i = 0; i + 1 < est.size() && i + 1 < gt.size(); i++, n++) {
+    const SE3 dp = se3_mul(est[i], se3_inv(est[i + 1])); // P_i^-1 P_{i+1} with P = est^-1
+    const SE3 dq = se3_mul(gt[i], se3_inv(gt[i + 1]));
+    const SE3 e = se3_mul(se3_inv(dq), dp);
+    st += e.t[0] * e.t[0] + e.t[1] * e.t[1] + e.t[2] * e.t[2];
+    const double sn = std::sqrt(e.q[0] * e.q[0] + e.q[1] * e.q[1] + e.q[2] * e.q[2]);
+    const double ang = 2.0 * std::atan2(sn, std::fabs(e.q[3]));
+    sr += ang * ang;
+  }
+  if (!n) return Rpe{0, 0};
+  return Rpe{std::sqrt(st / (double)n), std::sqrt(sr / (double)n) * 180.0 / M_PI};
+}
+
 static void print_result(const char *name, const RunResult &R, const Pack &P, const std::string &traj_path) {
   printf("\"%s\": {\"stages_mean_ms\": {", name);
   bool first = true;
@@ -1119,10 +1141,12 @@ static void print_result(const char *name, const RunResult &R, const Pack &P, co
     with_cand += !R.candidates[i].empty();
     twin += R.matched[i] == (int)i; // the first pass's keyframe of the same place
   }
+  const Rpe rp = rpe(R.est, P.gt);
   printf("}, \"frames\": %d, \"keyframes\": %d, \"hypothesis_tries\": %d, \"frames_needing_retries\": %d, \"frames_lost\": %d, \"ate_vs_ground_truth_m\": %.6g, "
+         "\"rpe_vs_ground_truth\": {\"delta_frames\": 1, \"trans_rmse_m\": %.6g, \"rot_rmse_deg\": %.6g}, "
          "\"loop_queries\": %d, \"queries_with_candidates\": %d, \"search_sc_matches_the_first_pass_twin\": %d, \"trajectory\": \"%s\"}",
-         P.n_frames, (P.n_frames + P.kf_every - 1) / P.kf_every, R.tries_total, R.frames_with_retries, R.lost, ate(R.est, P.gt), (int)R.candidates.size(),
-         with_cand, twin, traj_path.c_str());
+         P.n_frames, (P.n_frames + P.kf_every - 1) / P.kf_every, R.tries_total, R.frames_with_retries, R.lost, ate(R.est, P.gt), rp.trans_m, rp.rot_deg,
+         (int)R.candidates.size(), with_cand, twin, traj_path.c_str());
 }
 
 int main(int argc, char **argv) {
@@ -1202,9 +1226,12 @@ int main(int argc, char **argv) {
       same_cand += rg.candidates[i] == rc.candidates[i];
       same_match += rg.matched[i] == rc.matched[i];
     }
-    printf(", \"gpu_vs_cpu\": {\"max_abs_trajectory_diff_m\": %.6g, \"ate_ratio_gpu_over_cpu\": %.6f, \"loop_queries\": %d, \"queries_with_identical_candidates\": %d, "
-           "\"queries_with_identical_search_sc_match\": %d}",
-           dmax, ate(rg.est, P.gt) / std::fmax(ate(rc.est, P.gt), 1e-30), (int)rg.candidates.size(), same_cand, same_match);
+    const Rpe rpg = rpe(rg.est, P.gt), rpc = rpe(rc.est, P.gt), rpd = rpe(rg.est, rc.est); // (rpd: the GPU path's steps against the CPU path's own)
+    printf(", \"gpu_vs_cpu\": {\"max_abs_trajectory_diff_m\": %.6g, \"ate_ratio_gpu_over_cpu\": %.6f, \"rpe_trans_ratio_gpu_over_cpu\": %.6f, "
+           "\"rpe_rot_ratio_gpu_over_cpu\": %.6f, \"rpe_gpu_against_cpu_trans_m\": %.6g, \"rpe_gpu_against_cpu_rot_deg\": %.6g, \"loop_queries\": %d, "
+           "\"queries_with_identical_candidates\": %d, \"queries_with_identical_search_sc_match\": %d}",
+           dmax, ate(rg.est, P.gt) / std::fmax(ate(rc.est, P.gt), 1e-30), rpg.trans_m / std::fmax(rpc.trans_m, 1e-30), rpg.rot_deg / std::fmax(rpc.rot_deg, 1e-30),
+           rpd.trans_m, rpd.rot_deg, (int)rg.candidates.size(), same_cand, same_match);
     if (have_eq) {
       int keys_eq = 0, cand_eq = 0, match_eq = 0;
       for (size_t i = 0; i < eq.candidates.size() && i < rc.candidates.size(); i++) {
