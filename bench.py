@@ -63,6 +63,7 @@ CONFIGS = {
 
 def parse():
     a = _parse()
+    a.streams_given = a.streams
     if a.streams is None:
         a.streams = 3 if (a.stream and not a.with_upload) else 2
     return a
@@ -128,7 +129,8 @@ def _parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true", help="skip the short reference-faithful five-level (S1) leg reported in config.reference_five_level")
     ap.add_argument("--second-leg-steps", type=int, default=10, help="timed steps of the fixed-schedule and five-level legs (streamed: ramp-up and drain are inside, so a handful of steps understates the rate)")
-    ap.add_argument("--quick", action="store_true", help="the headline leg alone: --no-cpu --no-fixed-leg --no-second-leg --no-plane-leg --no-replay-leg --no-ringkey-leg (A/B runs, profiles)")
+    ap.add_argument("--quick", action="store_true", help="the headline leg alone: --no-cpu --no-fixed-leg --no-second-leg --no-plane-leg --no-upload-leg --no-replay-leg --no-ringkey-leg (A/B runs, profiles)")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the PCIe-inclusive leg of the default line (config.with_upload)")
     ap.add_argument("--no-plane-leg", action="store_true", help="skip the short leg on SURVEY.md 8d's literal scene family (config.plane_family)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-core leg of the CPU baseline (one share of frames per physical core, forked workers)")
     ap.add_argument("--evals-only", action="store_true",
@@ -153,7 +155,7 @@ def _parse():
                          "stdout line is its compact form (< 4 KB: contract keys, roofline and cpu_baseline as numbers, one summary per leg)")
     a = ap.parse_args()
     if a.quick:
-        a.no_cpu = a.no_fixed_leg = a.no_second_leg = a.no_plane_leg = a.no_replay_leg = a.no_ringkey_leg = True
+        a.no_cpu = a.no_fixed_leg = a.no_second_leg = a.no_plane_leg = a.no_upload_leg = a.no_replay_leg = a.no_ringkey_leg = True
     return a
 
 
@@ -1342,6 +1344,10 @@ def compact_line(res, detail_path):
     if isinstance(pf, dict):
         legs["plane"] = {"error": pf["error"][:120]} if "error" in pf else {
             **_pick(pf, ("value", "ms_per_step", "algorithmic_MB_per_frame")), **_pick(pf.get("roofline") or {}, ("frac", "frac_whole_step"))}
+    wu = c.get("with_upload")
+    if isinstance(wu, dict):
+        legs["with_upload"] = {"error": wu["error"][:120]} if "error" in wu else {
+            **_pick(wu, ("value", "ms_per_step")), "form": "batch, u8 pinned double-buffered", "host_MB_per_step": _r(wu.get("host_bytes_per_step", 0) / 1e6, 4)}
     rp = c.get("replay")
     if isinstance(rp, dict):
         lr = {}
@@ -1567,6 +1573,29 @@ def bench_tracking(args):
             del wl4
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["plane_family"] = {"error": repr(e)}
+    if not args.no_upload_leg and not args.with_upload and not args.evals_only and args.fixed_schedule == 0:
+        # The PCIe-inclusive figure in the driver's line (never `value`): every step hands the B new left images and
+        # the keyframes' right images over as camera bytes in page-locked host buffers -- double-buffered, the images of step i + 1 travel
+        # while step i is tracked -- and builds their pyramids on the device (row N1) inside the timed region; one synchronous
+        # dsm_track_and_scale_batch call per step (the batch form: a step's frames are all back before the next step swaps its images in,
+        # which the streamed form's standing backlog does not guarantee).  128 distinct frames cycled over the B trackers.
+        try:
+            a5 = argparse.Namespace(**vars(args))
+            a5.with_upload, a5.u8, a5.pinned, a5.overlap, a5.stream, a5.cpu_frames, a5.scenes = True, True, True, True, 0, 0, min(128, args.batch)
+            if args.streams_given is None:
+                a5.streams = 2
+            ctx.set_streams(a5.streams)
+            wl5 = build_workload(a5, ctx, args.config)
+            m5 = measure(a5, ctx, wl5, args.second_leg_steps, 2, world, True)
+            px = wl5["w"] * wl5["h"]
+            res["config"]["with_upload"] = {"what": "host images (mono8, page-locked) handed over and pyramids built inside the timed region, double-buffered; batch form",
+                                            "value": m5["value"], "unit": "stereo frames/s", "steps": args.second_leg_steps, "ms_per_step": m5["ms_per_step"],
+                                            "host_bytes_per_step": int(px * (len(wl5["trackers"]) + len(range(0, len(wl5["trackers"]), args.kf_every)))),
+                                            "roofline": m5["roofline"], **m5["detail"]}
+            del wl5
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            res["config"]["with_upload"] = {"error": repr(e)}
+        ctx.set_streams(args.streams)
     if rank == 0 and world == 1 and not args.no_replay_leg and not args.with_upload and not args.no_cpu:
         try:
             res["config"]["replay"] = replay_leg(args)

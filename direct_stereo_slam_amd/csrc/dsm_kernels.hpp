@@ -10,16 +10,20 @@ namespace dsm {
 // consecutive template points, thread t handles points chunk*256*P + k*256 + t for k = 0..P-1.  P is chosen per level from its point
 // count by one of two tables (dsm_params.chunk_geometry):
 //   throughput (0, the default): long chunks -- the per-chunk prologue (three dependent memory round trips before the first point's
-//     arithmetic) and epilogue (52 row sums, a barrier, the partial) are paid once per 16 points per thread down to levels of 16 k points.
-//     Many problems in flight: the stream, the batched calls.  Measured against the other table on the streamed bench: + 7 %
-//     (profiles/r05_ab_geometry.log; the levels below 0 run 10-45 % faster, the LM step reads half the partials)
+//     arithmetic) and epilogue (52 row sums, a barrier, the partial) are paid once per 16 points per thread, and a level of at most 4096
+//     points is ONE chunk (the smallest P of 1 / 2 / 4 / 8 / 16 whose 256 P points hold it).  Many problems in flight: the stream, the
+//     batched calls.  Round 5's table (16 points per thread from 16 k points up, 8 / 4 / 2 from 4 k / 1 k / 512) measured + 7 % on the
+//     streamed bench against the latency table (profiles/r05_ab_geometry.log); round 6's shader-clock stamps inside the tick engine's
+//     kernel (profiles/r06_tick_stamps.json) showed its small levels still paying the fixed cost several times over -- a
+//     chunk costs about 12 k cycles plus 2 k per point per thread: level 5 of the metric's pyramid (280 points) ran as two workgroups of
+//     14.6 k cycles, level 4 (1480) as two of 20 k, level 3 (6688) as four of 28 k; 8.6 % of the kernel's workgroup time for 2.2 % of its bytes
 //   latency (1): short chunks -- more workgroups per evaluation, each through sooner: ONE problem in flight (the replay adaptors):
 //     0.53 instead of 0.61 ms per frame there
 // Results differ between the tables in the last bits of the float sums only (another summation tree); integer outputs are identical.
 enum { kGeomThroughput = 0, kGeomLatency = 1 };
 __host__ __device__ inline int pts_per_thread(int n, int geom) {
   if (geom == kGeomLatency) return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
-  return n >= 16 * 1024 ? 16 : n >= 4 * 1024 ? 8 : n >= 1024 ? 4 : n >= 512 ? 2 : 1;
+  return n > 2048 ? 16 : n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
 }
 // chunks of a list of n points at P points per thread
 __host__ __device__ inline int chunks_of(int n, int ppt) {
@@ -31,7 +35,7 @@ __host__ __device__ inline int num_chunks(int n, int geom) { return chunks_of(n,
 // largest chunk count any n <= cap can produce under either table (P grows with n, so num_chunks is not monotone)
 inline int max_chunks_upto(int cap) {
   int best = 0;
-  const int edges[8] = {cap, 256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1, 1023, 511, 255};
+  const int edges[8] = {cap, 256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1, 1023, 511, 255}; // (the latency table's edges; the throughput table's count grows with n)
   for (int g = 0; g < 2; g++)
     for (int e : edges)
       if (e <= cap && num_chunks(e, g) > best) best = num_chunks(e, g);

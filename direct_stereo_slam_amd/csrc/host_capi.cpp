@@ -88,11 +88,22 @@ int dsm_scancontext_generate(const double *pts, int n, double lidar_range, int n
   mx /= n;
   my /= n;
   mz /= n;
-  double cov[9] = {0};
+  // the covariance (:40): kCovLanes interleaved partial sums, added in ascending order (loopdet_internal.hpp -- the device form's order)
+  std::vector<double> part(6 * (size_t)dsm::kCovLanes, 0.0); // [xx xy xz yy yz zz][lane]
   for (int i = 0; i < n; i++) {
     const double x = pts[3 * i] - mx, y = pts[3 * i + 1] - my, z = pts[3 * i + 2] - mz;
-    cov[0] += x * x, cov[1] += x * y, cov[2] += x * z, cov[4] += y * y, cov[5] += y * z, cov[8] += z * z;
+    const int l = i % dsm::kCovLanes;
+    part[0 * dsm::kCovLanes + l] += x * x, part[1 * dsm::kCovLanes + l] += x * y, part[2 * dsm::kCovLanes + l] += x * z;
+    part[3 * dsm::kCovLanes + l] += y * y, part[4 * dsm::kCovLanes + l] += y * z, part[5 * dsm::kCovLanes + l] += z * z;
   }
+  double m6[6];
+  for (int k = 0; k < 6; k++) {
+    double acc = part[(size_t)k * dsm::kCovLanes];
+    for (int l = 1; l < dsm::kCovLanes; l++) acc += part[(size_t)k * dsm::kCovLanes + l];
+    m6[k] = acc;
+  }
+  double cov[9] = {0};
+  cov[0] = m6[0], cov[1] = m6[1], cov[2] = m6[2], cov[4] = m6[3], cov[5] = m6[4], cov[8] = m6[5];
   cov[3] = cov[1], cov[6] = cov[2], cov[7] = cov[5];
   double ev[3], V[9];
   eig3_sym(cov, ev, V);

@@ -6,6 +6,14 @@
 #include <cmath>
 
 namespace dsm {
+// Summation order of align_points_PCA's moments, shared by the host form (host_capi.cpp) and the device form (loopdet_kernels.hip):
+//   * the MEAN is the reference's own loop, three sums in point order (ScanContext.cpp:22-29) -- kept to the letter;
+//   * the COVARIANCE `pts_mat.transpose() * pts_mat` (:40) is an Eigen product whose accumulation order the reference does not define
+//     (blocked GEMM): here kCovLanes interleaved partial sums -- partial l adds the products of points l, l + kCovLanes, ... in that
+//     order -- which are then added in ascending l.  (Round 5 summed the covariance in point order too, on ONE lane per moment: 0.86 of
+//     the 0.97 ms a single keyframe's loop chain took on the device.)
+constexpr int kCovLanes = 256;
+
 // symmetric 3x3 eigen-decomposition, eigenvalues ascending, eigenvectors in the columns of V, each oriented so that its
 // largest-magnitude component is positive (ScanContext.cpp:41-47; Eigen leaves the sign undefined).  Host AND device: the
 // device form of the loop descriptors (loopdet_kernels.hip) runs the same operations in the same order (-ffp-contract=off).

@@ -203,24 +203,56 @@ __global__ void voxel_emit_kernel(const JobDev *jobs, long long cells) {
 }
 
 // ---- ScanContext ----------------------------------------------------------------------------------------------------------
-// align_points_PCA :22-40: mean (sum in point order / n), then the covariance sums of the centred points in point order; one
-// lane per moment, so the sums have the host form's order and bits
-__global__ void sc_moments_kernel(const JobDev *jobs) {
+// align_points_PCA :22-40.  The mean is the reference's loop to the letter -- three sums in point order (lanes 0 .. 2 of wave 0) -- with
+// the points travelling through LDS tiles that waves 1 .. 3 load one tile ahead (coalesced), so that the chain is the additions alone
+// and not a global-memory round trip per point; the covariance as kCovLanes interleaved partial sums added in ascending order
+// (loopdet_internal.hpp), one partial per thread: the host form's order and bits.
+constexpr int kMomTile = 1024; // points per LDS tile
+static_assert(kCovLanes == kLdThreads, "one covariance partial per thread");
+__global__ __launch_bounds__(kLdThreads) void sc_moments_kernel(const JobDev *jobs) {
   const JobDev &J = jobs[blockIdx.x];
   const int n = *J.n_out, t = threadIdx.x;
+  __shared__ double tile[2][3 * kMomTile];
   __shared__ double mean[3];
+  __shared__ double part[6][kCovLanes];
+  const int ntiles = (n + kMomTile - 1) / kMomTile;
+  auto load_tile = [&](int k, int first, int step) {
+    const size_t base = 3 * (size_t)k * kMomTile;
+    const int cnt = 3 * ((n - k * kMomTile) < kMomTile ? (n - k * kMomTile) : kMomTile);
+    for (int i = first; i < cnt; i += step) tile[k & 1][i] = J.sph[base + i];
+  };
+  if (ntiles) load_tile(0, t, kLdThreads);
+  __syncthreads();
+  double s = 0;
+  for (int k = 0; k < ntiles; k++) {
+    if (t >= 64) {
+      if (k + 1 < ntiles) load_tile(k + 1, t - 64, kLdThreads - 64);
+    } else if (t < 3) {
+      const int cnt = (n - k * kMomTile) < kMomTile ? (n - k * kMomTile) : kMomTile;
+      const double *p = &tile[k & 1][t];
+      for (int i = 0; i < cnt; i++) s += p[3 * i];
+    }
+    __syncthreads();
+  }
   if (t < 3) {
-    double s = 0;
-    for (int i = 0; i < n; i++) s += J.sph[3 * (size_t)i + t];
     mean[t] = n > 0 ? s / n : 0.0;
     J.moments[t] = mean[t];
   }
   __syncthreads();
+  {
+    const double mx = mean[0], my = mean[1], mz = mean[2];
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    for (int i = t; i < n; i += kCovLanes) {
+      const double x = J.sph[3 * (size_t)i] - mx, y = J.sph[3 * (size_t)i + 1] - my, z = J.sph[3 * (size_t)i + 2] - mz;
+      xx += x * x, xy += x * y, xz += x * z, yy += y * y, yz += y * z, zz += z * z;
+    }
+    part[0][t] = xx, part[1][t] = xy, part[2][t] = xz, part[3][t] = yy, part[4][t] = yz, part[5][t] = zz;
+  }
+  __syncthreads();
   if (t < 6) {
-    const int a = t < 3 ? 0 : t < 5 ? 1 : 2, b = t < 3 ? t : t < 5 ? t - 2 : 2; // xx xy xz yy yz zz
-    double s = 0;
-    for (int i = 0; i < n; i++) s += (J.sph[3 * (size_t)i + a] - mean[a]) * (J.sph[3 * (size_t)i + b] - mean[b]);
-    J.moments[3 + t] = s;
+    double acc = part[t][0];
+    for (int l = 1; l < kCovLanes; l++) acc += part[t][l];
+    J.moments[3 + t] = acc; // xx xy xz yy yz zz
   }
 }
 __global__ void sc_clear_kernel(const JobDev *jobs, int nbins, double lidar_range) {
@@ -504,7 +536,7 @@ int loop_enqueue(dsm_context *ctx, int n_jobs, const dsm_loop_job *jobs, double 
   if (P.any_sc) {
     // ---- ScanContext::generate: PCA moments, the eigen-decomposition (:41-47) and tfm_pca_rig (:55-64), then binning, ring key and
     // signature: nothing leaves the device between the halves (jobs without points are skipped by every kernel and reported at the end)
-    hipLaunchKernelGGL(sc_moments_kernel, dim3(n_jobs), dim3(64), 0, st, dj);
+    hipLaunchKernelGGL(sc_moments_kernel, dim3(n_jobs), dim3(kLdThreads), 0, st, dj);
     hipLaunchKernelGGL(sc_pca_kernel, dim3((n_jobs + 63) / 64), dim3(64), 0, st, dj, n_jobs);
     hipLaunchKernelGGL(sc_clear_kernel, dim3((P.nbins + kLdThreads - 1) / kLdThreads, n_jobs), dim3(kLdThreads), 0, st, dj, P.nbins, lidar_range);
     hipLaunchKernelGGL(sc_bin_kernel, dim3(gx_pts, n_jobs), dim3(kLdThreads), 0, st, dj, lidar_range, num_s, num_r);

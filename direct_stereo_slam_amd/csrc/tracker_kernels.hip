@@ -1231,18 +1231,22 @@ __device__ __forceinline__ void store16_coherent(void *p, const uint4 &v) {
 // workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
 // g, g+19, g+38, ...: every load is a 16-byte read and up to kRedBatch of them are in flight per
 // thread.  `P` may point to global memory (lm_kernel) or LDS (coarse_kernel): same order, same sums.
-__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, RedBuf &sh) {
+// P2 != nullptr: a second evaluation's partials (the speculative candidate's, `sh2`) are reduced beside the first's -- same order, same
+// sums each, their loads requested TOGETHER (two reductions one after the other were two memory round trips in front of every LM step of
+// the small levels; shader-clock stamps: profiles/r06_tick_stamps.json).
+__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, RedBuf &sh, const float *P2 = nullptr, RedBuf *sh2 = nullptr) {
   constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
   const int q = tid % kQuads, g = tid / kQuads;
   if (g < kGroups) {
-    double sd[4] = {0, 0, 0, 0};
-    long long si[4] = {0, 0, 0, 0};
+    double sd[4] = {0, 0, 0, 0}, td[4] = {0, 0, 0, 0};
+    long long si[4] = {0, 0, 0, 0}, ti[4] = {0, 0, 0, 0};
     for (int c0 = g; c0 < nch; c0 += kGroups * kRedBatch) {
-      fvec4 v[kRedBatch];
+      fvec4 v[kRedBatch], w[kRedBatch];
 #pragma unroll
       for (int j = 0; j < kRedBatch; j++) {
         const int cc = c0 + j * kGroups;
         v[j] = cc < nch ? load_partial4(P + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
+        if (P2) w[j] = cc < nch ? load_partial4(P2 + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < kRedBatch; j++) {
@@ -1250,14 +1254,25 @@ __device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, 
         si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
             si[3] += __float_as_int(v[j].w);
       }
+      if (P2) {
+#pragma unroll
+        for (int j = 0; j < kRedBatch; j++) {
+          td[0] += (double)w[j].x, td[1] += (double)w[j].y, td[2] += (double)w[j].z, td[3] += (double)w[j].w;
+          ti[0] += __float_as_int(w[j].x), ti[1] += __float_as_int(w[j].y), ti[2] += __float_as_int(w[j].z),
+              ti[3] += __float_as_int(w[j].w);
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int slot = 4 * q + e;
-      if (slot < kSlotNTerms)
+      if (slot < kSlotNTerms) {
         sh.psum[g][slot] = sd[e];
-      else
+        if (P2) sh2->psum[g][slot] = td[e];
+      } else {
         sh.pisum[g][slot - kSlotNTerms] = si[e];
+        if (P2) sh2->pisum[g][slot - kSlotNTerms] = ti[e];
+      }
     }
   }
 }
@@ -1472,23 +1487,37 @@ __device__ __forceinline__ void lm_spec_wave1(int mode, const TrackerDev &T, LMS
 // back.  Shared by lm_kernel (LM_OP_STEP) and by the last-arriving workgroup of a fused eval kernel.
 // All threads of the workgroup must call it; S must be at this level (status RUNNING, lvl, mode).
 // sp != nullptr: speculative candidates (their partials sit spec_off floats behind the main ones).
+// What a caller already holds when it calls lm_step_block (round 6: the step's memory phase was three to four DEPENDENT round trips
+// -- tracker pointer -> descriptor, point count of the pending evaluation -> partials, main then speculative partials -- 11 k of the
+// 37 k cycles an LM workgroup of the tick engine lives, shader-clock stamps in profiles/r06_tick_stamps.json).  With the point
+// count known up front the descriptor, the state block and every partial are requested together: one round trip.
+struct LmPre {
+  int n_lvl, ppt_lvl; // S.in.n / S.in.ppt of the pending evaluation
+  bool have_sv;       // sv holds this thread's 16-byte block of the state (already loaded with the caller's own first reads)
+  uint4 sv;
+};
+constexpr int kLmS16 = sizeof(LMState) / 16, kLmT16 = sizeof(TrackerDev) / 16;
 template <bool COH = false>
 __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const TrackerDev *Tg, LMState &S,
                                               const float *partials_prob, LmShared &sh, int tid, int *status_out,
-                                              LmSpecShared *sp = nullptr, int spec_off = 0) {
-  constexpr int kS16 = sizeof(LMState) / 16, kT16 = sizeof(TrackerDev) / 16;
+                                              LmSpecShared *sp = nullptr, int spec_off = 0, const LmPre *pre = nullptr) {
+  constexpr int kS16 = kLmS16, kT16 = kLmT16;
   static_assert(kS16 <= kThreads && kT16 <= kThreads, "one 16-byte block per thread");
   // one round trip: state block, tracker descriptor and the chunk partials together
   uint4 sv = {0, 0, 0, 0}, tv = {0, 0, 0, 0};
-  if (tid < kS16) sv = COH ? load16_coherent((const uint4 *)&S + tid) : ((const uint4 *)&S)[tid];
+  if (pre && pre->have_sv)
+    sv = pre->sv;
+  else if (tid < kS16)
+    sv = COH ? load16_coherent((const uint4 *)&S + tid) : ((const uint4 *)&S)[tid];
   if (tid < kT16) tv = ((const uint4 *)Tg)[tid];
   // the pending evaluation was built for this level
-  const int n_lvl = COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
-  const int ppt_lvl = COH ? __hip_atomic_load(&S.in.ppt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.ppt;
-  reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red);
+  const int n_lvl = pre ? pre->n_lvl : COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
+  const int ppt_lvl = pre ? pre->ppt_lvl : COH ? __hip_atomic_load(&S.in.ppt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.ppt;
   if (sp) { // (garbage where no speculative candidate was evaluated: never looked at then)
-    reduce_partials_groups(partials_prob + spec_off, chunks_of(n_lvl, ppt_lvl), tid, sp->red);
+    reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red, partials_prob + spec_off, &sp->red);
     if (tid == 0) sp->cmd = 0, sp->done = 0;
+  } else {
+    reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red);
   }
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
   if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
@@ -1548,6 +1577,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   const DSM_GLOBAL LMState &S = ((const DSM_GLOBAL LMState *)states)[prob];
   const DSM_GLOBAL EvalIn &in = cand ? S.spec_in : S.in;
   const int s_status = S.status, s_lvl = S.lvl, s_kind = S.is_scale, s_spec_valid = S.spec_valid;
+  const TrackerDev *trk_ptr = FUSED ? ((const TrackerDev *const DSM_GLOBAL *)trackers)[prob] : nullptr; // (the fused step's descriptor: asked for with the state)
+  // the MAIN candidate's point count: what the fused step reduces over (a speculative row's own inputs, S.spec_in, are stale where no
+  // candidate was staged -- another level's count)
+  const int main_n = FUSED ? S.in.n : 0, main_ppt = FUSED ? S.in.ppt : 0;
   EvalConsts c;
   c.pts = in.pts, c.img = in.img, c.n = in.n, c.w = in.w, c.h = in.h, c.ppt = in.ppt;
   c.fx = in.fx, c.fy = in.fy, c.cx = in.cx, c.cy = in.cy, c.huber = in.huber;
@@ -1559,6 +1592,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
   eval_consts_defaults(c);
   asm volatile("" ::"s"(s_status), "s"(s_lvl), "s"(s_kind), "s"(s_spec_valid), "s"(c.pts), "s"(c.img), "s"(c.n), "s"(c.w), "s"(c.h),
                "s"(c.residual_only));
+  if (FUSED) asm volatile("" ::"s"(trk_ptr), "s"(main_n), "s"(main_ppt));
   asm volatile("" ::"s"(c.fx), "s"(c.fy), "s"(c.cx), "s"(c.cy), "s"(c.huber), "s"(c.t[0]), "s"(c.t[1]), "s"(c.t[2]), "s"(c.aff0),
                "s"(c.aff1), "s"(c.b0), "s"(c.scale), "s"(c.cutoff), "s"(c.max_energy));
   asm volatile("" ::"s"(c.M[0]), "s"(c.M[1]), "s"(c.M[2]), "s"(c.M[3]), "s"(c.M[4]), "s"(c.M[5]), "s"(c.M[6]), "s"(c.M[7]), "s"(c.M[8]));
@@ -1609,8 +1643,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(ROSEL 
     xwg_acquire(); // the other workgroups' partials were announced by their tickets
     __shared__ LmShared sh;
     __shared__ LmSpecShared sps;
-    lm_step_block(MODE, lvl, prob, trackers[prob], const_cast<LMState &>(states[prob]), partials_prob, sh, threadIdx.x,
-                  status_out, spec_nprob > 0 ? &sps : nullptr, spec_off);
+    // (the pending evaluation's point count came with this workgroup's own inputs, the tracker pointer with them: the step asks for
+    // state, descriptor and partials in ONE round trip -- one frame in flight is a chain of these launches)
+    LmPre pre;
+    pre.n_lvl = main_n, pre.ppt_lvl = main_ppt, pre.have_sv = false;
+    lm_step_block(MODE, lvl, prob, trk_ptr, const_cast<LMState &>(states[prob]), partials_prob, sh, threadIdx.x,
+                  status_out, spec_nprob > 0 ? &sps : nullptr, spec_off, &pre);
   }
 }
 
@@ -1718,17 +1756,22 @@ __global__ __launch_bounds__(kLmThreads) void lm_kernel(int mode, int op, int lv
   }
 
   // ---- LM_OP_STEP / LM_OP_SINGLE_FINISH ----
-  const bool active = (S.status == ST_RUNNING && S.lvl == lvl && S.is_scale == mode);
+  // (one round trip: status, level, kind, the pending evaluation's point count, the tracker pointer and this thread's block of the state)
+  LmPre pre;
+  const int s_status = S.status, s_lvl = S.lvl, s_kind = S.is_scale;
+  pre.n_lvl = S.in.n, pre.ppt_lvl = S.in.ppt, pre.have_sv = true;
+  const TrackerDev *Tg = trackers[prob];
+  pre.sv = tid < kLmS16 ? ((const uint4 *)&S)[tid] : uint4{0, 0, 0, 0};
+  const bool active = (s_status == ST_RUNNING && s_lvl == lvl && s_kind == mode);
   if (!active) { // block-uniform
     if (tid == 0 && status_out) {
-      status_out[2 * prob] = S.status;
-      status_out[2 * prob + 1] = S.lvl;
+      status_out[2 * prob] = s_status;
+      status_out[2 * prob + 1] = s_lvl;
     }
     return;
   }
   if (op == LM_OP_STEP) {
-    lm_step_block(mode, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, status_out,
-                  spec ? &sps : nullptr, partial_stride >> 1);
+    lm_step_block(mode, lvl, prob, Tg, S, partials + (size_t)prob * partial_stride, sh, tid, status_out, spec ? &sps : nullptr, partial_stride >> 1, &pre);
     return;
   }
 
@@ -2319,13 +2362,18 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   LMState &S = states[prob];
   __shared__ LmShared sh;
   __shared__ LmSpecShared sps;
-  if (!(S.status == ST_RUNNING && S.is_scale == MODE)) return; // a free slot (refilled by the next advance's admit launch)
-  const int lvl = S.lvl;
+  // ONE round trip for everything the step must know before it can ask for the partials: the slot's status and kind, the level and point
+  // count of the pending evaluation, the tracker pointer -- and this thread's block of the state itself
+  LmPre pre;
+  const int s_status = S.status, s_kind = S.is_scale, lvl = S.lvl;
+  pre.n_lvl = S.in.n, pre.ppt_lvl = S.in.ppt, pre.have_sv = true;
+  const TrackerDev *Tg = trackers[prob];
+  pre.sv = tid < kLmS16 ? ((const uint4 *)&S)[tid] : uint4{0, 0, 0, 0};
+  if (!(s_status == ST_RUNNING && s_kind == MODE)) return; // a free slot (refilled by the next advance's admit launch)
   // the speculative second candidate (dsm_params.speculate): on the small levels, as in the launch form (a tick's launch is
   // never bound by the doubled rows of a few small problems)
-  const bool spec_lvl = speculate >= 2 || (speculate == 1 && S.in.n <= 8192);
-  lm_step_block(MODE, lvl, prob, trackers[prob], S, partials + (size_t)prob * partial_stride, sh, tid, nullptr, spec_lvl ? &sps : nullptr,
-                partial_stride >> 1);
+  const bool spec_lvl = speculate >= 2 || (speculate == 1 && pre.n_lvl <= 8192);
+  lm_step_block(MODE, lvl, prob, Tg, S, partials + (size_t)prob * partial_stride, sh, tid, nullptr, spec_lvl ? &sps : nullptr, partial_stride >> 1, &pre);
   if (tid >= 64) return;
   const int lane = tid;
   if (sh.st.status == ST_RUNNING) {

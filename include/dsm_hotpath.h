@@ -121,9 +121,12 @@ typedef struct dsm_params {
                                          runs trackNewestCoarse / optimizeScale as written. */
   int chunk_geometry;                 /* Reduction geometry: which table gives a chunk's points per thread from the level's point count
                                          (a chunk = one workgroup's share of an evaluation = one partial).
-                                         0 (default) THROUGHPUT: 16 points per thread from 16 k points up, 8 / 4 / 2 from 4 k / 1 k / 512 --
+                                         0 (default) THROUGHPUT: 16 points per thread; a level of at most 4096 points is ONE chunk (the smallest
+                                           of 1 / 2 / 4 / 8 / 16 points per thread that holds it) --
                                            long chunks, their fixed cost (three dependent memory round trips before the first
                                            point, the 52-sum reduction after the last) amortised: many problems in flight.
+                                           (ABI version 3's table 0 -- 16 from 16 k points up, 8 / 4 / 2 from 4 k / 1 k / 512 -- gave the
+                                           small levels several short chunks; version 4's float sums there differ in their last bits.)
                                          1 LATENCY: 16 / 8 / 4 / 2 from 256 k / 64 k / 16 k / 4 k points, else 1 -- short chunks, more
                                            workgroups per evaluation, a single evaluation through sooner: ONE problem in flight
                                            (the replay adaptors set it).  Rounds 1-4 used this table for everything.

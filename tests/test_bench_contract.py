@@ -118,7 +118,12 @@ def test_bench_line_carries_every_key_of_the_contract(tmp_path):
     legs = line["config"]["legs"]
     assert legs["reference_five_level_S1"]["value"] > 0 and legs["fixed_schedule_1p3"]["cpu_value"] > 0
     assert all(k["bit_exact"] for k in legs["ringkey"]) and len(legs["ringkey"]) == 4
+    # round 6: SURVEY.md 8d's literal scene family and the PCIe-inclusive figure in the line; RPE beside the ATE (ratios within 1 %)
+    assert legs["plane"]["value"] > 0 and 0 < legs["plane"]["frac_whole_step"] < 1
+    assert legs["with_upload"]["value"] > 0 and legs["with_upload"]["host_MB_per_step"] > 0
     assert 0.99 <= line["cpu_baseline"]["ate_vs_cpu_ref"]["ate_ratio_gpu_over_cpu"] <= 1.01
+    rpe = line["cpu_baseline"]["rpe_vs_cpu_ref"]
+    assert 0.99 <= rpe["rpe_trans_ratio_gpu_over_cpu"] <= 1.01 and 0.99 <= rpe["rpe_rot_ratio_gpu_over_cpu"] <= 1.01
     # the side file holds the FULL object: the same headline numbers and every leg's own object
     d = json.load(open(detail))
     for k in CONTRACT_KEYS:

@@ -505,12 +505,12 @@ def test_call_order_errors(ctx):
         trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl)  # coarsestLvl >= pyrLevelsUsed (:457)
 
 
-@pytest.mark.parametrize("geometry,n_cut,expect", [(1, 65535, (256, 4, 64)), (0, 16383, (256, 8, 8))])
+@pytest.mark.parametrize("geometry,n_cut,expect", [(1, 65535, (256, 4, 64)), (0, 4095, (256, 16, 1))])
 def test_sparse_template_just_below_a_chunking_threshold(ctx, geometry, n_cut, expect):
-    """points-per-thread grows with n, so the chunk count is not monotone in n: under the latency table n = 65535 uses 4 points
-    per thread and 64 chunks although the level holds up to 113k points (8 per thread, 56 chunks); under the throughput table
-    n = 16383 uses 8 per thread and 8 chunks, n = 16384 16 per thread and 4.  The partial-sum workspace must be sized for the
-    worst n of either table, not for the largest."""
+    """points-per-thread grows with n, so under the latency table the chunk count is not monotone in n: n = 65535 uses 4 points
+    per thread and 64 chunks although the level holds up to 113k points (8 per thread, 56 chunks).  The partial-sum workspace must be
+    sized for the worst n of either table, not for the largest.  Under the throughput table a level of at most 4096 points is ONE chunk
+    (round 6): n = 4095 is one chunk of 16 points per thread, n = 4097 two."""
     from direct_stereo_slam_amd.tracker import default_params
 
     sc = make_scene("medium", seed=50)
@@ -522,7 +522,10 @@ def test_sparse_template_just_below_a_chunking_threshold(ctx, geometry, n_cut, e
     prm.chunk_geometry = geometry
     orc, trk = oracle_tracker(sc), hip_tracker(ctx, sc, prm)
     assert trk.reduction_geometry(0, n_cut) == expect
-    assert trk.reduction_geometry(0, n_cut + 1)[2] < expect[2]
+    if geometry == 1:
+        assert trk.reduction_geometry(0, n_cut + 1)[2] < expect[2]
+    else:  # the metric's small levels: 280 / 1480 / 6688 points (levels 5 / 4 / 3 of 1248 x 384)
+        assert [trk.reduction_geometry(0, n)[1:] for n in (280, 1480, 6688, 4096, 4097)] == [(2, 1), (8, 1), (16, 2), (16, 1), (16, 2)]
     assert_eval_pose_equal(orc, trk, 0, sc.gt_pose, sc.gt_aff, 20.0)
     good_o, pose_o, _, _, _ = orc.track(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
     good_g, pose_g, _, _ = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)

@@ -193,7 +193,7 @@ def _oracle_results(frames, kf_every):
     return out
 
 
-def _stream_vs_oracle(ctx, frames, track_slots, scale_slots, kf_every, waves, max_route_flips):
+def _stream_vs_oracle(ctx, frames, track_slots, scale_slots, kf_every, waves, max_route_flips, engine=1):
     """frames through the tick engine as bench.py drives it (three stream groups, the stream's own tick sizing, pipelined
     advances, a pool smaller than the job, submissions in waves) against orc.track / orc.optimize_scale frame by frame
     (TrackerAndScaler.cpp:451-638, 854-964): flags equal, per-level evaluation counts equal, poses and scales to 1e-4.  A frame
@@ -207,7 +207,7 @@ def _stream_vs_oracle(ctx, frames, track_slots, scale_slots, kf_every, waves, ma
     ctx.set_streams(3)
     try:
         trks = [hip_tracker(ctx, sc) for sc in frames]
-        st = Stream(ctx, track_slots, scale_slots, 1, 0)
+        st = Stream(ctx, track_slots, scale_slots, engine, 0)
         owner, got = {}, []
         per = (len(frames) + waves - 1) // waves
         for wv in range(waves):
@@ -315,19 +315,50 @@ def test_tick_engine_relief_golden_fixture(ctx):
         trk.upload_image(0, g["new_u8"][i], 1.0)  # camera bytes in, device makeImages
         trk.upload_image(1, g["right_u8"], 1.0)
         trks.append(trk)
-    st = Stream(ctx, 2, 1, 1, 0)
-    tk = st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
-    ts = st.submit_scale(trks[:1], np.ones(1, np.float32), nl - 1)
-    st.drain()
-    got = {r.ticket: r for r in st.results()}
-    st.close()
-    for i in range(n):
-        r = got[tk[i]]
-        assert bool(r.good) == bool(g["track_good"][i])
-        assert list(r.evals)[:nl] == list(g["track_evals"][i][:nl])
-        np.testing.assert_allclose(np.array(r.pose), g["track_pose"][i], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(np.array(r.aff), g["track_aff"][i], rtol=1e-3, atol=1e-3)
-        np.testing.assert_allclose(np.array(r.last_residuals)[:nl], g["track_last"][i][:nl], rtol=1e-4)
-    q = got[ts[0]]
-    assert abs(q.scale - float(g["scale_out"])) < 1e-4 and abs(q.err - float(g["scale_err"])) < 5e-4 * float(g["scale_err"])
-    assert list(q.evals)[:nl] == list(g["scale_evals"][:nl])
+    for engine in (1,):
+        st = Stream(ctx, 2, 1, engine, 0)
+        tk = st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+        ts = st.submit_scale(trks[:1], np.ones(1, np.float32), nl - 1)
+        st.drain()
+        got = {r.ticket: r for r in st.results()}
+        st.close()
+        for i in range(n):
+            r = got[tk[i]]
+            assert bool(r.good) == bool(g["track_good"][i])
+            assert list(r.evals)[:nl] == list(g["track_evals"][i][:nl])
+            np.testing.assert_allclose(np.array(r.pose), g["track_pose"][i], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(np.array(r.aff), g["track_aff"][i], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(np.array(r.last_residuals)[:nl], g["track_last"][i][:nl], rtol=1e-4)
+        q = got[ts[0]]
+        assert abs(q.scale - float(g["scale_out"])) < 1e-4 and abs(q.err - float(g["scale_err"])) < 5e-4 * float(g["scale_err"])
+        assert list(q.evals)[:nl] == list(g["scale_evals"][:nl])
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+def test_stream_engines_with_an_empty_level_and_a_single_point_level(ctx, engine):
+    """a level without template points still takes its LM step (TrackerAndScaler.cpp:474-505 on n = 0: the level ends at once, its
+    residual is 0 / 0): both engines must return the batch call's bits, and those the oracle's NaN at the empty level.  (Round 6: the fused
+    evaluate-and-step launch of the batch form reduced over a stale point count there -- the speculative row's -- until this test.)"""
+    from direct_stereo_slam_amd.tracker import Stream
+
+    scs = [make_scene("small", seed=820 + i) for i in range(6)]
+    for i, sc in enumerate(scs):
+        for a in sc.tpl:
+            a[1] = a[1][:0 if i % 2 == 0 else 1].copy()  # level 1: empty / one point
+            if i == 3:
+                a[2] = a[2][:0].copy()  # the coarsest (starting) level empty as well
+    nl = scs[0].nl
+    trks = [hip_tracker(ctx, sc) for sc in scs]
+    n = len(trks)
+    scales = np.ones(n, np.float32)
+    ref = _batch_reference(ctx, trks, nl, scales)
+    res, _, _ = _stream_run(ctx, trks, nl, scales.copy(), 4, 3, None, None, 2, engine=engine, ticks=0)
+    _check(res, ref, n, nl)
+    for i, sc in enumerate(scs):  # and the oracle, the single fused-launch call included
+        good_o, pose_o, aff_o, last_o, _ = oracle_tracker(sc).track(S.IDENTITY_POSE, [0, 0], nl - 1)
+        good_g, pose_g, aff_g, last_g = trks[i].trackNewestCoarse(S.IDENTITY_POSE, [0, 0], nl - 1)
+        for last in (ref[3][i], np.asarray(last_g)):
+            assert np.array_equal(np.isnan(last[:nl]), np.isnan(last_o[:nl])), (i, last, last_o)
+            np.testing.assert_allclose(last[:nl], last_o[:nl], rtol=1e-3, equal_nan=True)
+        assert bool(ref[0][i]) == good_o == bool(good_g)
+        np.testing.assert_allclose(ref[1][i], pose_o, atol=2e-4)
