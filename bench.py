@@ -1318,8 +1318,8 @@ def compact_line(res, detail_path):
     out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                "vs_baseline", "dtype", "data")}
     out["value"], out["ms_per_step"] = _r(res["value"], 5), _r(res["ms_per_step"], 5)
-    cfg = _pick(c, ("workload", "name", "w", "h", "levels", "n0", "replicas", "inputs", "frames_in_flight_per_gpu", "streams", "scene_family",
-                    "distinct_frames", "initial_guess", "fixed_schedule", "evals_per_frame_by_level", "algorithmic_MB_per_frame",
+    # (size, levels, scene family, distinct frames and the initial guess are spelt out in `workload`; everything else is in the detail file)
+    cfg = _pick(c, ("workload", "n0", "inputs", "frames_in_flight_per_gpu", "fixed_schedule", "evals_per_frame_by_level", "algorithmic_MB_per_frame",
                     "whole_step_GBps", "all_tracked", "frames_with_translation_error_above_1cm"), 3)
     st = c.get("stream")
     if isinstance(st, dict):
@@ -1356,18 +1356,20 @@ def compact_line(res, detail_path):
                 lr[name] = {"error": str((d or {}).get("error", d))[:120]} if isinstance(d, dict) else str(d)[:120]
                 continue
             g, cp, vs = d["gpu"]["stages_mean_ms"], d["cpu"]["stages_mean_ms"], d.get("gpu_vs_cpu", {})
-            lr[name] = {"ms_per_frame_gpu": _r(g["per_frame"]["mean_ms"]), "ms_per_frame_cpu": _r(cp["per_frame"]["mean_ms"]),
-                        "trackNewCoarse_ms_gpu": _r(g["trackNewCoarse"]["mean_ms"]),
-                        **_pick(vs, ("ate_ratio_gpu_over_cpu", "rpe_trans_ratio_gpu_over_cpu", "rpe_rot_ratio_gpu_over_cpu", "loop_queries",
-                                     "queries_with_identical_candidates"), 4)}
+            # (ratios: GPU path over CPU path; same_candidates: loop queries whose candidate lists are identical on both paths)
+            lr[name] = {"ms_per_frame_gpu": _r(g["per_frame"]["mean_ms"], 4), "ms_per_frame_cpu": _r(cp["per_frame"]["mean_ms"], 4),
+                        "trackNewCoarse_ms_gpu": _r(g["trackNewCoarse"]["mean_ms"], 4), "ate_ratio": _r(vs.get("ate_ratio_gpu_over_cpu"), 5),
+                        "rpe_trans_ratio": _r(vs.get("rpe_trans_ratio_gpu_over_cpu"), 5), "rpe_rot_ratio": _r(vs.get("rpe_rot_ratio_gpu_over_cpu"), 5),
+                        "loop_queries": vs.get("loop_queries"), "same_candidates": vs.get("queries_with_identical_candidates")}
             cc = d.get("concurrent")
             if isinstance(cc, dict):
-                lr[name]["concurrent"] = _pick(cc, ("sequences", "frames_per_s", "max_abs_trajectory_diff_vs_the_one_sequence_run_m"))
+                lr[name]["concurrent"] = {"sequences": cc.get("sequences"), "frames_per_s": _r(cc.get("frames_per_s"), 5),
+                                          "max_diff_vs_one_sequence_m": cc.get("max_abs_trajectory_diff_vs_the_one_sequence_run_m")}
         legs["replay"] = lr
     rk = c.get("ringkey")
     if isinstance(rk, dict):
         legs["ringkey"] = {"error": rk["error"][:120]} if "error" in rk else [
-            {"N": k["N"], "Q": k["Q"], "us": _r(k["us_per_call"], 2), "bound": k["roofline"]["bound"], "frac": _r(k["roofline"]["frac"], 2),
+            {"N": k["N"], "Q": k["Q"], "us": _r(k["us_per_call"], 4), "bound": k["roofline"]["bound"], "frac": _r(k["roofline"]["frac"], 3),
              "bit_exact": k["matches_oracle_bit_exact"]} for k in rk.get("cases", [])]
     lc = c.get("loop_chain")
     if isinstance(lc, dict):
@@ -1393,8 +1395,8 @@ def compact_line(res, detail_path):
     if cb is None:
         out["cpu_baseline"] = None
     else:
-        o = _pick(cb, ("value", "unit", "cores", "kind", "form", "cpu_model", "physical_cores"))
-        o["sample"] = str(cb.get("sample", "")).split(", oracle/")[0][:160] + "; " + str(cb.get("sample", "")).rsplit(", ", 1)[-1][:40]
+        o = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "physical_cores"))
+        o["sample"] = str(cb.get("sample", "")).split(", same initial")[0][:110] + "; " + str(cb.get("sample", "")).rsplit(", ", 1)[-1][:40]
         ate, lm, ac = cb.get("ate_vs_cpu_ref"), cb.get("lm_routes_vs_cpu_ref"), cb.get("all_cores")
         if isinstance(ate, dict):
             o["ate_vs_cpu_ref"] = _pick(ate, ("frames", "ate_gpu_m", "ate_cpu_m", "ate_ratio_gpu_over_cpu",
