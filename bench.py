@@ -1319,7 +1319,7 @@ def compact_line(res, detail_path):
                                "vs_baseline", "dtype", "data")}
     out["value"], out["ms_per_step"] = _r(res["value"], 5), _r(res["ms_per_step"], 5)
     # (size, levels, scene family, distinct frames and the initial guess are spelt out in `workload`; everything else is in the detail file)
-    cfg = _pick(c, ("workload", "n0", "inputs", "frames_in_flight_per_gpu", "fixed_schedule", "evals_per_frame_by_level", "algorithmic_MB_per_frame",
+    cfg = _pick(c, ("workload", "n0", "replicas", "inputs", "frames_in_flight_per_gpu", "fixed_schedule", "evals_per_frame_by_level", "algorithmic_MB_per_frame",
                     "whole_step_GBps", "all_tracked", "frames_with_translation_error_above_1cm"), 3)
     st = c.get("stream")
     if isinstance(st, dict):

@@ -254,9 +254,11 @@ __device__ __forceinline__ void eval_consts_defaults(EvalConsts &c) { c.lds_img 
 // rows and store the partial -- the same additions in the same order by another wave; the other waves leave at once instead
 // of waiting for the slowest wave's gathers (measured: a mid-level workgroup spent a third of its life between the end of
 // its first wave's loop and the partial store).
-// DEEP: the two-points-per-trip loop with fixed register roles (level 0 only: inside the tick engine's kernel, which runs at four
-// waves per SIMD whatever the level, it measured no faster than the one-point loop on the 16-point chunks of the other levels,
-// profiles/r05_ab_flow_first_deep16_b1.log)
+// DEEP: the two-points-per-trip loop with fixed register roles: level 0 everywhere, and every level inside the tick engine's kernel,
+// which runs at four waves per SIMD whatever the level.  (Round 5 measured it there on the 16-point chunks of the other levels and saw
+// no change, profiles/r05_ab_flow_first_deep16_b1.log; round 6's shader-clock stamps found the one-point loop's items of levels 1-2
+// resident 13 % longer than level 0's for the same 4096 points -- 34 % for the residual-only ones, which have two gathers and little
+// arithmetic between them -- and the same A/B now gives + 1.3 % frames/s, the kernel 0.61 -> 0.63 of peak: profiles/r06_ab_deep_all_levels.log)
 // VC: which wave-uniform constants the loop keeps in VGPRs (an SGPR source costs an instruction 4.65 instead of 2.5 cycles): 0 none
 // (the 96-register kernels of five waves per SIMD), 1 the warp's twelve (the two-point loop at four waves per SIMD: 128 registers hold
 // these and no more), 2 the camera, gradient-scale and brightness constants as well (the one-point loop inside a kernel that is
@@ -2348,7 +2350,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     if (lvl == 0)
       eval_chunk<MODE, true>(c, chunk, threadIdx.x, true, red, out);
     else
-      eval_chunk<MODE, false, false, 2>(c, chunk, threadIdx.x, true, red, out); // (this kernel is allocated 128 registers by its level-0 loop)
+      eval_chunk<MODE, false, true, 1>(c, chunk, threadIdx.x, true, red, out); // (the two-point loop here too: this kernel is allocated 128 registers by its level-0 loop anyway)
     __syncthreads(); // red[] is reused by the next item (the arrival-ticket form of eval_kernel measured the same here: profiles/r05_ab_tick_arrival_ticket.log)
   }
 }

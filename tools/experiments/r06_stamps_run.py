@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["DSM_HOTPATH_LIB"] = os.path.join(ROOT, "scratch", "lib_stamps", "libdsm_hotpath.so")
+os.environ.setdefault("DSM_HOTPATH_LIB", os.path.join(ROOT, "scratch", "lib_stamps", "libdsm_hotpath.so"))
 import bench  # noqa: E402
 
 sys.argv = ["bench.py", "--quick"] + sys.argv[1:]
