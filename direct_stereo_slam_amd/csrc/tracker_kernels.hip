@@ -1233,11 +1233,44 @@ __device__ __forceinline__ void store16_coherent(void *p, const uint4 &v) {
 // workgroup.  Thread (g, q) sums the slot quad q (one float4 = 4 of the 52 slots) over chunks
 // g, g+19, g+38, ...: every load is a 16-byte read and up to kRedBatch of them are in flight per
 // thread.  `P` may point to global memory (lm_kernel) or LDS (coarse_kernel): same order, same sums.
-// P2 != nullptr: a second evaluation's partials (the speculative candidate's, `sh2`) are reduced beside the first's -- same order, same
-// sums each, their loads requested TOGETHER (two reductions one after the other were two memory round trips in front of every LM step of
-// the small levels; shader-clock stamps: profiles/r06_tick_stamps.json).
-__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, RedBuf &sh, const float *P2 = nullptr, RedBuf *sh2 = nullptr) {
+// reduce_partials_groups2: TWO evaluations' partials -- the main and the speculative candidate's -- reduced side by side, each in
+// exactly the order above, their loads requested TOGETHER (two reductions one after the other were two memory round trips in front of
+// every LM step of the small levels; shader-clock stamps: profiles/r06_tick_stamps.json).  A speculative candidate exists on levels of at
+// most 8192 points only, i.e. at most 32 chunks = two per group: a batch of two is the whole job, and the registers stay few -- an LM
+// kernel must fit the hole ONE retiring evaluation wave leaves on a SIMD (128 VGPRs): with 138 the scale segment's LM launches, which
+// run beside the pose evaluations, took 68 us instead of 12 (profiles/r06_lm_vgpr_regression.txt).
+__device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, int tid, RedBuf &sh) {
   constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 8;
+  const int q = tid % kQuads, g = tid / kQuads;
+  if (g < kGroups) {
+    double sd[4] = {0, 0, 0, 0};
+    long long si[4] = {0, 0, 0, 0};
+    for (int c0 = g; c0 < nch; c0 += kGroups * kRedBatch) {
+      fvec4 v[kRedBatch];
+#pragma unroll
+      for (int j = 0; j < kRedBatch; j++) {
+        const int cc = c0 + j * kGroups;
+        v[j] = cc < nch ? load_partial4(P + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < kRedBatch; j++) {
+        sd[0] += (double)v[j].x, sd[1] += (double)v[j].y, sd[2] += (double)v[j].z, sd[3] += (double)v[j].w;
+        si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
+            si[3] += __float_as_int(v[j].w);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int slot = 4 * q + e;
+      if (slot < kSlotNTerms)
+        sh.psum[g][slot] = sd[e];
+      else
+        sh.pisum[g][slot - kSlotNTerms] = si[e];
+    }
+  }
+}
+__device__ __forceinline__ void reduce_partials_groups2(const float *P, const float *P2, int nch, int tid, RedBuf &sh, RedBuf &sh2) {
+  constexpr int kGroups = 19, kQuads = kNumSlots / 4, kRedBatch = 2;
   const int q = tid % kQuads, g = tid / kQuads;
   if (g < kGroups) {
     double sd[4] = {0, 0, 0, 0}, td[4] = {0, 0, 0, 0};
@@ -1248,33 +1281,25 @@ __device__ __forceinline__ void reduce_partials_groups(const float *P, int nch, 
       for (int j = 0; j < kRedBatch; j++) {
         const int cc = c0 + j * kGroups;
         v[j] = cc < nch ? load_partial4(P + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
-        if (P2) w[j] = cc < nch ? load_partial4(P2 + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
+        w[j] = cc < nch ? load_partial4(P2 + ((size_t)cc * (kPartialStride / 4) + q) * 4) : fvec4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < kRedBatch; j++) {
         sd[0] += (double)v[j].x, sd[1] += (double)v[j].y, sd[2] += (double)v[j].z, sd[3] += (double)v[j].w;
         si[0] += __float_as_int(v[j].x), si[1] += __float_as_int(v[j].y), si[2] += __float_as_int(v[j].z),
             si[3] += __float_as_int(v[j].w);
-      }
-      if (P2) {
-#pragma unroll
-        for (int j = 0; j < kRedBatch; j++) {
-          td[0] += (double)w[j].x, td[1] += (double)w[j].y, td[2] += (double)w[j].z, td[3] += (double)w[j].w;
-          ti[0] += __float_as_int(w[j].x), ti[1] += __float_as_int(w[j].y), ti[2] += __float_as_int(w[j].z),
-              ti[3] += __float_as_int(w[j].w);
-        }
+        td[0] += (double)w[j].x, td[1] += (double)w[j].y, td[2] += (double)w[j].z, td[3] += (double)w[j].w;
+        ti[0] += __float_as_int(w[j].x), ti[1] += __float_as_int(w[j].y), ti[2] += __float_as_int(w[j].z),
+            ti[3] += __float_as_int(w[j].w);
       }
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int slot = 4 * q + e;
-      if (slot < kSlotNTerms) {
-        sh.psum[g][slot] = sd[e];
-        if (P2) sh2->psum[g][slot] = td[e];
-      } else {
-        sh.pisum[g][slot - kSlotNTerms] = si[e];
-        if (P2) sh2->pisum[g][slot - kSlotNTerms] = ti[e];
-      }
+      if (slot < kSlotNTerms)
+        sh.psum[g][slot] = sd[e], sh2.psum[g][slot] = td[e];
+      else
+        sh.pisum[g][slot - kSlotNTerms] = si[e], sh2.pisum[g][slot - kSlotNTerms] = ti[e];
     }
   }
 }
@@ -1516,7 +1541,7 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   const int n_lvl = pre ? pre->n_lvl : COH ? __hip_atomic_load(&S.in.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.n;
   const int ppt_lvl = pre ? pre->ppt_lvl : COH ? __hip_atomic_load(&S.in.ppt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.ppt;
   if (sp) { // (garbage where no speculative candidate was evaluated: never looked at then)
-    reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red, partials_prob + spec_off, &sp->red);
+    reduce_partials_groups2(partials_prob, partials_prob + spec_off, chunks_of(n_lvl, ppt_lvl), tid, sh.red, sp->red);
     if (tid == 0) sp->cmd = 0, sp->done = 0;
   } else {
     reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red);
