@@ -130,6 +130,7 @@ def _parse():
     ap.add_argument("--no-second-leg", action="store_true", help="skip the short reference-faithful five-level (S1) leg reported in config.reference_five_level")
     ap.add_argument("--second-leg-steps", type=int, default=10, help="timed steps of the fixed-schedule and five-level legs (streamed: ramp-up and drain are inside, so a handful of steps understates the rate)")
     ap.add_argument("--quick", action="store_true", help="the headline leg alone: --no-cpu --no-fixed-leg --no-second-leg --no-plane-leg --no-upload-leg --no-replay-leg --no-ringkey-leg (A/B runs, profiles)")
+    ap.add_argument("--upload-stream-ticks", type=int, default=0, help="ticks per advance of the streamed hand-over leg (0: the library's own choice)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the PCIe-inclusive leg of the default line (config.with_upload)")
     ap.add_argument("--no-plane-leg", action="store_true", help="skip the short leg on SURVEY.md 8d's literal scene family (config.plane_family)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-core leg of the CPU baseline (one share of frames per physical core, forked workers)")
@@ -519,6 +520,123 @@ class StreamRunner:
 
     def close(self):
         self.st.close()
+
+
+class SequenceUploadRunner:
+    """The streamed form WITH the hand-over inside: every tracker is one SEQUENCE with ONE frame in flight, as a
+    node runs it (FrontEnd.cpp:585-686: the next image is taken once the previous frame's pose is back).  Per step: the results of the
+    earlier advances are collected; for every sequence whose frame (and, on the keyframe sequences, scale optimisation) has retired, the
+    NEXT frame -- camera bytes in page-locked buffers, handed over asynchronously into the back buffers while the previous frame was being
+    tracked (dsm_upload_images_async: copies + device pyramids on a stream of their own) -- is swapped in (dsm_frames_advance), the frame
+    after it starts travelling, and the new problems are submitted; then one advance.  A sequence's images are only ever replaced after its
+    own problem has retired: no in-flight problem reads a buffer that is being written."""
+
+    def __init__(self, args, ctx, wl, kf_idx):
+        from direct_stereo_slam_amd.tracker import Stream
+
+        self.ctx, self.wl = ctx, wl
+        self.S = len(wl["trackers"])
+        self.is_kf = np.zeros(self.S, bool)
+        self.is_kf[kf_idx] = True
+        self.st = Stream(ctx, self.S, max(1, int(self.is_kf.sum())), 1, args.stream_ticks)
+        self.owner, self.outstanding = {}, np.zeros(self.S, np.int32)
+        self.ready = list(range(self.S))
+        self.primed = False
+        self.frames_done = 0
+        self.bytes_handed = 0
+        self.last = {}
+
+    def _hand_over(self, seqs, asynchronous):
+        t, im = self.wl["trackers"], self.wl["images"]
+        kf = [i for i in seqs if self.is_kf[i]]
+        trks = [t[i] for i in seqs] + [t[i] for i in kf]
+        imgs = [im[i][0] for i in seqs] + [im[i][1] for i in kf]
+        self.ctx.upload_images(trks, [2] * len(seqs) + [3] * len(kf), imgs, asynchronous=asynchronous)
+        self.bytes_handed += sum(x.nbytes for x in imgs)
+        return trks, kf
+
+    def step(self):
+        wl, t = self.wl, self.wl["trackers"]
+        for r in self.st.results():
+            i, kind = self.owner.pop(r.ticket)
+            self.outstanding[i] -= 1
+            if kind == 0:
+                self.frames_done += 1
+                self.last[i] = r
+            if self.outstanding[i] == 0:
+                self.ready.append(i)
+        if self.ready:
+            seqs = self.ready
+            self.ready = []
+            if not self.primed:  # the very first frames: nothing to overlap with
+                self._hand_over(seqs, False)
+                self.primed = True
+            else:
+                self.ctx.upload_wait()  # (the batch started one step ago: long done)
+            kf = [i for i in seqs if self.is_kf[i]]
+            trks = [t[i] for i in seqs] + [t[i] for i in kf]
+            self.ctx.advance_frames(trks, [0] * len(seqs) + [1] * len(kf))
+            self._hand_over(seqs, True)  # the frames after these travel while these are tracked
+            tk = self.st.submit_track([t[i] for i in seqs], wl["poses0"][seqs], np.zeros((len(seqs), 2)), wl["nl"] - 1)
+            ts = self.st.submit_scale([t[i] for i in kf], np.ones(len(kf), np.float32), wl["nl"] - 1) if kf else []
+            for i, k in zip(seqs, tk):
+                self.owner[k] = (i, 0)
+                self.outstanding[i] += 1
+            for i, k in zip(kf, ts):
+                self.owner[k] = (i, 1)
+                self.outstanding[i] += 1
+        self.st.advance()
+
+    def finish(self):
+        """everything in flight retires (no new frames)"""
+        self.st.drain()
+        for r in self.st.results():
+            i, kind = self.owner.pop(r.ticket)
+            self.outstanding[i] -= 1
+            if kind == 0:
+                self.frames_done += 1
+                self.last[i] = r
+            if self.outstanding[i] == 0:
+                self.ready.append(i)
+        self.ctx.upload_wait()
+
+    def close(self):
+        self.st.close()
+
+
+def measure_stream_with_upload(args, ctx, wl, steps, warmup, world):
+    """the streamed form with the hand-over inside: W warm-up steps, then K timed steps + the drain of what they started; value = frames
+    retired inside the timed region / its wall time (every sequence has one frame in flight: a step hands over as many frames as retired)"""
+    S = len(wl["trackers"])
+    run = SequenceUploadRunner(args, ctx, wl, list(range(0, S, args.kf_every)))
+    for _ in range(warmup + 2):
+        run.step()
+    ctx.sync()
+    barrier_sync(world)
+    import gc
+
+    gc.collect()
+    gc.disable()
+    f0, b0 = run.frames_done, run.bytes_handed
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.step()
+    ctx.sync()
+    run.st.sync()
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    gc.enable()
+    # (the timed region is a window of the steady state: the frames counted are those whose results the steps inside it collected)
+    frames, handed = run.frames_done - f0, run.bytes_handed - b0
+    run.finish()
+    poses = np.array([list(run.last[i].pose) for i in range(S)])
+    good = np.array([bool(run.last[i].good) for i in range(S)])
+    terr = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
+    run.close()
+    return {"value": frames * world / dt, "ms_per_step": 1e3 * dt / steps, "frames_in_timed_region": int(frames), "sequences": S, "steps": steps,
+            "host_bytes_per_step": handed / steps, "host_GBps": handed / dt / 1e9, "all_tracked": bool(good.all()),
+            "frames_with_translation_error_above_1cm": int((terr > 0.01).sum()),
+            "ticks_per_advance": args.stream_ticks or "auto"}
 
 
 def measure_stream(args, ctx, wl, steps, warmup, world):
@@ -1347,7 +1465,9 @@ def compact_line(res, detail_path):
     wu = c.get("with_upload")
     if isinstance(wu, dict):
         legs["with_upload"] = {"error": wu["error"][:120]} if "error" in wu else {
-            **_pick(wu, ("value", "ms_per_step")), "form": "batch, u8 pinned double-buffered", "host_MB_per_step": _r(wu.get("host_bytes_per_step", 0) / 1e6, 4)}
+            **_pick(wu, ("value", "ms_per_step")), "form": "batch, u8 pinned double-buffered", "host_MB_per_step": _r(wu.get("host_bytes_per_step", 0) / 1e6, 4),
+            **({"stream_form": ({"error": wu["stream_form"]["error"][:100]} if "error" in wu["stream_form"] else
+                                _pick(wu["stream_form"], ("value", "sequences", "host_GBps", "all_tracked"), 4))} if isinstance(wu.get("stream_form"), dict) else {})}
     rp = c.get("replay")
     if isinstance(rp, dict):
         lr = {}
@@ -1594,6 +1714,15 @@ def bench_tracking(args):
                                             "value": m5["value"], "unit": "stereo frames/s", "steps": args.second_leg_steps, "ms_per_step": m5["ms_per_step"],
                                             "host_bytes_per_step": int(px * (len(wl5["trackers"]) + len(range(0, len(wl5["trackers"]), args.kf_every)))),
                                             "roofline": m5["roofline"], **m5["detail"]}
+            try:  # the streamed form of the same: every tracker one sequence with one frame in flight (SequenceUploadRunner)
+                ctx.set_streams(args.streams)
+                a6 = argparse.Namespace(**vars(a5))
+                a6.stream, a6.stream_ticks = 1, args.upload_stream_ticks
+                res["config"]["with_upload"]["stream_form"] = {
+                    "what": "dsm_stream_* with the hand-over inside: one frame in flight per sequence, the next frame travels (page-locked mono8, device pyramids) "
+                            "while this one is tracked, swapped in once its predecessor has retired", **measure_stream_with_upload(a6, ctx, wl5, 3 * args.second_leg_steps, 2, world)}
+            except Exception as e:
+                res["config"]["with_upload"]["stream_form"] = {"error": repr(e)}
             del wl5
         except Exception as e:  # a reported extra, never a reason to lose the bench line
             res["config"]["with_upload"] = {"error": repr(e)}
