@@ -114,6 +114,7 @@ def _parse():
                          "individually; after the K-th step the pool is drained inside the timed region.  0: one synchronous dsm_track_and_scale_batch call per step")
     ap.add_argument("--stream-engine", type=int, default=1, choices=[0, 1], help="with --stream: 0 passes with carried stragglers, 1 ticks (one LM round per resident problem and tick, admission and retirement on the device)")
     ap.add_argument("--stream-ticks", type=int, default=0, help="with --stream-engine 1: ticks per advance (0: the library's default)")
+    ap.add_argument("--chain", type=int, default=-1, help="tick engine: LM rounds a one-chunk evaluation's workgroup may run inside one tick (dsm_stream_set_chain; 0 off, -1 the library's default)")
     ap.add_argument("--stream-quantile", default=None, help="with --stream: rounds per level of a pass = this quantile of what retired problems needed (library default 0.75)")
     ap.add_argument("--stream-rounds", default=None, help="with --stream: fixed rounds per level of a pass, comma separated from level 0 (e.g. 5,6,8,12,16,16)")
     ap.add_argument("--separate-calls", action="store_true", help="dsm_track_batch then dsm_optimize_scale_batch instead of the one dsm_track_and_scale_batch call per step")
@@ -450,6 +451,7 @@ class StreamRunner:
         self.B = len(wl["trackers"])
         self.kf = [wl["trackers"][i] for i in kf_idx]
         self.st = Stream(ctx, self.B, max(1, len(kf_idx)), args.stream_engine, args.stream_ticks)
+        self.st.set_chain(args.chain)
         if args.stream_quantile is not None:
             q = [float(x) for x in str(args.stream_quantile).split(",")]
             self.st.set_quantile(q[0] if len(q) == 1 else q)
@@ -539,6 +541,7 @@ class SequenceUploadRunner:
         self.is_kf = np.zeros(self.S, bool)
         self.is_kf[kf_idx] = True
         self.st = Stream(ctx, self.S, max(1, int(self.is_kf.sum())), 1, args.stream_ticks)
+        self.st.set_chain(args.chain)
         self.owner, self.outstanding = {}, np.zeros(self.S, np.int32)
         self.ready = list(range(self.S))
         self.primed = False

@@ -126,6 +126,7 @@ SYMBOLS = {
     "dsm_stream_counts": (C.c_int, [_vp, c_int_p, c_int_p, c_int_p]),
     "dsm_stream_set_quantile": (C.c_int, [_vp, C.c_int, C.c_double]),
     "dsm_stream_set_engine": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "dsm_stream_set_chain": (C.c_int, [_vp, C.c_int]),
     "dsm_stream_set_rounds": (C.c_int, [_vp, C.c_int, c_int_p]),
     "dsm_stream_get_stats": (C.c_int, [_vp, C.POINTER(Stats), C.POINTER(Stats)]),
     "dsm_stream_get_schedule": (C.c_int, [_vp, C.c_int, c_int_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -87,12 +87,14 @@ enum LMStatus { ST_IDLE = 0, ST_RUNNING = 1, ST_GOOD = 2, ST_ABORTED = 3, ST_BAD
 // optimizeScale :854-964), resident in device memory for the whole call.
 struct alignas(16) LMState {
   int status, lvl, phase, iteration;
-  int have_repeated, coarsest, is_scale /* problem kind: 0 pose, 1 scale, 2 loop-closure pose (3-D points) */, pad0;
+  int have_repeated, coarsest, is_scale /* problem kind: 0 pose, 1 scale, 2 loop-closure pose (3-D points) */;
+  int stepped; // tick engine: this tick's LM step(s) of the slot already ran inside the evaluation launch (a chain, tracker_kernels.hip);
+               // the tick's LM launch clears the flag and leaves the slot alone
   float lambda, level_cutoff_repeat;
   float inc_f;      // scale: last increment (for the signed break test :937)
   float scale_cur, scale_cand;
   float Hs, bs;     // scale: H, b
-  float pad1;
+  int n0;           // template points of level 0 (lm_start_problem): the tick engine's default chains semi-dense problems only
   double inc_norm;  // pose: |inc| of the proposal being evaluated (:588)
   double cur[7], aff_cur[2];
   double cand[7], aff_cand[2];
@@ -111,7 +113,8 @@ struct alignas(16) LMState {
   // if this one is rejected (same H, b and current pose; lambda four times larger, :583-585) is evaluated in the same launch.
   // A rejection -- half of all steps on the coarse levels -- then finds its successor's residual already computed and the LM
   // step consumes both: same evaluations, same decisions, same counts as the sequential loop, fewer launches in a row.
-  int spec_valid, spec_pad0;
+  int spec_valid;
+  int ticks; // tick engine: ticks this problem has lived (= LM rounds, less the rounds a chain ran inside one tick)
   float spec_scale_cand, spec_inc_f;
   double spec_inc_norm;
   double spec_cand[7], spec_aff_cand[2];

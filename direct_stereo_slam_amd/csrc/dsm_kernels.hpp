@@ -92,7 +92,9 @@ constexpr int kTickChunkBits = 12;
 struct TickSegCtl { // one per segment (stream group / companion): item counts of the two lists (tick parity)
   int count[2];
   int overflow; // an item list ran over (cannot happen by construction: checked by the host)
-  int pad[29];
+  int chain[2]; // chain entries of the two lists (problems whose pending evaluation is ONE chunk: see tick_eval_kernel), kept behind
+                // the list's `cap` item slots
+  int pad[27];
 };
 struct TickModeCtl { // one per problem kind, shared by the kind's segments; every counter is monotonic over the stream's life (64 bits:
                      // 2^31 problems are nine hours at the benchmarked rate)
@@ -109,7 +111,7 @@ struct TickPending { // a waiting problem (host -> device)
 };
 struct TickResult { // a retired problem (device -> host)
   unsigned long long ticket;
-  int status, pad;
+  int status, ticks; // ticks the problem lived (the stream sizes its advances by their mean)
   double cur[7], aff_cur[2];
   double last_residuals[DSM_MAX_LEVELS];
   double flow[3];
@@ -126,13 +128,37 @@ struct TickReserveArgs {
   TickSegDesc seg[kTickMaxSegs];
 };
 void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, long long *admit_idx);
-void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx);
+// the list a tick's LM work appends to (the next tick's evaluations): item slots [0, cap), chain entries [cap, cap + chain_cap)
+struct TickList {
+  unsigned *items;
+  TickSegCtl *seg;
+  int buf, cap;
+  int chain_cap; // 0: chains off -- every pending evaluation becomes items
+  int chain_max_n0; // > 0: only problems whose level-0 template has at most this many points chain (0: all)
+};
+// what a chain (an evaluation workgroup that also steps its problem, see tick_eval_kernel) needs beyond the evaluation's own arguments
+struct TickChainArgs {
+  const TrackerDev **trackers;
+  LMState *states;
+  TickList next;
+  TickModeCtl *mc;
+  const TickPending *pending;
+  TickResult *results;
+  unsigned long long *slot_ticket;
+  int max_rounds; // LM rounds a chain may run inside one tick
+  int flags;      // bit 0: helper wave in the chain's LM step
+};
+void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const TickList &list, TickModeCtl *mc,
+                       const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx);
 void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
-                      TickSegCtl *seg, int buf);
+                      TickSegCtl *seg, int buf, int cap, const TickChainArgs &chain,
+                      bool with_chains /* the list may hold chain entries (now or from an earlier setting): the launch must look at them, if only
+                                          to turn them into items (chain.max_rounds 0) */);
 void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,
-                    unsigned *items_next, TickSegCtl *seg, int buf_next, int items_cap, TickModeCtl *mc, const TickPending *pending,
-                    TickResult *results, unsigned long long *slot_ticket, int speculate);
+                    const TickList &next, TickModeCtl *mc, const TickPending *pending, TickResult *results, unsigned long long *slot_ticket,
+                    int speculate, int opts /* bit 0: helper waves in the LM step, bit 1: the next items' place in the list asked for early */);
+// bounded waits of the LM steps' wave hand-shakes that expired since the library was loaded (0 unless something is badly wrong)
+int lm_spin_expired();
 
 // persistent LM loop of the small levels on LDS-resident data (levels whose target plane has at most max_px pixels, capped
 // by the kernel's LDS arena): coarse_level_fits tells whether a level of w x h pixels and n template points qualifies

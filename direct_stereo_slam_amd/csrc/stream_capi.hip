@@ -115,7 +115,14 @@ struct dsm_stream {
   TickSegCtl *d_segctl = nullptr, *h_segctl = nullptr;
   TickModeCtl *d_modectl = nullptr, *h_modectl = nullptr;
   std::vector<unsigned *> d_items; // [segment][2]
-  std::vector<int> items_cap, last_count;
+  std::vector<int> items_cap, last_count, last_chain;
+  // chains (tick_eval_kernel): LM rounds a problem whose pending evaluation is ONE chunk may run inside one tick, in the workgroup that
+  // evaluates it; 0 = off (every round costs a tick).  A scheduling switch: results are bit-identical.
+  int chain_rounds = DSM_STREAM_CHAIN_DEFAULT;
+  bool chain_possible = false; // a problem the chains apply to was submitted at some time (else the evaluation launches go without the chains' code)
+  int chain_max_n0 = DSM_STREAM_CHAIN_DEFAULT_MAX_N0; // the default chains semi-dense problems only; a number named by the caller: every problem
+  int chain_flags = getenv("DSM_CHAIN_FLAGS") ? atoi(getenv("DSM_CHAIN_FLAGS")) : 1; // (experiments) bit 0: helper wave in a chain's LM step
+  int lm_opts = getenv("DSM_LM_OPTS") ? atoi(getenv("DSM_LM_OPTS")) : 3;             // (experiments) tick_lm_kernel: bit 0 helper waves, bit 1 early list reservation
   TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr}; // waiting rings (device / pinned staging)
   TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};   // result rings (device / two pinned copies)
   int ring[2] = {0, 0};
@@ -281,6 +288,14 @@ int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance) {
   return DSM_OK;
 }
 
+int dsm_stream_set_chain(dsm_stream *s, int max_rounds) {
+  if (!s || max_rounds < -1 || max_rounds > 4096) return invalid("dsm_stream_set_chain: rounds 0 (off) .. 4096, or -1 (the default)");
+  s->chain_rounds = max_rounds < 0 ? DSM_STREAM_CHAIN_DEFAULT : max_rounds; // (takes effect with the next advance: the lists of both kinds are read every tick)
+  s->chain_max_n0 = max_rounds < 0 ? DSM_STREAM_CHAIN_DEFAULT_MAX_N0 : 0;
+  if (max_rounds > 0) s->chain_possible = true; // (a bound named by the caller applies to every problem)
+  return DSM_OK;
+}
+
 int dsm_stream_set_rounds(dsm_stream *s, int mode, const int *rounds_per_level) {
   if (!s || mode < 0 || mode > 1) return invalid("dsm_stream_set_rounds: bad argument");
   for (int l = 0; l < DSM_MAX_LEVELS; l++) s->fixed_rounds[mode][l] = rounds_per_level ? rounds_per_level[l] : 0;
@@ -298,6 +313,7 @@ static int submit_common(dsm_stream *s, int mode, int n, dsm_tracker *const *ts,
     if (coarsest < 0 || coarsest >= t->nlevels) return invalid("coarsest level out of range"); // :457 / :856
     rc = check_ready(t, mode);
     if (rc) return rc;
+    if (s->chain_max_n0 <= 0 || t->desc.lv[0].n <= s->chain_max_n0) s->chain_possible = true;
   }
   (void)tickets_out;
   return DSM_OK;
@@ -704,11 +720,13 @@ static int tick_setup(dsm_stream *s) {
   s->d_items.assign(2 * nseg, nullptr);
   s->items_cap.assign(nseg, 0);
   s->last_count.assign(nseg, 0);
+  s->last_chain.assign(nseg, 0);
   for (int si = 0; si < nseg; si++) {
-    const int cap = (s->tsegs[si].i1 - s->tsegs[si].i0) * 2 * maxpos + 64;
+    const int ns = s->tsegs[si].i1 - s->tsegs[si].i0;
+    const int cap = ns * 2 * maxpos + 64;
     s->items_cap[si] = cap;
-    for (int b = 0; b < 2; b++)
-      if ((rc = alloc_dev(&s->d_items[2 * si + b], cap))) return rc;
+    for (int b = 0; b < 2; b++) // item slots [0, cap), then one chain entry per slot of the segment
+      if ((rc = alloc_dev(&s->d_items[2 * si + b], (size_t)cap + ns))) return rc;
   }
   DSM_HIP(hipMemsetAsync(s->d_segctl, 0, sizeof(TickSegCtl) * nseg, ctx->stream));
   DSM_HIP(hipMemsetAsync(s->d_slot_ticket, 0, sizeof(unsigned long long) * N, ctx->stream));
@@ -754,6 +772,7 @@ static int tick_collect(dsm_stream *s, long long k) {
       return DSM_ERR_STATE;
     }
     s->last_count[si] = sc.count[s->inflight_parity[par]];
+    s->last_chain[si] = sc.chain[s->inflight_parity[par]];
   }
   for (int mode = 0; mode < 2; mode++) {
     const TickModeCtl &mc = s->h_modectl[par * 2 + mode];
@@ -775,7 +794,7 @@ static int tick_collect(dsm_stream *s, long long k) {
     long long life_sum = 0;
     for (long long i = 0; i < new_ret; i++) {
       const TickResult &R = res[(sn.retired + i) & (ring - 1)];
-      for (int l = 0; l < DSM_MAX_LEVELS; l++) life_sum += R.rounds[l];
+      life_sum += R.ticks; // (= its LM rounds, less the rounds chains ran inside one tick)
       auto it = s->origin.find(R.ticket);
       if (it == s->origin.end()) {
         set_error("internal: the tick engine returned an unknown ticket");
@@ -923,12 +942,15 @@ static int tick_advance(dsm_stream *s) {
   size_t ev_used = 0;
   s->ev_lvl.clear();
   const int speculate = s->sched_fixed_schedule > 0 ? 0 : s->sched_speculate;
+  // (with dsm_params.fixed_schedule a cohort moves in lock step and an advance is its whole life: chains would only unbalance it)
+  const int chain_rounds = (s->sched_fixed_schedule > 0 || !s->chain_possible) ? 0 : s->chain_rounds;
   for (int si = nseg - 1; si >= 0; si--) {
     const Seg &sg = s->tsegs[si];
     const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
     if (may_admit[mode]) // (free slots take what tick_reserve_kernel gave them)
-      launch_tick_admit(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, s->d_items[2 * si + s->parity], s->d_segctl + si,
-                        s->parity, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0, s->d_admit_idx + i0);
+      launch_tick_admit(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0,
+                        TickList{s->d_items[2 * si + s->parity], s->d_segctl + si, s->parity, s->items_cap[si], chain_rounds > 0 ? ns : 0, s->chain_max_n0},
+                        s->d_modectl + mode, s->d_pending[mode], s->d_slot_ticket + i0, s->d_admit_idx + i0);
   }
   for (int t = 0; t < T; t++) {
     const int buf = (s->parity + t) & 1;
@@ -936,8 +958,8 @@ static int tick_advance(dsm_stream *s) {
       const Seg &sg = s->tsegs[si];
       const int i0 = sg.i0, ns = sg.i1 - sg.i0, mode = sg.mode;
       // grid: what the segment's list held at the end of the last advance read back, plus slack (the kernel strides over a longer list)
-      long long grid = (long long)s->last_count[si] * 5 / 4 + 256;
-      if (s->last_count[si] == 0) grid = (long long)ns * 16;
+      long long grid = (long long)(s->last_count[si] + s->last_chain[si]) * 5 / 4 + 256;
+      if (s->last_count[si] + s->last_chain[si] == 0) grid = (long long)ns * 16;
       if (grid > s->items_cap[si]) grid = s->items_cap[si];
       float *part = s->d_partials + (size_t)i0 * s->partial_stride;
       hipEvent_t ea = nullptr, eb = nullptr;
@@ -947,11 +969,13 @@ static int tick_advance(dsm_stream *s) {
         s->ev_lvl.push_back(0); // (all levels in one launch: booked under index 0)
         if (ea) DSM_HIP(hipEventRecord(ea, sg.st));
       }
-      launch_tick_eval(sg.st, mode, (int)grid, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + buf], s->d_segctl + si, buf);
+      const TickList next{s->d_items[2 * si + (buf ^ 1)], s->d_segctl + si, buf ^ 1, s->items_cap[si], chain_rounds > 0 ? ns : 0, s->chain_max_n0};
+      const TickChainArgs chain{(const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, next, s->d_modectl + mode, s->d_pending[mode], s->d_results[mode],
+                                s->d_slot_ticket + i0, chain_rounds, s->chain_flags};
+      launch_tick_eval(sg.st, mode, (int)grid, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + buf], s->d_segctl + si, buf, s->items_cap[si], chain, s->chain_possible);
       if (eb) DSM_HIP(hipEventRecord(eb, sg.st));
-      launch_tick_lm(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, part, s->partial_stride, s->d_items[2 * si + (buf ^ 1)],
-                     s->d_segctl + si, buf ^ 1, s->items_cap[si], s->d_modectl + mode, s->d_pending[mode], s->d_results[mode], s->d_slot_ticket + i0,
-                     speculate);
+      launch_tick_lm(sg.st, mode, ns, (const TrackerDev **)s->d_tracker_ptrs + i0, s->d_states + i0, part, s->partial_stride, next, s->d_modectl + mode,
+                     s->d_pending[mode], s->d_results[mode], s->d_slot_ticket + i0, speculate, s->lm_opts);
     }
   }
   s->parity = (s->parity + T) & 1;
@@ -1003,12 +1027,27 @@ int dsm_stream_set_pipelined(dsm_stream *s, int on) {
 
 int dsm_stream_drain(dsm_stream *s) {
   if (!s) return invalid("null stream");
+  long long last_retired = -1;
+  int idle_advances = 0;
   for (;;) {
     int rc = dsm_stream_sync(s); // (the tail is short chains: nothing to overlap)
+    const long long ret_now = s->retired[0] + s->retired[1];
+    idle_advances = ret_now == last_retired ? idle_advances + 1 : 0;
+    last_retired = ret_now;
+    if (idle_advances > 4096) { // (a problem's whole life is a few dozen ticks)
+      set_error("internal: dsm_stream_drain makes no progress");
+      return DSM_ERR_STATE;
+    }
     if (rc) return rc;
     int resident = 0, waiting = 0;
     dsm_stream_counts(s, &resident, &waiting, nullptr);
-    if (resident == 0 && waiting == 0) return DSM_OK;
+    if (resident == 0 && waiting == 0) {
+      if (lm_spin_expired() != 0) { // (a wave hand-shake inside an LM step gave up waiting: results cannot be trusted -- never seen; the waits are bounded so that a defect shows here, not as a hung device)
+        set_error("internal: a bounded wait inside an LM step expired");
+        return DSM_ERR_STATE;
+      }
+      return DSM_OK;
+    }
     rc = dsm_stream_advance(s);
     if (rc) return rc;
   }

@@ -671,147 +671,109 @@ __device__ __forceinline__ void eval_chunk(const EvalConsts &c, int chunk, int t
 // ------------------------------------------------------------------------------------------
 constexpr int kLmThreads = 256;
 
-__device__ __forceinline__ void make_eval_pose(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7],
-                               const double aff[2], float cutoff) {
-  double Rd[9];
-  quat_to_rot(pose, Rd);
-  float Rf[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
-  float Ki[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) Ki[i] = T.lv[lvl].Ki[i];
-  float M[9];
-  mat3f_mul(Rf, Ki, M); // :715
-#pragma unroll
-  for (int i = 0; i < 9; i++) e.M[i] = M[i];
-#pragma unroll
-  for (int i = 0; i < 9; i++) e.Ki[i] = Ki[i];
-  {
-    const LevelDev &L = T.lv[lvl];
-    e.pts = L.pts;
-    e.img = L.img[0]; // new left frame (:709)
-    e.n = L.n;
-    e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
-    e.w = L.w;
-    e.h = L.h;
-    e.fx = L.fx;
-    e.fy = L.fy;
-    e.cx = L.cx;
-    e.cy = L.cy;
-    e.huber = T.p.huber_th;
-  }
-  e.t[0] = (float)pose[4]; // :716
-  e.t[1] = (float)pose[5];
-  e.t[2] = (float)pose[6];
-  double affd[2];
-  aff_from_to(T.ref_exposure, T.exposure[0], T.ref_a, T.ref_b, aff[0], aff[1], affd); // :717-720
-  e.aff0 = (float)affd[0];
-  e.aff1 = (float)affd[1];
-  e.b0 = (float)T.ref_b; // :646
-  e.scale = 1.0f;
-  e.cutoff = cutoff;
-  const float h = T.p.huber_th;
-  e.max_energy = 2 * h * cutoff - h * h; // :726-728
-}
-
-__device__ __forceinline__ void make_eval_scale(const TrackerDev &T, EvalIn &e, int lvl, float scale, float cutoff) {
-  double Rd[9];
-  quat_to_rot(T.T10, Rd);
-  float Rf[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
-  float Ki[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) Ki[i] = T.lv[lvl].Ki[i];
-  float M[9];
-  mat3f_mul(Rf, Ki, M); // :1022-1023
-#pragma unroll
-  for (int i = 0; i < 9; i++) e.M[i] = M[i];
-#pragma unroll
-  for (int i = 0; i < 9; i++) e.Ki[i] = Ki[i];
-  {
-    const LevelDev &L = T.lv[lvl];
-    e.pts = L.pts;
-    e.img = L.img[1]; // right frame fh1_ (:1016)
-    e.n = L.n;
-    e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
-    e.w = L.w;
-    e.h = L.h;
-    e.fx = L.fx1; // cam-1 intrinsics (:1017-1020)
-    e.fy = L.fy1;
-    e.cx = L.cx1;
-    e.cy = L.cy1;
-    e.huber = T.p.huber_th;
-  }
-  e.t[0] = (float)T.T10[4]; // :1024
-  e.t[1] = (float)T.T10[5];
-  e.t[2] = (float)T.T10[6];
-  e.aff0 = 1.0f;
-  e.aff1 = 0.0f;
-  e.b0 = 0.0f;
-  e.scale = scale;
-  e.cutoff = cutoff;
-  const float h = T.p.huber_th;
-  e.max_energy = 2 * h * cutoff - h * h; // :1030-1032
-}
-
-// loop-closure pose (PoseEstimator::calcRes, PoseEstimator.cpp:155-163): M = R (no K^-1), reference
-// affine parameters (0,0) (:317), exposure handed over by the caller
-__device__ __forceinline__ void make_eval_points3d(const TrackerDev &T, EvalIn &e, int lvl, const double pose[7], const double aff[2],
-                                   float cutoff) {
-  double Rd[9];
-  quat_to_rot(pose, Rd);
-#pragma unroll
-  for (int i = 0; i < 9; i++) e.M[i] = (float)Rd[i];
-  e.t[0] = (float)pose[4];
-  e.t[1] = (float)pose[5];
-  e.t[2] = (float)pose[6];
-  double affd[2];
-  aff_from_to(T.ref_exposure, T.exposure[0], 0.0, 0.0, aff[0], aff[1], affd);
-  e.aff0 = (float)affd[0];
-  e.aff1 = (float)affd[1];
-  e.b0 = 0.0f; // ref_aff_g2l_.b (:90)
-  e.scale = 1.0f;
-  e.cutoff = cutoff;
-  const float h = T.p.huber_th;
-  e.max_energy = 2 * h * cutoff - h * h;
+// The inputs of an evaluation, in parts (round 6 -- an LM step is ONE wave's chain of dependent instructions, every one of them is
+// time: shader-clock stamps in profiles/r06_tick_stamps.json had make_eval at 6 k of a step's 22 k cycles):
+//   make_eval_level  what depends on the level alone (and, for the scale problem, everything but the scale: R10 K^-1 and tsl_f1_f0 are
+//                    constants of the level) -- written ONCE when a level begins, into both candidates' blocks;
+//   make_eval_rot    M and t of a proposed pose;  make_eval_aff  affLL of a proposed affine pair (the only exp of the step);
+//   make_eval_cutoff cutoff, max_energy, the residual-only mark.
+// Every value is formed by the same operations on the same operands as the one-piece form of rounds 1-5: same bits.
+// `st`: this lane stores (the callers run on wave-uniform values; lane 0 writes).
+__device__ __forceinline__ void make_eval_level(const TrackerDev &T, EvalIn &e, int mode, int lvl) {
   const LevelDev &L = T.lv[lvl];
+  float Ki[9];
 #pragma unroll
-  for (int i = 0; i < 9; i++) e.Ki[i] = L.Ki[i];
+  for (int i = 0; i < 9; i++) Ki[i] = L.Ki[i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) e.Ki[i] = Ki[i];
   e.pts = L.pts;
-  e.img = L.img[0];
+  e.img = L.img[mode == 1 ? 1 : 0]; // new left frame (:709) / right frame fh1_ (:1016)
   e.n = L.n;
   e.ppt = pts_per_thread(L.n, T.p.geometry), e.pad0 = e.pad1 = e.pad2 = 0;
   e.w = L.w;
   e.h = L.h;
-  e.fx = L.fx;
-  e.fy = L.fy;
-  e.cx = L.cx;
-  e.cy = L.cy;
+  if (mode == 1) { // cam-1 intrinsics (:1017-1020)
+    e.fx = L.fx1, e.fy = L.fy1, e.cx = L.cx1, e.cy = L.cy1;
+  } else {
+    e.fx = L.fx, e.fy = L.fy, e.cx = L.cx, e.cy = L.cy;
+  }
   e.huber = T.p.huber_th;
+  e.b0 = mode == 0 ? (float)T.ref_b : 0.0f; // :646 (pose); the loop-closure estimator's reference has b = 0 (PoseEstimator.cpp:90)
+  e.scale = 1.0f;
+  if (mode == 1) {
+    double Rd[9];
+    quat_to_rot(T.T10, Rd);
+    float Rf[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+    float M[9];
+    mat3f_mul(Rf, Ki, M); // :1022-1023
+#pragma unroll
+    for (int i = 0; i < 9; i++) e.M[i] = M[i];
+    e.t[0] = (float)T.T10[4]; // :1024
+    e.t[1] = (float)T.T10[5];
+    e.t[2] = (float)T.T10[6];
+    e.aff0 = 1.0f;
+    e.aff1 = 0.0f;
+  }
+}
+// pose (mode 0): M = R K^-1 (:715), t (:716); loop-closure pose (mode 2, PoseEstimator.cpp:155-163): M = R.  e.Ki holds the level's K^-1.
+__device__ __forceinline__ void make_eval_rot(EvalIn &e, int mode, const double pose[7], bool st) {
+  double Rd[9];
+  quat_to_rot(pose, Rd);
+  float Rf[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+  float M[9];
+  if (mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) M[i] = Rf[i];
+  } else {
+    float Ki[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ki[i] = e.Ki[i];
+    mat3f_mul(Rf, Ki, M);
+  }
+  if (st) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) e.M[i] = M[i];
+    e.t[0] = (float)pose[4];
+    e.t[1] = (float)pose[5];
+    e.t[2] = (float)pose[6];
+  }
+}
+// affLL = fromToVecExposure(lastRef->ab_exposure, new_frame_->ab_exposure, lastRef_aff_g2l, aff_g2l) (:717-720); the loop-closure
+// estimator's reference affine is (0, 0) (PoseEstimator.cpp:317)
+__device__ __forceinline__ void make_eval_aff(const TrackerDev &T, EvalIn &e, int mode, const double aff[2], bool st) {
+  double affd[2];
+  aff_from_to(T.ref_exposure, T.exposure[0], mode == 2 ? 0.0 : T.ref_a, mode == 2 ? 0.0 : T.ref_b, aff[0], aff[1], affd);
+  if (st) {
+    e.aff0 = (float)affd[0];
+    e.aff1 = (float)affd[1];
+  }
+}
+__device__ __forceinline__ void make_eval_cutoff(const TrackerDev &T, EvalIn &e, float cutoff, bool residual_only, bool st) {
+  const float h = T.p.huber_th;
+  if (st) {
+    e.cutoff = cutoff;
+    e.max_energy = 2 * h * cutoff - h * h; // :726-728 / :1030-1032
+    e.residual_only = residual_only ? 1 : 0;
+  }
 }
 
-// Builds the inputs of the next evaluation and (store) writes them to the problem state: called by lane 0
-// alone, or by a whole wave with wave-uniform arguments and store = (lane == 0).
-// spec: the inputs go to the speculative slot (S.spec_in) instead of S.in.
-// residual_only: the loop is known to end after this evaluation (see EvalIn).
+// The complete inputs of an evaluation at `lvl` into the problem state: one thread (a level's first evaluation, a single evaluation
+// of dsm_tracker_calc_res_*).
 __device__ __forceinline__ void make_eval_any(const TrackerDev &T, LMState &S, int mode, int lvl, const double pose[7], const double aff[2],
-                              float scale, float cutoff, bool store = true, bool spec = false, bool residual_only = false) {
-  EvalIn e;
-  if (mode == 1)
-    make_eval_scale(T, e, lvl, scale, cutoff);
-  else if (mode == 2)
-    make_eval_points3d(T, e, lvl, pose, aff, cutoff);
-  else
-    make_eval_pose(T, e, lvl, pose, aff, cutoff);
-  e.residual_only = residual_only ? 1 : 0;
-  if (store) {
-    if (spec)
-      S.spec_in = e;
-    else
-      S.in = e;
+                              float scale, float cutoff) {
+  EvalIn &e = S.in;
+  make_eval_level(T, e, mode, lvl);
+  if (mode == 1) {
+    e.scale = scale;
+  } else {
+    make_eval_rot(e, mode, pose, true);
+    make_eval_aff(T, e, mode, aff, true);
   }
+  make_eval_cutoff(T, e, cutoff, false, true);
 }
 
 // lane 0 only
@@ -823,6 +785,7 @@ __device__ __forceinline__ void begin_level(const TrackerDev &T, LMState &S, int
   S.spec_valid = 0;
   const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
   make_eval_any(T, S, S.is_scale, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
+  make_eval_level(T, S.spec_in, S.is_scale, lvl); // (the speculative candidate's block: a proposal writes its own part only)
 }
 
 // iteration bound of a level: maxIterations[lvl] (:463,:505 / :862,:897), or the benchmark schedule's K (dsm_params.fixed_schedule)
@@ -1035,6 +998,47 @@ __device__ __forceinline__ void wave_ldlt_solve8(const double *Hlds, const doubl
   }
 }
 
+// value of an LDS word that another wave of the workgroup writes
+__device__ __forceinline__ int lds_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// A proposing wave's HELPER (round 6).  Of what follows the solve, the affine part of the next evaluation's inputs -- affLL: the
+// step's only exp, a division -- and its cut-off need nothing of the new pose: a wave that would otherwise sit idle forms them while
+// the proposing wave runs SE3::exp, the pose product and R K^-1.  The proposing wave posts the candidate's affine pair as soon as the
+// increment is known, and meets the helper again before it leaves.
+struct LmHelp {
+  int cmd;  // proposing wave -> helper: 0 wait, 1 go, 2 nothing to do this step
+  int done; // helper -> proposing wave
+  int spec, last;
+  float cutoff, pad;
+  double aff[2];
+};
+constexpr int kLmSpinBound = 1 << 22; // polls of an LDS flag before a wave gives up (seconds; a step is microseconds): waits are bounded
+__device__ int g_lm_spin_expired;      // ... and say so: nonzero once any bounded wait of an LM step has expired (read by the host with the statistics)
+__device__ __forceinline__ int lds_wait_nonzero(const int *p) {
+  int v = 0;
+  for (int spins = 0; (v = lds_flag(p)) == 0; spins++) {
+    if (spins > kLmSpinBound) {
+      atomicAdd(&g_lm_spin_expired, 1);
+      return -1;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return v;
+}
+__device__ __forceinline__ void lm_help_wave(const TrackerDev &T, LMState &S, LmHelp &h, int lane) {
+  const int cmd = lds_wait_nonzero(&h.cmd);
+  if (cmd != 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  EvalIn &e = h.spec ? S.spec_in : S.in;
+  const double aff[2] = {h.aff[0], h.aff[1]};
+  make_eval_aff(T, e, S.is_scale, aff, lane == 0);
+  make_eval_cutoff(T, e, h.cutoff, h.last != 0, lane == 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) lds_flag_set(&h.done, 1);
+}
+
 // lane 0 only: :612-637
 __device__ __forceinline__ void finish_track(const TrackerDev &T, LMState &S) {
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
@@ -1057,8 +1061,9 @@ __device__ __forceinline__ void finish_track(const TrackerDev &T, LMState &S) {
 }
 
 // whole wave: solve + propose for the pose problem (:505-554) from the H, b of the problem state (LDS).
-// spec: the proposal is the speculative one (S.spec_*).
-__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, float lambda, int lane, LdltScratch &scr, bool spec = false) {
+// spec: the proposal is the speculative one (S.spec_*).  hp: this wave's helper (lm_help_wave), or null.
+__device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, float lambda, int lane, LdltScratch &scr, bool spec = false,
+                                             LmHelp *hp = nullptr) {
   const float modeA = T.p.affine_opt_mode_a, modeB = T.p.affine_opt_mode_b;
   unsigned active = 0xFFu;
   bool stitch = false;
@@ -1089,35 +1094,54 @@ __device__ __forceinline__ void propose_pose(const TrackerDev &T, LMState &S, fl
 #pragma unroll
     for (int i = 0; i < 8; i++) incScaled[i] = 0;
   }
+  double aff_cand[2] = {S.aff_cur[0] + incScaled[6], S.aff_cur[1] + incScaled[7]};
+  double nrm = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+  const double inc_norm = sqrt(nrm);
+  // Is this the loop's last evaluation?  The step that consumes it ends the level when the increment is small (:588) or the
+  // iteration bound is reached (:505) -- both known now; the speculative proposal is consumed one iteration later.
+  const bool last = (T.p.fixed_schedule <= 0 && !(inc_norm > 1e-3)) || S.iteration + (spec ? 2 : 1) >= level_max_it(T.p, S.lvl);
+  const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
+  EvalIn &e = spec ? S.spec_in : S.in; // (its level part is in place since begin_level)
+  if (hp) { // the affine pair and the cut-off go to the helper now; the pose part follows here
+    if (lane == 0) {
+      hp->aff[0] = aff_cand[0], hp->aff[1] = aff_cand[1];
+      hp->cutoff = cutoff;
+      hp->last = last ? 1 : 0;
+      hp->spec = spec ? 1 : 0;
+      lds_flag_set(&hp->cmd, 1);
+    }
+  }
   double ex[7], cur[7], cand[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) cur[i] = S.cur[i];
   se3_exp_wave(incScaled, ex, lane);
   se3_mul(ex, cur, cand); // :550-551
-  double aff_cand[2] = {S.aff_cur[0] + incScaled[6], S.aff_cur[1] + incScaled[7]};
-  double nrm = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
   if (lane == 0) {
     if (spec) {
 #pragma unroll
       for (int i = 0; i < 7; i++) S.spec_cand[i] = cand[i];
       S.spec_aff_cand[0] = aff_cand[0];
       S.spec_aff_cand[1] = aff_cand[1];
-      S.spec_inc_norm = sqrt(nrm);
+      S.spec_inc_norm = inc_norm;
     } else {
 #pragma unroll
       for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
       S.aff_cand[0] = aff_cand[0];
       S.aff_cand[1] = aff_cand[1];
-      S.inc_norm = sqrt(nrm);
+      S.inc_norm = inc_norm;
       S.phase = PH_ITER;
     }
   }
-  // Is this the loop's last evaluation?  The step that consumes it ends the level when the increment is small (:588) or the
-  // iteration bound is reached (:505) -- both known now; the speculative proposal is consumed one iteration later.
-  const bool last = (T.p.fixed_schedule <= 0 && !(sqrt(nrm) > 1e-3)) || S.iteration + (spec ? 2 : 1) >= level_max_it(T.p, S.lvl);
-  make_eval_any(T, S, S.is_scale, S.lvl, cand, aff_cand, 1.0f, T.p.coarse_cutoff_th * S.level_cutoff_repeat, lane == 0, spec, last);
+  make_eval_rot(e, S.is_scale, cand, lane == 0);
+  if (hp) {
+    (void)lds_wait_nonzero(&hp->done);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else {
+    make_eval_aff(T, e, S.is_scale, aff_cand, lane == 0);
+    make_eval_cutoff(T, e, cutoff, last, lane == 0);
+  }
 }
 
 // lane 0 only: :897-913
@@ -1140,7 +1164,9 @@ __device__ __forceinline__ void propose_scale(const TrackerDev &T, LMState &S, f
     S.phase = PH_ITER;
   }
   const bool last = (T.p.fixed_schedule <= 0 && !(inc > 1e-3)) || S.iteration + (spec ? 2 : 1) >= level_max_it(T.p, S.lvl); // :937 (signed, Q7) / :897
-  make_eval_any(T, S, 1, S.lvl, S.cur, S.aff_cur, cand, T.p.coarse_cutoff_th * S.level_cutoff_repeat, true, spec, last);
+  EvalIn &e = spec ? S.spec_in : S.in; // (R10 K^-1, tsl_f1_f0 and the camera are the level's: in place since begin_level)
+  e.scale = cand;
+  make_eval_cutoff(T, e, T.p.coarse_cutoff_th * S.level_cutoff_repeat, last, true);
 }
 
 // lane 0 only
@@ -1183,6 +1209,7 @@ struct RedBuf { // fixed-order reduction of one evaluation's chunk partials
 struct LmSpecShared {
   RedBuf red;
   LdltScratch ldlt; // wave 1's
+  LmHelp help;      // wave 1's helper (wave 3)
   int cmd;      // wave 0 -> wave 1: 0 wait, 1 stage the speculative proposal with `lambda`, 2 nothing to do
   int done;     // wave 1 -> wave 0
   float lambda;
@@ -1190,6 +1217,7 @@ struct LmSpecShared {
 struct LmShared {
   RedBuf red;
   LdltScratch ldlt; // wave 0's
+  LmHelp help;      // wave 0's helper (wave 2)
   // The problem's LMState and its tracker descriptor are staged here for the duration of a step
   // (lm_kernel) or of the whole small-level loop (coarse_kernel): the state machine then runs on LDS
   // latencies instead of a chain of dependent global-memory round trips.
@@ -1322,15 +1350,20 @@ __device__ __forceinline__ void reduce_partials_final(int lane, RedBuf &sh) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// value of an LDS word that another wave of the workgroup writes
-__device__ __forceinline__ int lds_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // One step of the LM state machine by wave 0 (all 64 lanes; lane 0 writes the state).
 // sp != nullptr: the launch also evaluated the speculative candidates (where S.spec_valid) -- their reduced sums are in
 // sp->red -- and new proposals may stage one; wave 1 of the workgroup runs lm_spec_wave1 beside this function.
+// hp: wave 0's helper is running beside it (lm_help_wave on sh.help): it is told what to do, or that there is nothing, exactly once.
+// early: called (whole wave) as soon as the step knows that it proposes -- i.e. that the next evaluation is one of THIS level -- and
+// whether a speculative twin may be staged: before the solve and everything after it (the tick engine asks for its place in the item
+// list then, a returning atomic whose round trip used to follow the step).
+struct LmNoEarly {
+  __device__ __forceinline__ void operator()(const LMState &, int, bool) const {}
+};
+template <class EARLY = LmNoEarly>
 __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDev &T, LMState &S, LmShared &sh, int lane,
-                                              LmSpecShared *sp = nullptr) {
+                                              LmSpecShared *sp = nullptr, bool helped = false, EARLY *early = nullptr) {
   const bool pose_like = mode != 1;
   const double *sums = sh.red.sums;
   const long long *isums = sh.red.isums;
@@ -1350,6 +1383,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   int iteration = 0;
   if (lane == 0) {
     S.rounds[lvl]++;
+    S.ticks++; // (a chain of the tick engine takes its extra rounds off again)
     S.spec_valid = 0;
   }
   if (phase == PH_INIT) {
@@ -1358,7 +1392,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
         S.evals[lvl]++;
         S.level_cutoff_repeat *= 2;
         const float cutoff = T.p.coarse_cutoff_th * S.level_cutoff_repeat;
-        make_eval_any(T, S, mode, lvl, S.cur, S.aff_cur, S.scale_cur, cutoff);
+        make_eval_cutoff(T, S.in, cutoff, false, true); // (the same pose or scale once more, with the wider cut-off: nothing else changes)
       }
     } else {
       if (pose_like) {
@@ -1469,6 +1503,7 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   // the speculative proposal: what the loop proposes after rejecting the main one -- lambda four times larger (:583-585);
   // it exists only if the loop would go on after that rejection (one more iteration allowed; the main step not "too small")
   const bool want_spec = sp && do_propose && !fixed && iteration + 1 < max_it;
+  if (early && do_propose) (*early)(S, lane, want_spec);
   if (sp && lane == 0) {
     float l4 = lambda_next * 4;
     if (l4 < lim) l4 = lim;
@@ -1477,12 +1512,13 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   }
   if (do_propose) {
     if (pose_like)
-      propose_pose(T, S, lambda_next, lane, sh.ldlt);
+      propose_pose(T, S, lambda_next, lane, sh.ldlt, false, helped ? &sh.help : nullptr);
     else if (lane == 0)
       propose_scale(T, S, lambda_next);
   }
+  if (helped && !(do_propose && pose_like) && lane == 0) lds_flag_set(&sh.help.cmd, 2);
   if (want_spec) {
-    while (lds_flag(&sp->done) == 0) __builtin_amdgcn_s_sleep(1);
+    (void)lds_wait_nonzero(&sp->done);
     if (lane == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const bool main_small = pose_like ? !(S.inc_norm > 1e-3) : !(S.inc_f > 1e-3); // the loop breaks after the main step
@@ -1492,15 +1528,17 @@ __device__ __forceinline__ void lm_step_wave0(int mode, int lvl, const TrackerDe
   if (lane == 0 && level_done) end_level(T, S);
 }
 
-// wave 1 beside lm_step_wave0: stages the speculative proposal when wave 0 asks for it
-__device__ __forceinline__ void lm_spec_wave1(int mode, const TrackerDev &T, LMState &S, LmSpecShared &sp, int lane) {
-  int cmd;
-  while ((cmd = lds_flag(&sp.cmd)) == 0) __builtin_amdgcn_s_sleep(1);
-  if (cmd != 1) return;
+// wave 1 beside lm_step_wave0: stages the speculative proposal when wave 0 asks for it (helped: its own helper runs on sp.help)
+__device__ __forceinline__ void lm_spec_wave1(int mode, const TrackerDev &T, LMState &S, LmSpecShared &sp, int lane, bool helped = false) {
+  const int cmd = lds_wait_nonzero(&sp.cmd);
+  if (cmd != 1 || mode == 1) {
+    if (helped && lane == 0) lds_flag_set(&sp.help.cmd, 2);
+    if (cmd != 1) return;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const float lambda = sp.lambda;
   if (mode != 1) {
-    propose_pose(T, S, lambda, lane, sp.ldlt, true);
+    propose_pose(T, S, lambda, lane, sp.ldlt, true, helped ? &sp.help : nullptr);
   } else if (lane == 0) {
     propose_scale(T, S, lambda, true);
   }
@@ -1524,10 +1562,11 @@ struct LmPre {
   uint4 sv;
 };
 constexpr int kLmS16 = sizeof(LMState) / 16, kLmT16 = sizeof(TrackerDev) / 16;
-template <bool COH = false>
+template <bool COH = false, class EARLY = LmNoEarly>
 __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const TrackerDev *Tg, LMState &S,
                                               const float *partials_prob, LmShared &sh, int tid, int *status_out,
-                                              LmSpecShared *sp = nullptr, int spec_off = 0, const LmPre *pre = nullptr) {
+                                              LmSpecShared *sp = nullptr, int spec_off = 0, const LmPre *pre = nullptr, EARLY *early = nullptr,
+                                              bool help = true) {
   constexpr int kS16 = kLmS16, kT16 = kLmT16;
   static_assert(kS16 <= kThreads && kT16 <= kThreads, "one 16-byte block per thread");
   // one round trip: state block, tracker descriptor and the chunk partials together
@@ -1542,19 +1581,24 @@ __device__ __forceinline__ void lm_step_block(int mode, int lvl, int prob, const
   const int ppt_lvl = pre ? pre->ppt_lvl : COH ? __hip_atomic_load(&S.in.ppt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.in.ppt;
   if (sp) { // (garbage where no speculative candidate was evaluated: never looked at then)
     reduce_partials_groups2(partials_prob, partials_prob + spec_off, chunks_of(n_lvl, ppt_lvl), tid, sh.red, sp->red);
-    if (tid == 0) sp->cmd = 0, sp->done = 0;
+    if (tid == 0) sp->cmd = 0, sp->done = 0, sp->help.cmd = 0, sp->help.done = 0;
   } else {
     reduce_partials_groups(partials_prob, chunks_of(n_lvl, ppt_lvl), tid, sh.red);
   }
+  if (tid == 0) sh.help.cmd = 0, sh.help.done = 0;
   if (tid < kS16) ((uint4 *)&sh.st)[tid] = sv;
   if (tid < kT16) ((uint4 *)&sh.trk)[tid] = tv;
   __syncthreads();
-  if (sp && tid >= 64 && tid < 128) lm_spec_wave1(mode, sh.trk, sh.st, *sp, tid - 64);
+  // waves 2 and 3: the helpers of the proposing waves 0 and 1 (the pose problems' affine part, lm_help_wave)
+  const bool helped = mode != 1 && help;
+  if (sp && tid >= 64 && tid < 128) lm_spec_wave1(mode, sh.trk, sh.st, *sp, tid - 64, helped);
+  if (helped && tid >= 128 && tid < 192) lm_help_wave(sh.trk, sh.st, sh.help, tid - 128);
+  if (helped && sp && tid >= 192 && tid < 256) lm_help_wave(sh.trk, sh.st, sp->help, tid - 192);
   if (tid >= 64) return; // wave 0 carries on
   const int lane = tid;
   reduce_partials_final(lane, sh.red);
   if (sp) reduce_partials_final(lane, sp->red);
-  lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane, sp);
+  lm_step_wave0(mode, lvl, sh.trk, sh.st, sh, lane, sp, helped, early);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // lane 0's LDS writes -> the whole wave
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1739,6 +1783,8 @@ __device__ __forceinline__ void lm_start_problem(const TrackerDev &T, LMState &S
     S.rounds[i] = 0;
   }
   S.spec_valid = 0;
+  S.ticks = 0;
+  S.n0 = T.lv[0].n;
   S.flow[0] = S.flow[1] = S.flow[2] = 1000; // :460
   S.status = ST_RUNNING;
   begin_level(T, S, I.coarsest);
@@ -2197,37 +2243,76 @@ void launch_queue(hipStream_t s, int mode, int nblocks, int nprob, const Tracker
 // waiting list.  Kernel boundaries order everything: no cross-workgroup protocol, no tickets, no host round trip inside an
 // advance.  Same chunks, same partials, same reduction order as every other form: bit-identical results.
 // ------------------------------------------------------------------------------------------
-// wave 0: the items of the evaluation(s) staged in `St` (the main candidate and, where staged, the speculative one)
-__device__ __forceinline__ void tick_push(const LMState &St, int prob, unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, int lane) {
+// wave 0: the items of the evaluation(s) staged in `St` (the main candidate and, where staged, the speculative one) -- or, where chains
+// are on and the evaluation is ONE chunk with no speculative twin, a chain entry: the problem's number behind the list's item slots
+// res_base / res_total: item slots this problem reserved EARLY in its step (TickReserve below), to be used or filled with no-ops.
+__device__ __forceinline__ void tick_push(const LMState &St, int prob, const TickList &L, TickModeCtl *mc, int lane, int res_base = 0, int res_total = 0) {
   const int nch = chunks_of(St.in.n, St.in.ppt), per_xcd = (nch + 7) >> 3;
+  const bool chain = L.chain_cap > 0 && nch == 1 && !St.spec_valid && (L.chain_max_n0 <= 0 || St.n0 <= L.chain_max_n0);
   const int npos = nch < 8 ? nch : 8 * per_xcd;
-  const int total = St.spec_valid ? 2 * npos : npos;
-  if (total == 0) return; // an empty level: nothing to evaluate, the LM step runs anyway
-  int base = 0;
-  if (lane == 0) {
-    base = atomicAdd(&seg->count[buf], total);
-    if (base + total > cap) seg->overflow = 1;
+  int total = chain ? 0 : St.spec_valid ? 2 * npos : npos;
+  if (chain && lane == 0) {
+    const int idx = atomicAdd(&L.seg->chain[L.buf], 1);
+    if (idx < L.chain_cap)
+      L.items[L.cap + idx] = (unsigned)prob;
+    else
+      L.seg->overflow = 1;
+    // (the chain books its evaluations itself, round by round)
+  }
+  int base = res_base;
+  if (total > res_total) { // nothing reserved (a reservation is never too short: it is made for the same level, with the twin counted)
+    for (int i = lane; i < res_total; i += 64) L.items[res_base + i] = kTickNoop;
+    res_total = 0;
+    if (lane == 0) {
+      base = atomicAdd(&L.seg->count[L.buf], total);
+      if (base + total > L.cap) L.seg->overflow = 1;
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+  if (total > 0 && lane == 0) {
     const int lvl = St.lvl;
     atomicAdd((unsigned long long *)&mc->sched_evals[lvl], 1ull);
     if (St.in.residual_only) atomicAdd((unsigned long long *)&mc->sched_ro[lvl], 1ull);
     atomicAdd((unsigned long long *)&mc->sched_items[lvl], (unsigned long long)total);
   }
-  base = __builtin_amdgcn_readfirstlane(base);
-  for (int i = lane; i < total; i += 64) {
+  const int fill = total > res_total ? total : res_total; // (total == 0: an empty level -- nothing to evaluate, the LM step runs anyway)
+  for (int i = lane; i < fill; i += 64) {
     const bool cand = i >= npos;
     const int p = cand ? i - npos : i;
-    // position p runs on XCD (base + p) % 8 (workgroup index = list position): XCD-contiguous bands of the template, as eval_kernel
+    // position p runs on XCD (base + p) % 8 (workgroup index = list position + a constant): XCD-contiguous bands of the template, as eval_kernel
     const int chunk = nch < 8 ? p : (p & 7) * per_xcd + (p >> 3);
-    const unsigned item = chunk < nch ? (((unsigned)prob << kTickChunkBits) | (unsigned)chunk | (cand ? kTickCand : 0u)) : kTickNoop;
-    if (base + i < cap) items[base + i] = item;
+    const unsigned item = (i < total && chunk < nch) ? (((unsigned)prob << kTickChunkBits) | (unsigned)chunk | (cand ? kTickCand : 0u)) : kTickNoop;
+    if (base + i < L.cap) L.items[base + i] = item;
   }
 }
+// The reservation: handed to the LM step as its `early` hook by tick_lm_kernel.  The step proposes, so the next evaluation is one of the
+// level the state stands on: its items (and the speculative twin's, should one be staged) get their place in the list NOW, and the
+// atomic's round trip -- 2 k of the 4.9 k cycles "items of the next tick" cost at the end of a step (profiles/r06_tick_stamps.json) --
+// runs under the solve.
+struct TickReserve {
+  TickList L;
+  int base, total;
+  __device__ __forceinline__ void operator()(const LMState &St, int lane, bool want_spec) {
+    const int nch = chunks_of(St.in.n, St.in.ppt), per_xcd = (nch + 7) >> 3;
+    const int npos = nch < 8 ? nch : 8 * per_xcd;
+    if (L.chain_cap > 0 && nch == 1 && !want_spec && (L.chain_max_n0 <= 0 || St.n0 <= L.chain_max_n0)) return; // (goes to the chain list)
+    total = want_spec ? 2 * npos : npos;
+    if (total == 0) return;
+    int b = 0;
+    if (lane == 0) {
+      b = atomicAdd(&L.seg->count[L.buf], total);
+      if (b + total > L.cap) L.seg->overflow = 1;
+    }
+    base = b; // (lane 0's value is broadcast where it is used: no wait for the atomic here)
+  }
+};
 
 // wave 0: entry h of the waiting ring goes into slot `prob`: tracker pointer, ticket, state machine started, first items staged.
-// st / trk: LDS scratch of the caller.
+// st / trk: LDS scratch of the caller.  stepped: the value of the new state's `stepped` flag (1 when the admission happens inside an
+// evaluation launch: the tick's LM launch must leave the newcomer alone).
 __device__ __forceinline__ void tick_admit_entry(int mode, long long h, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
-                                                 unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc, const TickPending *pending,
-                                                 unsigned long long *slot_ticket, int lane) {
+                                                 const TickList &L, TickModeCtl *mc, const TickPending *pending,
+                                                 unsigned long long *slot_ticket, int lane, int stepped) {
   const TickPending &Pn = pending[h & (mc->ring - 1)];
   const TrackerDev *tp = Pn.trk;
   stage_in(trk, tp, lane, 64);
@@ -2238,18 +2323,19 @@ __device__ __forceinline__ void tick_admit_entry(int mode, long long h, int prob
     trackers[prob] = tp;
     slot_ticket[prob] = Pn.ticket;
     lm_start_problem(trk, st, mode, Pn.start);
+    st.stepped = stepped;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   stage_out(&states[prob], st, lane, 64);
-  tick_push(st, prob, items, seg, buf, cap, mc, lane);
+  tick_push(st, prob, L, mc, lane);
 }
 
 // wave 0, inside a tick: the slot whose problem just retired takes the next waiting problem (if any) on the spot.
 __device__ __forceinline__ void tick_try_admit(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
-                                               unsigned *items, TickSegCtl *seg, int buf, int cap, TickModeCtl *mc,
-                                               const TickPending *pending, unsigned long long *slot_ticket, int lane) {
+                                               const TickList &L, TickModeCtl *mc,
+                                               const TickPending *pending, unsigned long long *slot_ticket, int lane, int stepped) {
   // pending_head / pending_count are monotonic over the life of the stream (the waiting list is a ring the host appends to while the
   // device consumes): an index is taken by compare-and-swap so that the head never runs past the count -- an overshoot would skip
   // entries the host appends later.  (Few problems retire in one tick, so the swap is rarely contended; the start of an advance,
@@ -2269,7 +2355,36 @@ __device__ __forceinline__ void tick_try_admit(int mode, int prob, const Tracker
   }
   h = ((long long)__builtin_amdgcn_readfirstlane((int)(h >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h);
   if (h < 0) return;
-  tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, lane);
+  tick_admit_entry(mode, h, prob, trackers, states, st, trk, L, mc, pending, slot_ticket, lane, stepped);
+}
+
+// wave 0, after a problem's LM step (state in `st`, already written back): a running problem stages its next evaluation; a terminated
+// one writes its result and its slot takes the next waiting problem on the spot
+__device__ __forceinline__ void tick_after_step(int mode, int prob, const TrackerDev **trackers, LMState *states, LMState &st, TrackerDev &trk,
+                                                const TickList &L, TickModeCtl *mc, const TickPending *pending, TickResult *results,
+                                                unsigned long long *slot_ticket, int lane, int stepped, int res_base = 0, int res_total = 0) {
+  if (st.status == ST_RUNNING) {
+    tick_push(st, prob, L, mc, lane, res_base, res_total);
+    return;
+  }
+  for (int i = lane; i < res_total; i += 64) L.items[res_base + i] = kTickNoop; // (cannot happen: a step that proposes does not terminate)
+  if (lane == 0) {
+    const long long r = (long long)atomicAdd((unsigned long long *)&mc->retired, 1ull); // monotonic; the host never lets more problems in than the result ring has room for
+    TickResult &R = results[r & (mc->ring - 1)];
+    const LMState &F = st;
+    R.ticket = slot_ticket[prob];
+    R.status = F.status;
+    R.ticks = F.ticks;
+    for (int i = 0; i < 7; i++) R.cur[i] = F.cur[i];
+    R.aff_cur[0] = F.aff_cur[0], R.aff_cur[1] = F.aff_cur[1];
+    R.flow[0] = F.flow[0], R.flow[1] = F.flow[1], R.flow[2] = F.flow[2];
+    R.scale_cur = F.scale_cur;
+    for (int l = 0; l < DSM_MAX_LEVELS; l++) {
+      R.last_residuals[l] = F.last_residuals[l];
+      R.evals[l] = F.evals[l], R.evals_ro[l] = F.evals_ro[l], R.rounds[l] = F.rounds[l];
+    }
+  }
+  tick_try_admit(mode, prob, trackers, states, st, trk, L, mc, pending, slot_ticket, lane, stepped);
 }
 
 // Start of an advance, on the context's stream before the stream groups fork (nothing else touches the stream's state then): one
@@ -2333,28 +2448,116 @@ __global__ __launch_bounds__(256) void tick_reserve_kernel(TickReserveArgs a, co
 }
 
 // start of an advance: the free slots take the entries tick_reserve_kernel gave them
-__global__ __launch_bounds__(64) void tick_admit_kernel(int mode, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                                                        int buf, int cap, TickModeCtl *mc, const TickPending *pending,
-                                                        unsigned long long *slot_ticket, const long long *__restrict__ admit_idx) {
+__global__ __launch_bounds__(64) void tick_admit_kernel(int mode, const TrackerDev **trackers, LMState *states, TickList L, TickModeCtl *mc,
+                                                        const TickPending *pending, unsigned long long *slot_ticket,
+                                                        const long long *__restrict__ admit_idx) {
   const int prob = blockIdx.x;
   __shared__ __attribute__((aligned(16))) LMState st;
   __shared__ __attribute__((aligned(16))) TrackerDev trk;
   const long long h = admit_idx[prob];
   if (h < 0) return;
   stage_in(st, &states[prob], threadIdx.x, 64); // (fields the start does not write keep their old bits: none is read)
-  tick_admit_entry(mode, h, prob, trackers, states, st, trk, items, seg, buf, cap, mc, pending, slot_ticket, threadIdx.x);
+  tick_admit_entry(mode, h, prob, trackers, states, st, trk, L, mc, pending, slot_ticket, threadIdx.x, 0);
 }
 
+// One LM round of a chain (below): the single chunk's partial (LDS) reduced in the fixed order of every other form, wave 0 steps the
+// state machine on the LDS copy of the state.  Not inlined: the evaluation loops of tick_eval_kernel keep their registers.
+// (LDS objects are handed over as local-address-space pointers: the inlined state machine keeps its ds_ instructions.)
 template <int MODE>
+__device__ __attribute__((noinline)) void tick_chain_round(DSM_LDS LmShared *shp, const DSM_LDS float *partp, int nch, int lvl, int tid, bool help) {
+  LmShared &sh = *(LmShared *)shp;
+  const float *part = (const float *)partp;
+  reduce_partials_groups(part, nch, tid, sh.red);
+  if (tid == 0) sh.help.cmd = 0, sh.help.done = 0;
+  __syncthreads();
+  if (tid < 64) {
+    reduce_partials_final(tid, sh.red);
+    lm_step_wave0(MODE, lvl, sh.trk, sh.st, sh, tid, nullptr, MODE != 1 && help);
+  } else if (MODE != 1 && help && tid >= 128 && tid < 192) {
+    lm_help_wave(sh.trk, sh.st, sh.help, tid - 128);
+  }
+  __syncthreads(); // the state (status, level, next evaluation inputs) is read by all waves
+}
+// end of a chain, wave 0: the rounds beyond the first did not cost the problem a tick; state written back with the `stepped` flag up
+// (this tick's LM launch leaves the slot alone), then what tick_lm_kernel does after a step
+template <int MODE>
+__device__ __attribute__((noinline)) void tick_chain_finish(DSM_LDS LmShared *shp, int prob, int rounds, const DSM_LDS TickChainArgs *cap, int lane) {
+  LmShared &sh = *(LmShared *)shp;
+  const TickChainArgs ca = *(const TickChainArgs *)cap; // (an LDS copy: a by-value struct would go through the stack of EVERY workgroup of the launch)
+  if (lane == 0) {
+    if (rounds > 1) sh.st.ticks -= rounds - 1;
+    sh.st.stepped = 1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  stage_out(&ca.states[prob], sh.st, lane, 64);
+  tick_after_step(MODE, prob, ca.trackers, ca.states, sh.st, sh.trk, ca.next, ca.mc, ca.pending, ca.results, ca.slot_ticket, lane, 1);
+}
+
+// The tick's evaluation launch.  Items [0, count): (problem, chunk) evaluations of all levels mixed, their partials go to memory for
+// tick_lm_kernel.  Chain entries [cap, cap + chain): problems whose pending evaluation is ONE chunk (the small pyramid levels -- half of
+// a frame's LM rounds on the metric's pyramid, every level of a semi-dense template).  Nothing but this workgroup takes part in such a
+// round, so the workgroup that evaluates the chunk also steps the problem -- state and descriptor in LDS, the partial never leaves it --
+// and goes on to the NEXT round, for as long as the staged evaluation stays one chunk (at most max_rounds): the rounds that cost a frame
+// a tick each (two launches, one trip of the state through memory, a wait for the tick's largest item) cost an evaluation and a step.
+// Same chunk, same partial, same reduction order: bit-identical results.  The first workgroups of the grid take the chains (they run
+// longest), the others stride over the items.
+// CHAIN = false: the launch of a stream that never took in a problem the chains apply to (the host knows: dsm_stream's chain_possible) --
+// the items alone, without the chains' code, LDS and stack behind them (the streamed bench of dense templates measured 1.2 % slower
+// with them merely present: profiles/r06_ab_lm_opts.log).
+template <int MODE, bool CHAIN>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void tick_eval_kernel(const LMState *__restrict__ states,
                                                                                                   float *__restrict__ partials, int partial_stride,
                                                                                                   const unsigned *__restrict__ items,
-                                                                                                  TickSegCtl *__restrict__ seg, int buf) {
+                                                                                                  TickSegCtl *__restrict__ seg, int buf, int cap, TickChainArgs ca) {
   __shared__ float red[16][kNumSlots];
   const int n_items = ((const DSM_GLOBAL TickSegCtl *)seg)->count[buf];
-  // the other list was consumed by the previous tick's evaluation; this tick's LM launch appends to it
-  if (blockIdx.x == 0 && threadIdx.x == 0) seg->count[buf ^ 1] = 0;
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+  const int n_chain = CHAIN ? ((const DSM_GLOBAL TickSegCtl *)seg)->chain[buf] : 0;
+  int nc_wg = (int)(gridDim.x >> 1);
+  nc_wg = n_chain < nc_wg ? n_chain : nc_wg;
+  if (CHAIN && (int)blockIdx.x < nc_wg) {
+    __shared__ LmShared sh;
+    __shared__ __attribute__((aligned(16))) float part[kPartialStride];
+    __shared__ TickChainArgs s_ca;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_ca = ca;
+    for (int ci = blockIdx.x; ci < n_chain; ci += nc_wg) {
+      const int prob = (int)((const DSM_GLOBAL unsigned *)items)[cap + ci];
+      stage_in(sh.st, &ca.states[prob], tid, kThreads);
+      stage_in(sh.trk, ca.trackers[prob], tid, kThreads);
+      __syncthreads();
+      int rounds = 0;
+      for (;;) {
+        const int status = __builtin_amdgcn_readfirstlane(sh.st.status), lvl = __builtin_amdgcn_readfirstlane(sh.st.lvl);
+        const int spec_valid = __builtin_amdgcn_readfirstlane(sh.st.spec_valid);
+        EvalConsts c;
+        eval_consts_from_lds(sh.st.in, c);
+        const int nch = chunks_of(c.n, c.ppt);
+        // one more round while the staged evaluation is one chunk (or none: an empty level), up to the bound: every tick waits for its
+        // longest workgroup, and a chain that ran on alone would make every other resident problem wait (measured: the bound of 8)
+        if (status != ST_RUNNING || nch > 1 || spec_valid || rounds >= ca.max_rounds) break; // workgroup-uniform
+        if (nch == 1) {
+          if (lvl == 0)
+            eval_chunk<MODE, true>(c, 0, tid, true, red, part);
+          else
+            eval_chunk<MODE, false, true, 1>(c, 0, tid, true, red, part);
+          if (tid == 0) {
+            atomicAdd((unsigned long long *)&ca.mc->sched_evals[lvl], 1ull);
+            if (c.residual_only) atomicAdd((unsigned long long *)&ca.mc->sched_ro[lvl], 1ull);
+            atomicAdd((unsigned long long *)&ca.mc->sched_items[lvl], 1ull);
+          }
+        }
+        __syncthreads();
+        tick_chain_round<MODE>((DSM_LDS LmShared *)&sh, (const DSM_LDS float *)part, nch, lvl, tid, (ca.flags & 1) != 0);
+        rounds++;
+      }
+      if (tid < 64) tick_chain_finish<MODE>((DSM_LDS LmShared *)&sh, prob, rounds, (const DSM_LDS TickChainArgs *)&s_ca, tid);
+      __syncthreads(); // sh is restaged for the next entry
+    }
+    return;
+  }
+  for (int it = (int)blockIdx.x - nc_wg; it < n_items; it += (int)gridDim.x - nc_wg) {
     const unsigned item = ((const DSM_GLOBAL unsigned *)items)[it];
     if (item & kTickNoop) continue; // (workgroup-uniform)
     const bool cand = (item & kTickCand) != 0;
@@ -2382,77 +2585,73 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
 
 template <int MODE>
 __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **trackers, LMState *__restrict__ states, const float *__restrict__ partials,
-                                                             int partial_stride, unsigned *__restrict__ items_next, TickSegCtl *__restrict__ seg,
-                                                             int buf_next, int cap, TickModeCtl *__restrict__ mc, const TickPending *__restrict__ pending,
-                                                             TickResult *__restrict__ results, unsigned long long *__restrict__ slot_ticket, int speculate) {
+                                                             int partial_stride, TickList next, TickModeCtl *__restrict__ mc,
+                                                             const TickPending *__restrict__ pending, TickResult *__restrict__ results,
+                                                             unsigned long long *__restrict__ slot_ticket, int speculate, int opts) {
   const int prob = blockIdx.x, tid = threadIdx.x;
   LMState &S = states[prob];
   __shared__ LmShared sh;
   __shared__ LmSpecShared sps;
+  // the list this tick's evaluation launch consumed (every workgroup of it has finished): empty again for the tick after the next.
+  // (Not by the evaluation launch itself: its chains append to the other list while it runs.)
+  if (prob == 0 && tid == 0) next.seg->count[next.buf ^ 1] = 0, next.seg->chain[next.buf ^ 1] = 0;
   // ONE round trip for everything the step must know before it can ask for the partials: the slot's status and kind, the level and point
   // count of the pending evaluation, the tracker pointer -- and this thread's block of the state itself
   LmPre pre;
-  const int s_status = S.status, s_kind = S.is_scale, lvl = S.lvl;
+  const int s_status = S.status, s_kind = S.is_scale, lvl = S.lvl, s_stepped = S.stepped;
   pre.n_lvl = S.in.n, pre.ppt_lvl = S.in.ppt, pre.have_sv = true;
   const TrackerDev *Tg = trackers[prob];
   pre.sv = tid < kLmS16 ? ((const uint4 *)&S)[tid] : uint4{0, 0, 0, 0};
+  if (s_stepped) { // a chain of this tick's evaluation launch stepped the slot (and staged, retired or refilled it)
+    if (tid == 0) S.stepped = 0;
+    return;
+  }
   if (!(s_status == ST_RUNNING && s_kind == MODE)) return; // a free slot (refilled by the next advance's admit launch)
   // the speculative second candidate (dsm_params.speculate): on the small levels, as in the launch form (a tick's launch is
   // never bound by the doubled rows of a few small problems)
   const bool spec_lvl = speculate >= 2 || (speculate == 1 && pre.n_lvl <= 8192);
-  lm_step_block(MODE, lvl, prob, Tg, S, partials + (size_t)prob * partial_stride, sh, tid, nullptr, spec_lvl ? &sps : nullptr, partial_stride >> 1, &pre);
+  TickReserve rsv{next, 0, 0};
+  lm_step_block<false, TickReserve>(MODE, lvl, prob, Tg, S, partials + (size_t)prob * partial_stride, sh, tid, nullptr, spec_lvl ? &sps : nullptr,
+                                    partial_stride >> 1, &pre, (opts & 2) ? &rsv : nullptr, (opts & 1) != 0);
   if (tid >= 64) return;
-  const int lane = tid;
-  if (sh.st.status == ST_RUNNING) {
-    tick_push(sh.st, prob, items_next, seg, buf_next, cap, mc, lane);
-    return;
-  }
-  // the problem terminated: its result, then the slot takes the next waiting problem
-  if (lane == 0) {
-    const long long r = (long long)atomicAdd((unsigned long long *)&mc->retired, 1ull); // monotonic; the host never lets more problems in than the result ring has room for
-    {
-      TickResult &R = results[r & (mc->ring - 1)];
-      const LMState &F = sh.st;
-      R.ticket = slot_ticket[prob];
-      R.status = F.status;
-      for (int i = 0; i < 7; i++) R.cur[i] = F.cur[i];
-      R.aff_cur[0] = F.aff_cur[0], R.aff_cur[1] = F.aff_cur[1];
-      R.flow[0] = F.flow[0], R.flow[1] = F.flow[1], R.flow[2] = F.flow[2];
-      R.scale_cur = F.scale_cur;
-      for (int l = 0; l < DSM_MAX_LEVELS; l++) {
-        R.last_residuals[l] = F.last_residuals[l];
-        R.evals[l] = F.evals[l], R.evals_ro[l] = F.evals_ro[l], R.rounds[l] = F.rounds[l];
-      }
-    }
-  }
-  tick_try_admit(MODE, prob, trackers, states, sh.st, sh.trk, items_next, seg, buf_next, cap, mc, pending, slot_ticket, lane);
+  const int res_base = __builtin_amdgcn_readfirstlane(rsv.base);
+  tick_after_step(MODE, prob, trackers, states, sh.st, sh.trk, next, mc, pending, results, slot_ticket, tid, 0, res_base, rsv.total);
 }
 
 void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, long long *admit_idx) {
   hipLaunchKernelGGL(tick_reserve_kernel, dim3(1), dim3(256), 0, s, a, states, mcs, admit_idx);
 }
-void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, unsigned *items, TickSegCtl *seg,
-                       int buf, int items_cap, TickModeCtl *mc, const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx) {
-  hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, items, seg, buf, items_cap, mc, pending, slot_ticket,
-                     admit_idx);
+void launch_tick_admit(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const TickList &list, TickModeCtl *mc,
+                       const TickPending *pending, unsigned long long *slot_ticket, const long long *admit_idx) {
+  hipLaunchKernelGGL(tick_admit_kernel, dim3(nslots), dim3(64), 0, s, mode, trackers, states, list, mc, pending, slot_ticket, admit_idx);
 }
 void launch_tick_eval(hipStream_t s, int mode, int grid, const LMState *states, float *partials, int partial_stride, const unsigned *items,
-                      TickSegCtl *seg, int buf) {
-  if (grid < 1) grid = 1;
-  if (mode == 0)
-    hipLaunchKernelGGL((tick_eval_kernel<0>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf);
+                      TickSegCtl *seg, int buf, int cap, const TickChainArgs &chain, bool with_chains) {
+  if (grid < 2) grid = 2; // (at least one workgroup for the items beside one for the chains)
+  if (mode == 0 && with_chains)
+    hipLaunchKernelGGL((tick_eval_kernel<0, true>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf, cap, chain);
+  else if (mode == 0)
+    hipLaunchKernelGGL((tick_eval_kernel<0, false>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf, cap, chain);
+  else if (with_chains)
+    hipLaunchKernelGGL((tick_eval_kernel<1, true>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf, cap, chain);
   else
-    hipLaunchKernelGGL((tick_eval_kernel<1>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf);
+    hipLaunchKernelGGL((tick_eval_kernel<1, false>), dim3(grid), dim3(kThreads), 0, s, states, partials, partial_stride, items, seg, buf, cap, chain);
 }
 void launch_tick_lm(hipStream_t s, int mode, int nslots, const TrackerDev **trackers, LMState *states, const float *partials, int partial_stride,
-                    unsigned *items_next, TickSegCtl *seg, int buf_next, int items_cap, TickModeCtl *mc, const TickPending *pending,
-                    TickResult *results, unsigned long long *slot_ticket, int speculate) {
+                    const TickList &next, TickModeCtl *mc, const TickPending *pending, TickResult *results, unsigned long long *slot_ticket,
+                    int speculate, int opts) {
   if (mode == 0)
-    hipLaunchKernelGGL((tick_lm_kernel<0>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, items_next, seg,
-                       buf_next, items_cap, mc, pending, results, slot_ticket, speculate);
+    hipLaunchKernelGGL((tick_lm_kernel<0>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, next, mc, pending,
+                       results, slot_ticket, speculate, opts);
   else
-    hipLaunchKernelGGL((tick_lm_kernel<1>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, items_next, seg,
-                       buf_next, items_cap, mc, pending, results, slot_ticket, speculate);
+    hipLaunchKernelGGL((tick_lm_kernel<1>), dim3(nslots), dim3(kLmThreads), 0, s, trackers, states, partials, partial_stride, next, mc, pending,
+                       results, slot_ticket, speculate, opts);
+}
+
+int lm_spin_expired() {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lm_spin_expired), sizeof v) != hipSuccess) return -1;
+  return v;
 }
 
 void launch_lm(hipStream_t s, int mode, int op, int lvl, int nprob, const TrackerDev *const *trackers,

@@ -259,6 +259,8 @@ public:
     return ticket;
   }
   void advance() { check(dsm_stream_advance(s_), "dsm_stream_advance"); }
+  // LM rounds a problem whose pending evaluation is one chunk may run inside one tick (dsm_stream_set_chain; 0 off, -1 the default)
+  void setChain(int max_rounds) { check(dsm_stream_set_chain(s_, max_rounds), "dsm_stream_set_chain"); }
   void drain() { check(dsm_stream_drain(s_), "dsm_stream_drain"); }
   // appends the problems retired so far; dsm_stream_result::pose / aff / good / last_residuals / flow are trackNewestCoarse's
   // outputs, scale / err optimizeScale's

@@ -231,6 +231,11 @@ class Stream:
         ticks = 0 keeps what is in force (initially: every advance sized by the stream from the retired problems' mean life)"""
         check(self.L.dsm_stream_set_engine(self.h, int(engine), int(ticks)))
 
+    def set_chain(self, max_rounds):
+        """tick engine: LM rounds a problem whose pending evaluation is ONE chunk may run inside one tick, in the workgroup that evaluates
+        it (dsm_stream_set_chain); 0 = off, -1 = the library's default.  Scheduling only."""
+        check(self.L.dsm_stream_set_chain(self.h, int(max_rounds)))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.dsm_stream_destroy(self.h)

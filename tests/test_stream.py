@@ -19,11 +19,16 @@ def _batch_reference(ctx, trks, nl, scales):
     return good, poses, affs, last, flow, err, sc, ev_t, ev_s
 
 
-def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1, engine=0, ticks=0, pipelined=True):  # noqa: PLR0913
+def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, quantile=None, waves=1, engine=0, ticks=0, pipelined=True, chain=None):  # noqa: PLR0913
     from direct_stereo_slam_amd.tracker import Stream
 
     n = len(trks)
     st = Stream(ctx, track_slots, scale_slots, engine, ticks)
+    chain_seq = None
+    if isinstance(chain, (list, tuple)):  # another setting before every advance
+        chain_seq = list(chain)
+    elif chain is not None:
+        st.set_chain(chain)
     if not pipelined:
         st.set_pipelined(False)
     if rounds is not None:
@@ -43,6 +48,8 @@ def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, qu
         ts = st.submit_scale([trks[i] for i in idx], scales[idx], nl - 1)
         for i, a, b in zip(idx, tk, ts):
             owner[a], owner[b] = ("track", i), ("scale", i)
+        if chain_seq:
+            st.set_chain(chain_seq[passes % len(chain_seq)])
         st.advance()
         passes += 1
         out += st.results()
@@ -51,6 +58,8 @@ def _stream_run(ctx, trks, nl, scales, track_slots, scale_slots, rounds=None, qu
         if resident == 0 and waiting == 0:
             break
         assert resident <= track_slots + scale_slots
+        if chain_seq:
+            st.set_chain(chain_seq[passes % len(chain_seq)])
         st.advance()
         passes += 1
         out += st.results()
@@ -113,6 +122,45 @@ def test_stream_results_equal_the_batch_calls_bit_for_bit(ctx, streams):
             _check(res, ref, len(trks), nl)
     finally:
         ctx.set_streams(1)
+
+
+def test_tick_engine_chains_are_scheduling_only(ctx):
+    """dsm_stream_set_chain: a problem whose pending evaluation is ONE chunk is evaluated AND stepped by one workgroup inside the
+    tick's evaluation launch, for up to max_rounds LM rounds in a row (the reference's loop, TrackerAndScaler.cpp:505-593, running in
+    place on the small levels).  Same chunk, same partial, same reduction order: every pose, residual, flag and per-level evaluation
+    count must equal the batch calls' -- with chains off, one round, a few, without bound, switched between advances, with slots
+    refilled inside a chain's tick, pose and scale problems alike -- and a frame must live fewer ticks."""
+    from direct_stereo_slam_amd.tracker import Stream
+
+    # dense templates of the small pyramid: level 0 has several chunks, levels 1-2 one; sparse templates: one chunk on every level
+    scs = [make_scene("small", seed=900 + i, template="dense" if i % 2 else "sparse", n0=2500) for i in range(16)]
+    nl = scs[0].nl
+    trks = [hip_tracker(ctx, sc) for sc in scs]
+    n = len(trks)
+    scales = np.linspace(0.85, 1.25, n).astype(np.float32)
+    ref = _batch_reference(ctx, trks, nl, scales)
+    for slots, sslots, ticks, waves, pipelined, chain in ((16, 16, 0, 1, True, 0), (16, 16, 0, 1, True, 1), (16, 16, 0, 1, True, 3), (16, 16, 0, 1, True, 4096),
+                                                        (5, 3, 3, 2, True, 4096), (4, 2, 1, 3, False, 2), (6, 4, 2, 2, True, [0, 4096, 1, 0, 5]), (3, 3, 64, 4, True, -1)):
+        res, _, _ = _stream_run(ctx, trks, nl, scales.copy(), slots, sslots, None, None, waves, engine=1, ticks=ticks, pipelined=pipelined, chain=chain)
+        _check(res, ref, n, nl)
+    # a frame's life in ticks: with chains the stream needs fewer ticks for the same problems (one tick per advance: advances = ticks)
+    need = {}
+    for chain in (0, 4096):
+        st = Stream(ctx, n, n, 1, 1)
+        st.set_chain(chain)
+        st.submit_track(trks, np.tile(S.IDENTITY_POSE, (n, 1)), np.zeros((n, 2)), nl - 1)
+        adv = 0
+        while True:
+            st.advance()
+            st.sync()
+            adv += 1
+            resident, waiting, _ = st.counts()
+            if resident == 0 and waiting == 0:
+                break
+            assert adv < 500
+        need[chain] = adv
+        st.close()
+    assert need[4096] < need[0], need
 
 
 def test_stream_with_fixed_schedule_and_mixed_coarsest_levels(ctx):

@@ -787,6 +787,8 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
     }
     dsm_host::Stream stream(ctx, S, std::min(8 * S, 256));
     if (!pipelined) dsm_host::check(dsm_stream_set_pipelined(stream.handle(), 0), "dsm_stream_set_pipelined");
+    if (const char *e = getenv("DSM_REPLAY_CHAIN")) stream.setChain(atoi(e)); // (experiments: the library's default otherwise)
+    if (const char *e = getenv("DSM_REPLAY_TICKS")) dsm_host::check(dsm_stream_set_engine(stream.handle(), 1, atoi(e)), "dsm_stream_set_engine");
     std::map<uint64_t, std::pair<int, int>> owner; // ticket -> (sequence, index of the scale guess or -1 for the frame's tracking)
     int n_done = 0;
     auto left_id = [&](int s, int i) { return (long long)s * 100000000LL + i; };
