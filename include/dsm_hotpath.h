@@ -406,13 +406,19 @@ int dsm_stream_counts(dsm_stream *s, int *resident_out, int *waiting_out, int *r
  * Both are scheduling only: results are bit-identical to the batch calls. */
 int dsm_stream_set_engine(dsm_stream *s, int engine, int ticks_per_advance);
 /* Tick engine, CHAINS (round 6): a problem whose pending evaluation is ONE chunk (a pyramid level of at most 4096 template points under
- * the default chunk table: the two coarsest levels of the metric's dense pyramid -- half of a frame's LM rounds --, every level of a
- * semi-dense template) needs no other workgroup for its round, so the workgroup that evaluates the chunk also steps the problem (state
- * in LDS, the partial never leaves it) and runs the NEXT round too, up to max_rounds rounds inside one tick, while the staged evaluation
- * stays one chunk.  That is the reference's LM loop (TrackerAndScaler.cpp:505-593) running in place on the levels where it is a chain
- * of tiny steps: a frame lives about half as many ticks.  max_rounds 0: off (every round costs a tick); -1: the default
- * (DSM_STREAM_CHAIN_DEFAULT).  Scheduling only: same chunk, same partial, same reduction order -- results are bit-identical
- * (tests/test_stream.py).  May be changed between advances. */
+ * the default chunk table: every level of a semi-dense template but the finest one or two; the two coarsest levels of the metric's
+ * dense pyramid) needs no other workgroup for its LM round, so the workgroup that evaluates the chunk also steps the problem -- state
+ * and descriptor in LDS, the partial never leaves it -- and runs the NEXT round too, up to max_rounds rounds inside one tick, for as long
+ * as the staged evaluation stays one chunk.  That is the reference's LM loop (TrackerAndScaler.cpp:505-593) running in place on the
+ * levels where it is a chain of tiny steps: such a frame lives a third of the ticks.
+ *   max_rounds > 0  every problem with a one-chunk evaluation chains, up to that many rounds per tick;
+ *   max_rounds 0    off: every round costs a tick;
+ *   max_rounds -1   the default: DSM_STREAM_CHAIN_DEFAULT rounds, for problems whose level-0 template has at most
+ *                   DSM_STREAM_CHAIN_DEFAULT_MAX_N0 points.  Measured: semi-dense templates (10 k points) + 31-33 %
+ *                   frames/s; dense templates gain nothing (their ticks wait for level 0's items, and a chain that runs longer than
+ *                   those makes every other resident problem wait), hence the rule.
+ * Scheduling only: same chunk, same partial, same reduction order -- results are bit-identical (tests/test_stream.py).  May be changed
+ * between advances. */
 #define DSM_STREAM_CHAIN_DEFAULT 8
 #define DSM_STREAM_CHAIN_DEFAULT_MAX_N0 65536 /* the default applies to problems whose level-0 template has at most this many points */
 int dsm_stream_set_chain(dsm_stream *s, int max_rounds);

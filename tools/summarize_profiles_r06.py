@@ -14,7 +14,7 @@ src, tag, dst = sys.argv[1], sys.argv[2], sys.argv[3]
 what = sys.argv[4] if len(sys.argv) > 4 else "all"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(dst, exist_ok=True)
-KERNEL = "tick_eval_kernel<0>"
+KERNEL = "tick_eval_kernel<0"  # (<0> in rounds 4-6; <0, false> / <0, true> since the chains: the launch without / with the chains' code)
 
 
 def last_json(path):
@@ -87,7 +87,7 @@ if fetch is not None and os.path.exists(os.path.join(src, "pmc_fetch.log")):
     wr = (write or 0.0) * 1024.0
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace -- python bench.py --quick --steps 2 --warmup 1",
-        "kernel_source_sha": kernel_source_sha(), "config": pb["config"]["name"], "kernel": "dsm::" + KERNEL, "engine": "ticks", "dispatches": nf,
+        "kernel_source_sha": kernel_source_sha(), "config": pb["config"]["name"], "kernel": "dsm::tick_eval_kernel<pose>", "engine": "ticks", "dispatches": nf,
         "frames_tracked_in_the_run": frames, "algorithmic_bytes": alg, "layout_bytes": lay,
         "FETCH_SIZE_bytes_raw": raw_fetch, "WRITE_SIZE_bytes_raw": wr,
         "correction": "the template stream (one global_load_dwordx4 per lane) is under-reported by 1/2 on gfx950 (MI355X_MICROARCH.md): half of its bytes added back; the tap gathers of the 4-byte intensity planes are taken as reported (calibration: r02_pmc_calibration.json)",
@@ -125,7 +125,7 @@ if trace and os.path.exists(os.path.join(src, "trace.log")):
     d = [e - s for s, e in iv]
     busy = union_ns(iv)
     summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --quick",
-               "kernel": "dsm::" + KERNEL, "dispatches": len(d), "avg_ns": sum(d) / max(1, len(d)), "sum_ns": sum(d), "union_ns": busy,
+               "kernel": "dsm::tick_eval_kernel<pose>", "dispatches": len(d), "avg_ns": sum(d) / max(1, len(d)), "sum_ns": sum(d), "union_ns": busy,
                "frames_tracked_in_the_run": frames, "algorithmic_bytes_of_the_run": alg,
                "achieved_GBps_from_trace": alg / max(1, busy), "achieved_GBps_bench_hip_events": tb["roofline"]["achieved"],
                "bench_avg_dispatch_us": tb["roofline"]["avg_launch_us"], "bench_value_frames_per_s": tb["value"],

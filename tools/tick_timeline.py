@@ -45,7 +45,7 @@ def short(n):
 
 # Pipelined advances leave no host gap between them: besides the gap-separated segments, the same table over a steady-state WINDOW --
 # the middle fifth of the run's tick_eval dispatches
-te = [e for e in ev if "tick_eval_kernel<0>" in e[2]]
+te = [e for e in ev if "tick_eval_kernel<0" in e[2]]
 if len(te) > 50:
     w0, w1 = te[int(0.4 * len(te))][0], te[int(0.6 * len(te))][1]
     win = [e for e in ev if e[0] >= w0 and e[1] <= w1]
