@@ -121,9 +121,10 @@ def _parse():
     ap.add_argument("--speculate", type=int, default=None, help="dsm_params.speculate (default: library default)")
     ap.add_argument("--compact", type=int, default=None, help="dsm_params.compact_tail (default: library default)")
     ap.add_argument("--fuse", type=int, default=None, help="dsm_params.fuse_lm (default: library default)")
-    ap.add_argument("--geometry", type=int, default=None, choices=(0, 1),
-                    help="dsm_params.chunk_geometry: 0 throughput table (library default), 1 latency table (what one frame in flight -- --batch 1, the replay adaptors -- uses)")
-    ap.add_argument("--coarse", type=int, default=None, help="persistent_coarse point threshold (0 = off; default: library default)")
+    ap.add_argument("--geometry", type=int, default=None, choices=(0, 1, 2),
+                    help="dsm_params.chunk_geometry: 0 throughput table (library default), 1 latency table, 2 latency table above 4096 points and one chunk below "
+                         "(one frame in flight -- --batch 1 --coarse -1, the replay adaptors)")
+    ap.add_argument("--coarse", type=int, default=None, help="dsm_params.persistent_coarse: N > 0 the LDS-resident small-level kernel up to N pixels, -1 the one-chunk levels as a chain (one launch), 0 off (library default)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="upper bound of the frames timed on the CPU baseline (rank 0, N=1); the leg stops after --cpu-seconds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the single-core CPU baseline leg once --cpu-min-frames are done")
     ap.add_argument("--cpu-min-frames", type=int, default=448, help="distinct frames the single-core CPU leg covers at least (the ATE half of the metric is taken over them)")
@@ -743,7 +744,7 @@ def measure_stream(args, ctx, wl, steps, warmup, world):
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     frames = B * steps
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": 0, "adaptive_schedule": True, "persistent_coarse": int(wl["params"].persistent_coarse),
-              "chunk_geometry": ("throughput table (library default)", "latency table")[int(wl["params"].chunk_geometry)],
+              "chunk_geometry": ("throughput table (library default)", "latency table", "chain table (latency table above 4096 points, one chunk below)")[int(wl["params"].chunk_geometry)],
               "streams": args.streams,
               "form": ("stream, tick engine (dsm_stream_*: every resident problem advances one LM round per tick, admission and retirement on the device; "
                        "a step submits its frames and runs one advance, the pool is drained after the last step)") if ticks else
@@ -896,7 +897,7 @@ def measure(args, ctx, wl, steps, warmup, world, with_upload=False):
     terr_all = np.abs(poses[:, 4:] - wl["gts"][:, 4:]).max(1)
     detail = {"frames_in_flight_per_gpu": B, "work_queue_blocks": int(stt.queue_blocks), "adaptive_schedule": not args.no_adaptive,
               "persistent_coarse": int(wl["params"].persistent_coarse), "streams": args.streams,
-              "chunk_geometry": ("throughput table (library default)", "latency table")[int(wl["params"].chunk_geometry)],
+              "chunk_geometry": ("throughput table (library default)", "latency table", "chain table (latency table above 4096 points, one chunk below)")[int(wl["params"].chunk_geometry)],
               "launch_pairs_per_step": int(sum(stt.launches) + sum(sts.launches)), "readbacks_per_step": int(stt.polls + sts.polls),
               "evals_per_frame_by_level": [stt.evals[l] / B for l in range(wl["nl"])],
               "algorithmic_MB_per_frame": all_bytes / B / 1e6,

@@ -386,8 +386,8 @@ static int tracker_create_fill(dsm_tracker *t, dsm_context *ctx, int w, int h, i
     if (params->struct_size != sizeof(dsm_params))
       return invalid("dsm_params.struct_size does not match this library's dsm_params: the caller was built against another "
                      "version of dsm_hotpath.h (use dsm_params_default, compare dsm_abi_version() with DSM_ABI_VERSION)");
-    if (params->chunk_geometry != 0 && params->chunk_geometry != 1)
-      return invalid("dsm_params.chunk_geometry: 0 (throughput table) or 1 (latency table)");
+    if (params->chunk_geometry < 0 || params->chunk_geometry > 2)
+      return invalid("dsm_params.chunk_geometry: 0 (throughput table), 1 (latency table) or 2 (latency table, one chunk up to 4096 points)");
     t->params = *params;
   } else {
     dsm_params_default(&t->params);
@@ -1302,7 +1302,7 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
   {
     int bucket = 0;
     for (int v = N; v >= 4; v >>= 2) bucket++;
-    const int key = bucket * 4 + (use_queue ? 2 : 0) + (P.persistent_coarse > 0 ? 1 : 0);
+    const int key = bucket * 4 + (use_queue ? 2 : 0) + (P.persistent_coarse != 0 ? 1 : 0);
     if (key != ctx->sched_bulk_key) {
       for (int m = 0; m < 3; m++)
         for (int l = 0; l < DSM_MAX_LEVELS; l++) ctx->sched_bulk[m][l] = 1 << 30;
@@ -1318,6 +1318,39 @@ static int run_lm_batch(dsm_context *ctx, int n, dsm_tracker *const *ts, int mod
     if (rc) return rc;
   }
   int top = coarsest, top2 = n2 > 0 ? coarsest : -1;
+  if (!use_queue && P.persistent_coarse < 0) {
+    // Small levels as a CHAIN (chain_kernel): every problem whose evaluation at the coarsest level is one chunk runs its LM loop in one
+    // launch, down to its first level of several chunks.  One launch per stream group and one for the companion segment.
+    auto one_chunk = [&](int i, int L) { return level_chunks(ts[i]->desc, L) <= 1; };
+    bool any = false;
+    for (int i = 0; i < N && !any; i++) any = one_chunk(i, coarsest);
+    if (any) {
+      if (ng > 1 || top2 >= 0) {
+        DSM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+        for (int g = 1; g < ng; g++) DSM_HIP(hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork_event, 0));
+        if (top2 >= 0) DSM_HIP(hipStreamWaitEvent(ctx->companion_stream, ctx->fork_event, 0));
+      }
+      for (int g = 0; g < ng; g++) {
+        const int g0 = (int)((long long)n * g / ng), g1 = (int)((long long)n * (g + 1) / ng);
+        if (g1 <= g0) continue;
+        launch_chain(g == 0 ? ctx->stream : ctx->extra_streams[g - 1], mode, g1 - g0, ctx->d_tracker_ptrs + g0, ctx->d_states + g0, ctx->d_status + 2 * g0);
+      }
+      if (n2 > 0) launch_chain(ctx->companion_stream, mode2, n2, ctx->d_tracker_ptrs + n, ctx->d_states + n, ctx->d_status + 2 * n);
+      ctx->stats.coarse_launches = 1;
+      auto first_launch_level = [&](int i0, int i1) { // (the launch-per-step schedule starts at the first level some problem cannot chain through)
+        int t = -1;
+        for (int i = i0; i < i1; i++)
+          for (int L = coarsest; L > t; L--)
+            if (!one_chunk(i, L)) {
+              t = L;
+              break;
+            }
+        return t;
+      };
+      top = first_launch_level(0, n);
+      if (n2 > 0) top2 = first_launch_level(n, N);
+    }
+  }
   if (!use_queue && P.persistent_coarse > 0) {
     // Small levels: the whole LM loop in one launch per problem on LDS-resident data (coarse_kernel), one launch per stream
     // group and one for the companion segment.  A problem is handed back (still RUNNING) at the first level whose target

@@ -20,9 +20,11 @@ namespace dsm {
 //   latency (1): short chunks -- more workgroups per evaluation, each through sooner: ONE problem in flight (the replay adaptors):
 //     0.53 instead of 0.61 ms per frame there
 // Results differ between the tables in the last bits of the float sums only (another summation tree); integer outputs are identical.
-enum { kGeomThroughput = 0, kGeomLatency = 1 };
+//   chain (2, round 6): the latency table above 4096 points, ONE chunk up to 4096 (as the throughput table) -- one frame in flight whose
+//     small levels run as a chain (an LM loop inside one workgroup: chain_kernel, dsm_params.persistent_coarse < 0; the tick engine's chains)
+enum { kGeomThroughput = 0, kGeomLatency = 1, kGeomChain = 2 };
 __host__ __device__ inline int pts_per_thread(int n, int geom) {
-  if (geom == kGeomLatency) return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
+  if (geom == kGeomLatency || (geom == kGeomChain && n > 4096)) return n >= 256 * 1024 ? 16 : n >= 64 * 1024 ? 8 : n >= 16 * 1024 ? 4 : n >= 4 * 1024 ? 2 : 1;
   return n > 2048 ? 16 : n > 1024 ? 8 : n > 512 ? 4 : n > 256 ? 2 : 1;
 }
 // chunks of a list of n points at P points per thread
@@ -36,7 +38,7 @@ __host__ __device__ inline int num_chunks(int n, int geom) { return chunks_of(n,
 inline int max_chunks_upto(int cap) {
   int best = 0;
   const int edges[8] = {cap, 256 * 1024 - 1, 64 * 1024 - 1, 16 * 1024 - 1, 4 * 1024 - 1, 1023, 511, 255}; // (the latency table's edges; the throughput table's count grows with n)
-  for (int g = 0; g < 2; g++)
+  for (int g = 0; g < 3; g++)
     for (int e : edges)
       if (e <= cap && num_chunks(e, g) > best) best = num_chunks(e, g);
   return best;
@@ -165,6 +167,9 @@ int lm_spin_expired();
 void launch_coarse(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states,
                    int *status_out, int max_px, bool spec);
 bool coarse_level_fits(int w, int h, int n, int geom, int max_px);
+// the same for the levels whose evaluation is ONE chunk, without LDS staging (chain_kernel: the tick engine's chain as a launch of its
+// own, one workgroup per problem, until the problem reaches a level of several chunks or terminates; no speculative candidates)
+void launch_chain(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states, int *status_out);
 
 // row A4 / N3: makeCoarseDepthL0 on the device (template_kernels.hip), batched over the keyframes of a call
 struct TplJob {

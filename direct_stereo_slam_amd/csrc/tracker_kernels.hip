@@ -2618,6 +2618,55 @@ __global__ __launch_bounds__(kLmThreads) void tick_lm_kernel(const TrackerDev **
   tick_after_step(MODE, prob, trackers, states, sh.st, sh.trk, next, mc, pending, results, slot_ticket, tid, 0, res_base, rsv.total);
 }
 
+// chain_kernel: the chain of the tick engine as a launch of its own (dsm_params.persistent_coarse < 0: single calls -- one frame in
+// flight).  One workgroup per problem carries it through every level whose evaluation is ONE chunk -- evaluate, reduce, step, on the
+// LDS copy of the state -- and hands it back (still RUNNING) at the first level of several chunks: the coarse levels' rounds, each
+// a launch of 12-14 us in the launch-per-step form, cost an evaluation and a step.  Same chunk, same partial, same reduction order.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void chain_kernel(const TrackerDev *const *__restrict__ trackers,
+                                                                                              LMState *__restrict__ states, int *__restrict__ status_out) {
+  __shared__ float red[16][kNumSlots];
+  __shared__ LmShared sh;
+  __shared__ __attribute__((aligned(16))) float part[kPartialStride];
+  const int prob = blockIdx.x, tid = threadIdx.x;
+  LMState &S = states[prob];
+  if (!(S.status == ST_RUNNING && S.is_scale == MODE)) return; // workgroup-uniform
+  stage_in(sh.st, &S, tid, kThreads);
+  stage_in(sh.trk, trackers[prob], tid, kThreads);
+  __syncthreads();
+  int rounds = 0;
+  for (;;) {
+    const int status = __builtin_amdgcn_readfirstlane(sh.st.status), lvl = __builtin_amdgcn_readfirstlane(sh.st.lvl);
+    const int spec_valid = __builtin_amdgcn_readfirstlane(sh.st.spec_valid);
+    EvalConsts c;
+    eval_consts_from_lds(sh.st.in, c);
+    const int nch = chunks_of(c.n, c.ppt);
+    if (status != ST_RUNNING || nch > 1 || spec_valid) break; // workgroup-uniform
+    if (nch == 1) {
+      if (lvl == 0)
+        eval_chunk<MODE, true>(c, 0, tid, true, red, part);
+      else
+        eval_chunk<MODE, false, true, 1>(c, 0, tid, true, red, part);
+    }
+    __syncthreads();
+    tick_chain_round<MODE>((DSM_LDS LmShared *)&sh, (const DSM_LDS float *)part, nch, lvl, tid, true);
+    rounds++;
+  }
+  if (rounds > 0 && tid < 64) stage_out(&S, sh.st, tid, 64);
+  if (tid == 0 && status_out) {
+    status_out[2 * prob] = sh.st.status;
+    status_out[2 * prob + 1] = sh.st.lvl;
+  }
+}
+void launch_chain(hipStream_t s, int mode, int nprob, const TrackerDev *const *trackers, LMState *states, int *status_out) {
+  if (mode == 0)
+    hipLaunchKernelGGL((chain_kernel<0>), dim3(nprob), dim3(kThreads), 0, s, trackers, states, status_out);
+  else if (mode == 1)
+    hipLaunchKernelGGL((chain_kernel<1>), dim3(nprob), dim3(kThreads), 0, s, trackers, states, status_out);
+  else
+    hipLaunchKernelGGL((chain_kernel<2>), dim3(nprob), dim3(kThreads), 0, s, trackers, states, status_out);
+}
+
 void launch_tick_reserve(hipStream_t s, const TickReserveArgs &a, const LMState *states, TickModeCtl *mcs, long long *admit_idx) {
   hipLaunchKernelGGL(tick_reserve_kernel, dim3(1), dim3(256), 0, s, a, states, mcs, admit_idx);
 }

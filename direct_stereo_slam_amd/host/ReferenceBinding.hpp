@@ -45,7 +45,10 @@ public:
     dsm_params p;
     if (DSM_PARAMS_INIT(&p) != DSM_OK) throw std::runtime_error(dsm_last_error()); // (the size this host was compiled with)
     R::fill_params(p);
-    p.chunk_geometry = 1; // the reference tracks ONE frame at a time (FrontEnd.cpp:585-686): short chunks, an evaluation through sooner
+    // the reference tracks ONE frame at a time (FrontEnd.cpp:585-686): short chunks on the large levels (an evaluation through sooner), the
+    // levels of at most 4096 points as a chain -- their LM loop (:505-593) in one launch instead of one launch per round
+    p.chunk_geometry = 2;
+    p.persistent_coarse = -1;
     const float k1[4] = {K1(0, 0), K1(1, 1), K1(0, 2), K1(1, 2)}; // fx1_, fy1_, cx1_, cy1_ (:89-98)
     impl_.reset(new TrackerAndScaler(ctx, ww, hh, R::levels(), tfm_vec, k1, &p));
     for (int i = 0; i < 3; i++) lastFlowIndicators[i] = 1000; // :460

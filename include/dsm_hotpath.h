@@ -87,7 +87,13 @@ typedef struct dsm_params {
                                          (evaluate, step) launch pair per LM evaluation at every level.  Scheduling only --
                                          results are bit-identical.  Measured: neutral for hundreds of frames in
                                          flight (a third of the launches), slower for one frame (the launch form spreads a
-                                         level's chunks over many CUs). */
+                                         level's chunks over many CUs).
+                                         N < 0 (round 6): the CHAIN form for single calls -- every level whose evaluation is ONE chunk
+                                         (chunk_geometry) runs its LM loop in one launch per problem (evaluate, reduce, step on an LDS
+                                         copy of the state; global gathers, no speculative candidates), down to the first level of
+                                         several chunks, where the launch-per-step schedule takes over: one frame in flight saves a
+                                         launch per LM round of its coarse levels (with chunk_geometry 2: what the replay adaptors
+                                         set).  Scheduling only -- bit-identical under the same chunk table. */
   int fuse_lm;                        /* at pyramid levels >= 1 the evaluation kernel's last-arriving workgroup of a
                                          problem can perform the LM step itself (one launch per evaluation instead of
                                          two): 0 never, 1 (default) for batches of at most 8 problems (where it shortens
@@ -129,7 +135,10 @@ typedef struct dsm_params {
                                            small levels several short chunks; version 4's float sums there differ in their last bits.)
                                          1 LATENCY: 16 / 8 / 4 / 2 from 256 k / 64 k / 16 k / 4 k points, else 1 -- short chunks, more
                                            workgroups per evaluation, a single evaluation through sooner: ONE problem in flight
-                                           (the replay adaptors set it).  Rounds 1-4 used this table for everything.
+                                           Rounds 1-4 used this table for everything.
+                                         2 CHAIN (round 6): table 1 above 4096 points, ONE chunk up to 4096 points (as table 0): one problem
+                                           in flight whose small levels run as a chain (persistent_coarse < 0; the tick engine's chains):
+                                           what the replay adaptors set.
                                          Every form (single, batch, stream) follows the tracker's table: results of one tracker are
                                          bit-identical across forms; between the tables only the summation tree of the float sums
                                          differs (last bits), integer outputs are equal.  dsm_reduction_geometry reports the choice.

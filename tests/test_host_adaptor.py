@@ -46,7 +46,7 @@ def test_reference_binding_through_standin_types_equals_the_plain_adaptor(ctx, t
     sc = make_scene("small", seed=23)
     path = tmp_path / "fixture.bin"
     write_fixture(sc, path)
-    plain, bound = run_host("host_adaptor_demo", path, "1"), run_host("reference_binding_check", path)  # (the binding tracks one frame at a time: latency table)
+    plain, bound = run_host("host_adaptor_demo", path, "2"), run_host("reference_binding_check", path)  # (the binding tracks one frame at a time: chunk table 2; its chained small levels are scheduling only)
     a, b = json.loads(plain), json.loads(bound)
     assert a["good"] == 1
     a.pop("stream_results_equal")  # (the plain demo also exercises dsm_host::Stream)

@@ -553,13 +553,21 @@ def test_chunk_geometries_agree(ctx):
         np.testing.assert_allclose(poses[i], pose_o, atol=1e-4)
     # one scene under both tables: single evaluations agree in the integer outputs exactly
     a, b = hip_tracker(ctx, scs[0], prm[0]), hip_tracker(ctx, scs[0], prm[1])
+    p2 = default_params()
+    p2.chunk_geometry = 2  # the latency table above 4096 points, one chunk below (round 6: one frame in flight with chained small levels)
+    c = hip_tracker(ctx, scs[0], p2)
     differ = 0
     for lvl in range(scs[0].nl):
-        (rsa, Ha, ba, na), (rsb, Hb, bb, nb) = (t.calcResPose(lvl, scs[0].gt_pose, scs[0].gt_aff, 20.0) for t in (a, b))
+        (rsa, Ha, ba, na), (rsb, Hb, bb, nb), (rsc, Hc, bc, nc) = (t.calcResPose(lvl, scs[0].gt_pose, scs[0].gt_aff, 20.0) for t in (a, b, c))
         assert rsa[1] == rsb[1] and rsa[5] == rsb[5] and na == nb  # numTermsInE, saturated share, warped count
+        assert rsa[1] == rsc[1] and rsa[5] == rsc[5] and na == nc
         np.testing.assert_allclose(rsa[0], rsb[0], rtol=1e-5)
+        np.testing.assert_allclose(rsa[0], rsc[0], rtol=1e-5)
         np.testing.assert_allclose(Ha, Hb, rtol=0, atol=1e-5 * np.abs(Ha).max())
-        differ += a.reduction_geometry(lvl, len(scs[0].tpl[lvl][0]))[2] != b.reduction_geometry(lvl, len(scs[0].tpl[lvl][0]))[2]
+        np.testing.assert_allclose(Ha, Hc, rtol=0, atol=1e-5 * np.abs(Ha).max())
+        n_l = len(scs[0].tpl[lvl][0])
+        differ += a.reduction_geometry(lvl, n_l)[2] != b.reduction_geometry(lvl, n_l)[2]
+        assert c.reduction_geometry(lvl, n_l)[2] == (a if n_l <= 4096 else b).reduction_geometry(lvl, n_l)[2]
     assert differ > 0  # (the tables do cut this scene's levels differently)
 
 
@@ -612,6 +620,50 @@ def test_persistent_coarse_kernel_is_bit_identical(ctx, size, template):
         for a, b in zip(r0[1:], r1[1:]):
             np.testing.assert_array_equal(a, b)
         assert s0 == s1
+
+
+@pytest.mark.parametrize("size,template", [("small", "dense"), ("medium", "dense"), ("medium", "sparse"), ("kitti", "dense")])
+@pytest.mark.parametrize("geometry", [0, 2])
+def test_chain_kernel_is_bit_identical(ctx, size, template, geometry):
+    """persistent_coarse < 0: the levels whose evaluation is ONE chunk run their LM loop in one launch per problem (chain_kernel: the
+    tick engine's chain as a launch of its own; TrackerAndScaler.cpp:505-593 in place) and the launch-per-step schedule takes over at the
+    first level of several chunks.  Same chunk, partial and reduction order: every output bit-identical to the launch form under the
+    same chunk table, the evaluation counts equal -- for the throughput table and for table 2 (latency table above 4096 points, one chunk
+    below: what the replay adaptors select; its single evaluations against the other tables: test_chunk_geometries_agree)."""
+    from direct_stereo_slam_amd.tracker import default_params
+
+    sc = make_scene(size, seed=63, template=template, n0=12000)
+    out, evals, coarse = [], [], []
+    for chain in (0, -1):
+        p = default_params()
+        p.chunk_geometry = geometry
+        p.persistent_coarse = chain
+        trk = hip_tracker(ctx, sc, p)
+        r = trk.trackNewestCoarse(S.IDENTITY_POSE, [0, 0], sc.nl - 1)
+        st = ctx.stats()
+        evals.append(list(st.evals))
+        coarse.append(st.coarse_launches)
+        s = trk.optimizeScale(1.3, sc.nl - 1)
+        evals.append(list(ctx.stats().evals))
+        out.append((r, s))
+        # a batch of several problems through the same path (stream groups, the companion segment of track + scale)
+        if chain:
+            trks = [hip_tracker(ctx, make_scene(size, seed=64 + i, template=template, n0=12000), p) for i in range(3)]
+            p0 = default_params()
+            p0.chunk_geometry = geometry
+            refs = [hip_tracker(ctx, make_scene(size, seed=64 + i, template=template, n0=12000), p0) for i in range(3)]
+            a = ctx.track_and_scale_batch(trks, np.tile(S.IDENTITY_POSE, (3, 1)), np.zeros((3, 2)), sc.nl - 1, trks[:2], np.array([1.0, 1.2], np.float32))
+            b = ctx.track_and_scale_batch(refs, np.tile(S.IDENTITY_POSE, (3, 1)), np.zeros((3, 2)), sc.nl - 1, refs[:2], np.array([1.0, 1.2], np.float32))
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    n_coarsest = len(sc.tpl[0][sc.nl - 1])  # (tpl = [pc_u, pc_v, pc_idepth, pc_color], each a list over the levels)
+    assert coarse == [0, 1 if n_coarsest <= 4096 else 0], (coarse, n_coarsest)
+    (r0, s0), (r1, s1) = out
+    assert evals[2] == evals[0] and evals[3] == evals[1]
+    assert r0[0] == r1[0]
+    for a, b in zip(r0[1:], r1[1:]):
+        np.testing.assert_array_equal(a, b)
+    assert s0 == s1
 
 
 @pytest.mark.parametrize("size,template", [("small", "dense"), ("medium", "sparse"), ("kitti", "dense")])

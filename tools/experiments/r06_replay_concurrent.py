@@ -1,5 +1,5 @@
 """same-box A/B of the replay's concurrent leg (S sequences through ONE dsm_host::Stream from C++):
-python tools/experiments/r06_replay_concurrent.py S 'geometry,chain,ticks,pipelined[,streams]' ..."""
+python tools/experiments/r06_replay_concurrent.py S 'geometry,chain,ticks,pipelined[,coarse]' ..."""
 import json, os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as td:
         if ticks:
             env["DSM_REPLAY_TICKS"] = str(ticks)
         if len(cb) > 4:
-            env["DSM_REPLAY_STREAMS"] = str(cb[4])
+            env["DSM_REPLAY_COARSE"] = str(cb[4])
         p = subprocess.run([exe, pack, os.path.join(td, "o"), "gpu", str(S), str(pipe)], capture_output=True, text=True, timeout=900, env=env)
         if p.returncode != 0:
             print("S", S, cb, "FAILED", (p.stderr or p.stdout)[-400:])
@@ -26,6 +26,6 @@ with tempfile.TemporaryDirectory() as td:
         d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         c = d["concurrent"]
         g = d["gpu"]["stages_mean_ms"]
-        print("S", S, "geometry,chain,ticks,pipelined[,streams]", cb, "frames/s", round(c["frames_per_s"]), "latency ms", round(c["mean_frame_latency_ms"], 3), "advances", c["advances"],
+        print("S", S, "geometry,chain,ticks,pipelined[,coarse]", cb, "frames/s", round(c["frames_per_s"]), "latency ms", round(c["mean_frame_latency_ms"], 3), "advances", c["advances"],
               "diff vs one sequence", c.get("max_abs_trajectory_diff_vs_the_one_sequence_run_m"), "host/adv", {k: round(v, 3) for k, v in c["host_ms_per_advance_by_call"].items()},
-              "| one sequence: trackNewCoarse", round(g["trackNewCoarse"]["mean_ms"], 4), flush=True)
+              "| one sequence: trackNewCoarse", round(g["trackNewCoarse"]["mean_ms"], 4), "scale_opt", round(g["scale_opt"]["mean_ms"], 4), "per frame", round(g["per_frame"]["mean_ms"], 4), flush=True)

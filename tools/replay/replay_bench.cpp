@@ -203,11 +203,25 @@ struct TrackOut {
 };
 
 // ---- backend 1: the product through the C++ adaptors ----
-// dsm_params.chunk_geometry of every tracker of the replay: 1 (latency table: one frame of a sequence is in flight at a time) unless
-// DSM_REPLAY_GEOMETRY says otherwise; the one-sequence run and the concurrent run share it, so their results stay comparable bit for bit
+// dsm_params.chunk_geometry of every tracker of the replay: 2 (one frame of a sequence is in flight at a time: the latency table above 4096
+// points, one chunk below) unless DSM_REPLAY_GEOMETRY says otherwise; the one-sequence run and the concurrent run share it, so their
+// results stay comparable bit for bit.  dsm_params.persistent_coarse: -1 (the one-chunk levels' LM loop as a chain, one launch) unless
+// DSM_REPLAY_COARSE says otherwise.
+static int g_geometry_override = -1; // (the concurrent leg's table while that leg and its one-sequence reference run)
 static int replay_geometry() {
+  if (g_geometry_override >= 0) return g_geometry_override;
   const char *e = getenv("DSM_REPLAY_GEOMETRY");
+  return e ? atoi(e) : 2;
+}
+// the concurrent leg (many sequences through one stream: bound by the host's calls, its levels evaluated beside other sequences') keeps the
+// latency table, measured 4-5 % faster there than the tables with one-chunk small levels; DSM_REPLAY_CONC_GEOMETRY says otherwise
+static int replay_concurrent_geometry() {
+  const char *e = getenv("DSM_REPLAY_CONC_GEOMETRY");
   return e ? atoi(e) : 1;
+}
+static int replay_coarse() {
+  const char *e = getenv("DSM_REPLAY_COARSE");
+  return e ? atoi(e) : -1;
 }
 
 struct GpuBackend {
@@ -224,6 +238,7 @@ struct GpuBackend {
     dsm_params prm;
     dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
     prm.chunk_geometry = replay_geometry();
+    prm.persistent_coarse = replay_coarse();
     std::vector<double> tv(P.T, P.T + 16);
     a.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
     b.reset(new dsm_host::TrackerAndScaler(ctx, P.w, P.h, P.nl, tv, P.K, &prm));
@@ -774,6 +789,7 @@ static ConcurrentResult run_concurrent(const Pack &P, int S, bool pipelined) {
     dsm_params prm;
     dsm_host::check(DSM_PARAMS_INIT(&prm), "DSM_PARAMS_INIT");
     prm.chunk_geometry = replay_geometry();
+    prm.persistent_coarse = replay_coarse();
     std::vector<double> tv(P.T, P.T + 16);
     std::vector<Seq> seqs((size_t)S);
     for (int s = 0; s < S; s++) {
@@ -1161,7 +1177,7 @@ int main(int argc, char **argv) {
   const std::string prefix = argv[2];
   const int n_concurrent = argc > 4 ? atoi(argv[4]) : 0;
   const bool conc_pipelined = argc > 5 ? atoi(argv[5]) != 0 : true;
-  RunResult rg, rc;
+  RunResult rg, rc, rg_conc; // (rg_conc: the one-sequence reference of the concurrent leg, under that leg's chunk table)
   LoopReplay eq;
   bool have_eq = false;
   ConcurrentResult cc;
@@ -1191,8 +1207,18 @@ int main(int argc, char **argv) {
       dsm_host::save_trajectory((prefix + "_dslam_gpu.txt").c_str(), ids, centres(rg.est)); // LoopHandler.cpp:59-80
     }
     if (which != "cpu" && n_concurrent > 0) {
+      const int cg = replay_concurrent_geometry();
+      if (cg != replay_geometry()) { // another chunk table than the one-sequence run's: the float sums' last bits differ, so the leg is
+                                     // compared (bit for bit) with a one-sequence run under ITS table (untimed)
+        g_geometry_override = cg;
+        GpuBackend be(P);
+        rg_conc = run(be, P);
+      } else {
+        rg_conc = rg;
+      }
       (void)run_concurrent(P, n_concurrent, conc_pipelined); // untimed: schedules, allocators, the stream's learnt life of a problem
       cc = run_concurrent(P, n_concurrent, conc_pipelined);
+      g_geometry_override = -1;
     }
     if (which != "gpu") {
       CpuBackend be(P);
@@ -1260,18 +1286,19 @@ int main(int argc, char **argv) {
     bool scales_equal = true;
     for (const std::vector<SE3> &e : cc.est) {
       ate_max = std::fmax(ate_max, ate(e, P.gt));
-      for (size_t i = 0; i < e.size() && i < rg.est.size(); i++) {
-        const SE3 a = se3_inv(e[i]), b = se3_inv(rg.est[i]);
+      for (size_t i = 0; i < e.size() && i < rg_conc.est.size(); i++) {
+        const SE3 a = se3_inv(e[i]), b = se3_inv(rg_conc.est[i]);
         for (int c = 0; c < 3; c++) dmax = std::fmax(dmax, std::fabs(a.t[c] - b.t[c]));
       }
     }
-    for (const std::vector<float> &sc : cc.scales) scales_equal = scales_equal && sc == rg.scales;
+    for (const std::vector<float> &sc : cc.scales) scales_equal = scales_equal && sc == rg_conc.scales;
     printf(", \"concurrent\": {\"what\": \"%d sequences (the same frames, keyframes out of phase) through ONE dsm_host::Stream from C++: per sequence one problem in flight "
-           "(a frame's first hypothesis, or its keyframe's scale guesses), hand-over, setCoarseTrackingRef and tracker swap as in the one-sequence run; no loop descriptors\", "
+           "(a frame's first hypothesis, or its keyframe's scale guesses), hand-over, setCoarseTrackingRef and tracker swap as in the one-sequence run; no loop descriptors; "
+           "chunk table %d (compared bit for bit with a one-sequence run under the same table)\", "
            "\"sequences\": %d, \"pipelined_advances\": %s, \"frames\": %lld, \"wall_ms\": %.3f, \"frames_per_s\": %.1f, \"ms_per_frame_of_one_sequence\": %.4f, "
            "\"mean_frame_latency_ms\": %.4f, \"max_frame_latency_ms\": %.4f, \"advances\": %d, \"frames_through_the_whole_hypothesis_list\": %d, \"frames_lost\": %d, "
            "\"max_ate_vs_ground_truth_m\": %.6g, \"max_abs_trajectory_diff_vs_the_one_sequence_run_m\": %.6g, \"scales_equal_the_one_sequence_run\": %s",
-           cc.sequences, cc.sequences, conc_pipelined ? "true" : "false", cc.frames, cc.wall_ms, 1e3 * (double)cc.frames / cc.wall_ms,
+           cc.sequences, replay_concurrent_geometry(), cc.sequences, conc_pipelined ? "true" : "false", cc.frames, cc.wall_ms, 1e3 * (double)cc.frames / cc.wall_ms,
            cc.wall_ms * cc.sequences / (double)cc.frames, cc.latency_ms_sum / (double)cc.frames, cc.latency_ms_max, cc.advances, cc.fallbacks, cc.lost, ate_max, dmax,
            scales_equal ? "true" : "false");
     printf(", \"host_ms_per_advance_by_call\": {");
