@@ -121,8 +121,9 @@ struct dsm_stream {
   int chain_rounds = DSM_STREAM_CHAIN_DEFAULT;
   bool chain_possible = false; // a problem the chains apply to was submitted at some time (else the evaluation launches go without the chains' code)
   int chain_max_n0 = DSM_STREAM_CHAIN_DEFAULT_MAX_N0; // the default chains semi-dense problems only; a number named by the caller: every problem
-  int chain_flags = getenv("DSM_CHAIN_FLAGS") ? atoi(getenv("DSM_CHAIN_FLAGS")) : 1; // (experiments) bit 0: helper wave in a chain's LM step
-  int lm_opts = getenv("DSM_LM_OPTS") ? atoi(getenv("DSM_LM_OPTS")) : 3;             // (experiments) tick_lm_kernel: bit 0 helper waves, bit 1 early list reservation
+  // options of the tick kernels' LM step, both measured on (profiles/r06b_ab_lm_step.log, where they were switched through the environment):
+  int chain_flags = 1; // bit 0: helper wave in a chain's LM step
+  int lm_opts = 3;     // tick_lm_kernel: bit 0 helper waves, bit 1 the next items' place in the list reserved before the solve
   TickPending *d_pending[2] = {nullptr, nullptr}, *h_pending[2] = {nullptr, nullptr}; // waiting rings (device / pinned staging)
   TickResult *d_results[2] = {nullptr, nullptr}, *h_results[2] = {nullptr, nullptr};   // result rings (device / two pinned copies)
   int ring[2] = {0, 0};
