@@ -14,7 +14,7 @@ with tempfile.TemporaryDirectory() as td:
     bench.write_replay_pack(pack, "kitti00", 200, 4, 2000)
     for cb in combos:
         geom, chain, ticks, pipe = cb[:4]
-        env = dict(os.environ, DSM_REPLAY_GEOMETRY=str(geom), DSM_REPLAY_CHAIN=str(chain))
+        env = dict(os.environ, DSM_REPLAY_GEOMETRY=str(geom), DSM_REPLAY_CONC_GEOMETRY=str(geom), DSM_REPLAY_CHAIN=str(chain))  # (both legs under the table named)
         if ticks:
             env["DSM_REPLAY_TICKS"] = str(ticks)
         if len(cb) > 4:
